@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    class _G:
+        def __getitem__(self, name):
+            return np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    return _G()
+
+
+def seeded_randn(seed, *shape):
+    import torch
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
