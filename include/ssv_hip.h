@@ -1,0 +1,150 @@
+/*
+ * ssv_hip.h - C ABI of libssv_hip.so: the MI355X (gfx950) hot path of the two-view
+ * self-supervised training step.
+ *
+ * The reference (NightShade99/Self-Supervised-Vision) is pure Python/PyTorch and has NO
+ * FFI of its own: each entry point below replaces the implicit ATen / cuDNN
+ * call that a reference line issues, cited as "replaces <file:line>".  INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted;
+ *   - activations are NHWC fp32 ([N*H*W][C], C contiguous), filters are OHWI fp32
+ *     (= a torch [O,I,H,W] tensor in channels_last memory format);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only
+ *     enqueued, nothing synchronises, nothing is allocated, no pointer is kept after return;
+ *   - the caller owns every buffer including `ws` (size from the matching *_workspace_bytes);
+ *   - return 0 on success, a negative ssv_status otherwise; ssv_last_error() gives the
+ *     thread-local message.  Nothing throws across the ABI.
+ */
+#ifndef SSV_HIP_H
+#define SSV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ssv_status {
+  SSV_OK = 0,
+  SSV_ERR_INVALID = -1,     /* bad shape / null pointer / unsupported configuration */
+  SSV_ERR_WORKSPACE = -2,   /* workspace too small */
+  SSV_ERR_LAUNCH = -3       /* hipLaunch / hipGetLastError failure */
+} ssv_status;
+
+int ssv_version(void);
+const char* ssv_last_error(void);
+/* number of CUs of the current device (0 if no device) - host-side helper for grid sizing */
+int ssv_device_cus(void);
+
+/* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) -----------------
+ * replaces nn.Conv2d forward/backward issued at networks/resnet.py:39-40,68-70,147 and,
+ * with H=W=R=S=1, nn.Linear at models/simclr.py:34-35, models/byol.py:34, models/barlow.py:31-34 */
+typedef struct ssv_conv_desc {
+  int32_t N, H, W, C;      /* input  [N,H,W,C]            */
+  int32_t K, R, S;         /* filter [K,R,S,C]            */
+  int32_t stride, pad;     /* same in both spatial dims   */
+  int32_t Ho, Wo;          /* output [N,Ho,Wo,K]          */
+} ssv_conv_desc;
+
+/* y = conv(x, w) (+ bias[k]) (+ addend)            bias/addend may be NULL */
+int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias,
+                   const float* addend, float* y, void* stream);
+/* dx = conv_transpose(dy, w) (+ addend)            addend may alias dx (accumulate) or be NULL */
+int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend,
+                     float* dx, void* stream);
+/* dw (+)= x (*) dy     deterministic split-K over N*Ho*Wo through `ws`, then a fixed-order reduce */
+size_t ssv_conv2d_wgrad_workspace_bytes(const ssv_conv_desc* d);
+int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dw,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNorm (training mode, batch statistics) over rows of an [M][C] matrix ------------
+ * replaces nn.BatchNorm2d / nn.BatchNorm1d (+ReLU, + residual add) at networks/resnet.py:39-44,
+ * 68-74,147 and models/simclr.py:34-35.  C % 4 == 0.
+ * fwd: mean/var per channel (shifted sums per block, Chan merge in double), running stats with
+ * unbiased var, y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ). */
+size_t ssv_bn_workspace_bytes(int64_t M, int32_t C);
+int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
+                     const float* residual, int relu, float eps, float momentum,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* y, float* save_mean, float* save_invstd,
+                     void* ws, size_t ws_bytes, void* stream);
+/* bwd: g = dy * (y>0 if relu); dgamma (+)= sum g*xhat; dbeta (+)= sum g;
+ * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dresidual = g if not NULL. */
+int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const float* x,
+                     const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+                     float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,
+                     void* ws, size_t ws_bytes, void* stream);
+/* out[c] (+)= sum_m x[m][c]   (bias gradient of nn.Linear); same workspace size as BN */
+int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int accumulate,
+               void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pooling / layout --------------------------------------------------------------------
+ * replaces nn.MaxPool2d(3,2,1) networks/resnet.py:102,148 and AdaptiveAvgPool2d(1)+Flatten :107-108 */
+int ssv_maxpool3x3s2_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* x, float* y,
+                         uint8_t* argmax, void* stream);
+int ssv_maxpool3x3s2_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dy,
+                         const uint8_t* argmax, float* dx, void* stream);
+int ssv_gap_fwd(int32_t N, int32_t HW, int32_t C, const float* x, float* y, void* stream);
+int ssv_gap_bwd(int32_t N, int32_t HW, int32_t C, const float* dy, float* dx, void* stream);
+/* the reference boundary hands NCHW fp32 batches (models/simclr.py:87) */
+int ssv_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, const float* in, float* out, void* stream);
+int ssv_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float* in, float* out, void* stream);
+
+/* ---- F.normalize(p=2, dim=-1) : utils/losses.py:20-22, models/byol.py:47,59, models/barlow.py:35
+ * zhat is written with row stride ldo >= D, columns [D, ldo) zero-filled.  normalize=0 copies. */
+int ssv_l2norm_fwd(int32_t rows, int32_t D, const float* z, int32_t normalize, float eps,
+                   float* zhat, int32_t ldo, float* inv_norm, void* stream);
+/* dz = (dzhat - zhat*(zhat.dzhat)) * inv_norm       (normalize=0: dz = dzhat) */
+int ssv_l2norm_bwd(int32_t rows, int32_t D, const float* zhat, int32_t ldz, const float* inv_norm,
+                   const float* dzhat, int32_t ldd, int32_t normalize, float* dz, void* stream);
+
+/* ---- NT-Xent : SimclrLoss.forward utils/losses.py:15-46 in Gram / log-sum-exp form --------
+ * Z is the (gathered) [2*Nglob][ldz] matrix [zi_all ; zj_all] (ldz % 32 == 0, ldz <= 128,
+ * pad columns zero).  This rank owns local rows lr in [0, 2*Bloc): global row
+ * r = seg0 + lr (lr < Bloc) or Nglob + seg0 + (lr - Bloc).
+ * fwd: lse[lr] = logsumexp_{c != r} Z_r.Z_c * inv_temp ; pos[lr] = Z_r.Z_pos(r) * inv_temp.
+ * loss = sum_lr (lse - pos) / (2*Nglob)  (ssv_ntxent_loss; all-reduce SUM across ranks).
+ * bwd: needs lse of ALL 2*Nglob rows (all-gathered); writes dZ for the local rows:
+ *   dZ_r = gscale * ( sum_{c != r} (e^{S_rc-lse_r} + e^{S_rc-lse_c}) Z_c - 2 Z_pos(r) ),
+ *   gscale = dloss * inv_temp / (2*Nglob). */
+int ssv_ntxent_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                   float inv_temp, float* lse, float* pos, void* stream);
+int ssv_ntxent_loss(int32_t rows, const float* lse, const float* pos, float scale, float* loss, void* stream);
+int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                   const float* lse_all, float inv_temp, float gscale, float* dZ, void* stream);
+
+/* ---- BYOL loss: nn.MSELoss pair models/byol.py:89,129-130 on [B][D] matrices ---------------
+ * loss = (sum (o1-t2)^2 + sum (o2-t1)^2) / (B*D); do1 = 2*(o1-t2)*gscale, do2 likewise. */
+int ssv_mse_pair_fwd_bwd(int64_t n, const float* o1, const float* o2, const float* t1, const float* t2,
+                         float inv_count, float* loss, float* do1, float* do2,
+                         void* ws, size_t ws_bytes, void* stream);
+size_t ssv_reduce_workspace_bytes(int64_t n);
+/* x[i] *= *factor_dev (factor read on the device: no host sync) - chain-rule scale by an upstream grad */
+int ssv_scale(int64_t n, float* x, const float* factor_dev, void* stream);
+
+/* ---- optimizer: optim.SGD(momentum=0.9, nesterov=True, weight_decay) utils/train_utils.py:11-13
+ * over a flat arena of n floats.  first_step != 0 seeds buf = g. */
+int ssv_sgd_nesterov(int64_t n, float* p, const float* g, float* buf, float lr, float weight_decay,
+                     float momentum, int first_step, void* stream);
+/* BYOL.momentum_update models/byol.py:120-123: t = tau*t + (1-tau)*o over n floats */
+int ssv_ema(int64_t n, float* target, const float* online, float tau, void* stream);
+int ssv_fill(int64_t n, float* p, float value, void* stream);
+/* dst[i] += src[i]  (gradient accumulation where no producer kernel can fuse it) */
+int ssv_add(int64_t n, float* dst, const float* src, void* stream);
+
+/* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
+ * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
+ * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */
+enum { SSV_PROF_CONV_FWD = 0, SSV_PROF_CONV_DGRAD, SSV_PROF_CONV_WGRAD, SSV_PROF_BN_FWD, SSV_PROF_BN_BWD,
+       SSV_PROF_POOL, SSV_PROF_LOSS, SSV_PROF_OPTIM, SSV_PROF_AUG, SSV_PROF_MISC, SSV_PROF_NCLASS };
+int ssv_prof_enable(int on);
+int ssv_prof_reset(void);
+int ssv_prof_collect(double* ms_per_class, int64_t* launches_per_class);   /* HOST arrays [SSV_PROF_NCLASS] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSV_HIP_H */

@@ -1,0 +1,137 @@
+"""ctypes binding of libssv_hip.so (include/ssv_hip.h) - the only door into the HIP hot path.
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+torch is used for device memory and the current HIP stream only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libssv_hip.so")
+
+PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc")
+
+
+class SsvError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_cd = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/ssv_hip.h one to one
+SIGNATURES = {
+    "ssv_version": (C.c_int, []),
+    "ssv_last_error": (C.c_char_p, []),
+    "ssv_device_cus": (C.c_int, []),
+    "ssv_conv2d_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_dgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
+    "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_bn_workspace_bytes": (_sz, [_i64, _i32]),
+    "ssv_bn_train_fwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssv_bn_train_bwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_colsum": (C.c_int, [_i64, _i32, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_maxpool3x3s2_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ssv_maxpool3x3s2_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ssv_gap_fwd": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssv_gap_bwd": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssv_nchw_to_nhwc": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssv_nhwc_to_nchw": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssv_l2norm_fwd": (C.c_int, [_i32, _i32, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),
+    "ssv_l2norm_bwd": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ssv_ntxent_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
+    "ssv_ntxent_loss": (C.c_int, [_i32, _vp, _vp, _f32, _vp, _vp]),
+    "ssv_ntxent_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "ssv_reduce_workspace_bytes": (_sz, [_i64]),
+    "ssv_mse_pair_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssv_scale": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "ssv_sgd_nesterov": (C.c_int, [_i64, _vp, _vp, _vp, _f32, _f32, _f32, C.c_int, _vp]),
+    "ssv_ema": (C.c_int, [_i64, _vp, _vp, _f32, _vp]),
+    "ssv_fill": (C.c_int, [_i64, _vp, _f32, _vp]),
+    "ssv_add": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "ssv_prof_enable": (C.c_int, [C.c_int]),
+    "ssv_prof_reset": (C.c_int, []),
+    "ssv_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once) and attach the signatures.  Raises SsvError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsvError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"(or `make -C {os.path.dirname(LIB_PATH)}`); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SsvError(f"{what} failed ({rc}): {load().ssv_last_error().decode()}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SsvError("libssv_hip operates on device tensors only (got a CPU tensor); there is no CPU fallback")
+
+
+def call(name, *args):
+    _check(getattr(load(), name)(*args), name)
+
+
+# ------------------------------------------------------------------------------------------- workspace
+class _Workspace:
+    """One grow-only scratch buffer per device (torch caching allocator owns the memory)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        b = self.buf.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[device] = b
+        return b
+
+
+workspace = _Workspace()
+
+
+# ------------------------------------------------------------------------------------------- profiling
+def prof_enable(on=True):
+    call("ssv_prof_enable", int(bool(on)))
+
+
+def prof_reset():
+    call("ssv_prof_reset")
+
+
+def prof_collect():
+    ms = (C.c_double * len(PROF_CLASSES))()
+    n = (C.c_int64 * len(PROF_CLASSES))()
+    call("ssv_prof_collect", ms, n)
+    return {k: (ms[i], n[i]) for i, k in enumerate(PROF_CLASSES)}

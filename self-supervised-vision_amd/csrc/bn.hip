@@ -1,0 +1,330 @@
+// Training-mode BatchNorm over the rows of an [M][C] fp32 matrix (NHWC activations: M = N*H*W),
+// fused with ReLU and the residual add, plus the column-sum used for Linear bias gradients.
+// All of it is HBM-streaming work: float4 per lane along C (coalesced rows), every thread keeps
+// its channel group fixed and walks rows, per-block partials are merged in a FIXED order
+// (deterministic) with double precision in the finalize kernels.
+//
+// Statistics: per block shifted sums  S1 = sum(x-K), S2 = sum((x-K)^2)  with K = first row of the
+// block (kills the E[x^2]-E[x]^2 cancellation), turned into (mean_b, M2_b) and merged with Chan's
+// formula in double - the same accumulation width ATen's CPU batch_norm uses (acc_type<float> = double).
+#include "common.h"
+
+namespace {
+
+struct BnPlan { int C4, CT, RT, GY, rpb, nblk; };
+
+BnPlan bn_plan(int64_t M, int C) {
+  BnPlan p;
+  p.C4 = C / 4;
+  p.CT = p.C4 < 256 ? p.C4 : 256;
+  p.RT = 256 / p.CT;
+  p.GY = cdiv(p.C4, p.CT);
+  int64_t rpb = cdiv64(M, 1024);
+  const int64_t min_rows = (int64_t)p.RT * 4;
+  if (rpb < min_rows) rpb = min_rows;
+  p.rpb = (int)rpb;
+  p.nblk = (int)cdiv64(M, rpb);
+  return p;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---- forward statistics ----------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bn_stats_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ x, float* __restrict__ pmean, float* __restrict__ pm2) {
+  __shared__ f32x4 sm1[256], sm2[256];
+  const int tid = threadIdx.x;
+  const int ct = tid % CT, rt = tid / CT;
+  const int c4 = blockIdx.y * CT + ct;
+  const bool active = rt < RT && c4 < C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, K = {0, 0, 0, 0};
+  if (active) {
+    K = ld4(x + r0 * C + 4 * c4);
+    for (int64_t r = r0 + rt; r < r1; r += RT) {
+      const f32x4 v = ld4(x + r * C + 4 * c4) - K;
+      s1 += v; s2 += v * v;
+    }
+  }
+  sm1[tid] = s1; sm2[tid] = s2;
+  __syncthreads();
+  if (active && rt == 0) {
+    for (int j = 1; j < RT; ++j) { s1 += sm1[j * CT + ct]; s2 += sm2[j * CT + ct]; }
+    const float n = (float)(r1 - r0);
+    const f32x4 mean = K + s1 / n;
+    const f32x4 m2 = s2 - s1 * s1 / n;
+    st4(pmean + (size_t)blockIdx.x * C + 4 * c4, mean);
+    st4(pm2 + (size_t)blockIdx.x * C + 4 * c4, m2);
+  }
+}
+
+// one thread per (channel, merge group); 4 groups merged through LDS in fixed order
+__global__ void __launch_bounds__(256)
+bn_stats_finalize_k(int64_t M, int C, int rpb, int nblk, const float* __restrict__ pmean, const float* __restrict__ pm2,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* nbt,
+                    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double sn[4][64], smean[4][64], sm2[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  if (c < C) {
+    const int per = (nblk + 3) / 4;
+    const int b0 = grp * per, b1 = min(b0 + per, nblk);
+    for (int b = b0; b < b1; ++b) {
+      const int64_t rb0 = (int64_t)b * rpb;
+      const double nb = (double)((rb0 + rpb < M ? rb0 + rpb : M) - rb0);
+      const double mb = (double)pmean[(size_t)b * C + c], m2b = (double)pm2[(size_t)b * C + c];
+      const double nt = n + nb, delta = mb - mean;
+      mean += delta * nb / nt;
+      m2 += m2b + delta * delta * n * nb / nt;
+      n = nt;
+    }
+  }
+  sn[grp][cl] = n; smean[grp][cl] = mean; sm2[grp][cl] = m2;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    for (int g = 1; g < 4; ++g) {
+      const double nb = sn[g][cl];
+      if (nb > 0.0) {
+        const double nt = n + nb, delta = smean[g][cl] - mean;
+        mean += delta * nb / nt;
+        m2 += sm2[g][cl] + delta * delta * n * nb / nt;
+        n = nt;
+      }
+    }
+    const double var = m2 / (double)M;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    save_mean[c] = fmean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - fmean * sc;
+    if (running_mean) {
+      const float unbiased = (float)(M > 1 ? m2 / (double)(M - 1) : var);
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (nbt && c == 0) *nbt += 1;
+  }
+}
+
+template <bool RELU, bool RES>
+__global__ void __launch_bounds__(256)
+bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ x, const float* __restrict__ scale,
+           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y) {
+  const int tid = threadIdx.x;
+  const int ct = tid % CT, rt = tid / CT;
+  const int c4 = blockIdx.y * CT + ct;
+  if (rt >= RT || c4 >= C / 4) return;
+  const f32x4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
+  for (int64_t r = r0 + rt; r < r1; r += RT) {
+    const size_t o = (size_t)r * C + 4 * c4;
+    f32x4 v = ld4(x + o) * sc + sh;
+    if constexpr (RES) v += ld4(res + o);
+    if constexpr (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    st4(y + o, v);
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+template <bool RELU>
+__device__ __forceinline__ f32x4 masked(f32x4 g, f32x4 yv) {
+  if constexpr (RELU) {
+    g[0] = yv[0] > 0.f ? g[0] : 0.f; g[1] = yv[1] > 0.f ? g[1] : 0.f;
+    g[2] = yv[2] > 0.f ? g[2] : 0.f; g[3] = yv[3] > 0.f ? g[3] : 0.f;
+  }
+  return g;
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
+                const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                float* __restrict__ psg, float* __restrict__ psgx) {
+  __shared__ f32x4 sm1[256], sm2[256];
+  const int tid = threadIdx.x;
+  const int ct = tid % CT, rt = tid / CT;
+  const int c4 = blockIdx.y * CT + ct;
+  const bool active = rt < RT && c4 < C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  if (active) {
+    const f32x4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+    for (int64_t r = r0 + rt; r < r1; r += RT) {
+      const size_t o = (size_t)r * C + 4 * c4;
+      f32x4 g = ld4(dy + o);
+      if constexpr (RELU) g = masked<true>(g, ld4(y + o));
+      const f32x4 xh = (ld4(x + o) - mu) * is;
+      s1 += g; s2 += g * xh;
+    }
+  }
+  sm1[tid] = s1; sm2[tid] = s2;
+  __syncthreads();
+  if (active && rt == 0) {
+    for (int j = 1; j < RT; ++j) { s1 += sm1[j * CT + ct]; s2 += sm2[j * CT + ct]; }
+    st4(psg + (size_t)blockIdx.x * C + 4 * c4, s1);
+    st4(psgx + (size_t)blockIdx.x * C + 4 * c4, s2);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, const float* __restrict__ psgx,
+                  float* dgamma, float* dbeta, int accumulate, float* __restrict__ k1, float* __restrict__ k2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int b = 0; b < nblk; ++b) { sg += (double)psg[(size_t)b * C + c]; sgx += (double)psgx[(size_t)b * C + c]; }
+  k1[c] = (float)(sg / (double)M);
+  k2[c] = (float)(sgx / (double)M);
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
+}
+
+template <bool RELU, bool DRES>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
+               const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+               const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
+               float* __restrict__ dx, float* __restrict__ dres) {
+  const int tid = threadIdx.x;
+  const int ct = tid % CT, rt = tid / CT;
+  const int c4 = blockIdx.y * CT + ct;
+  if (rt >= RT || c4 >= C / 4) return;
+  const f32x4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+  const f32x4 gi = ld4(gamma + 4 * c4) * is, a1 = ld4(k1 + 4 * c4), a2 = ld4(k2 + 4 * c4);
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
+  for (int64_t r = r0 + rt; r < r1; r += RT) {
+    const size_t o = (size_t)r * C + 4 * c4;
+    f32x4 g = ld4(dy + o);
+    if constexpr (RELU) g = masked<true>(g, ld4(y + o));
+    const f32x4 xh = (ld4(x + o) - mu) * is;
+    st4(dx + o, gi * (g - a1 - xh * a2));
+    if constexpr (DRES) st4(dres + o, g);
+  }
+}
+
+// ---- column sum --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+colsum_partial_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ x, float* __restrict__ ps) {
+  __shared__ f32x4 sm1[256];
+  const int tid = threadIdx.x;
+  const int ct = tid % CT, rt = tid / CT;
+  const int c4 = blockIdx.y * CT + ct;
+  const bool active = rt < RT && c4 < C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
+  f32x4 s1 = {0, 0, 0, 0};
+  if (active) for (int64_t r = r0 + rt; r < r1; r += RT) s1 += ld4(x + (size_t)r * C + 4 * c4);
+  sm1[tid] = s1;
+  __syncthreads();
+  if (active && rt == 0) {
+    for (int j = 1; j < RT; ++j) s1 += sm1[j * CT + ct];
+    st4(ps + (size_t)blockIdx.x * C + 4 * c4, s1);
+  }
+}
+__global__ void colsum_finalize_k(int C, int nblk, const float* __restrict__ ps, float* out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)ps[(size_t)b * C + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+int check_mc(int64_t M, int C, const char* who) {
+  SSV_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "%s: need M > 0, C > 0, C %% 4 == 0 (M=%lld C=%d)", who, (long long)M, C);
+  SSV_REQUIRE(M < (1ll << 31), "%s: M too large", who);
+  return SSV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ssv_bn_workspace_bytes(int64_t M, int32_t C) {
+  if (M <= 0 || C <= 0 || C % 4) return 0;
+  const BnPlan p = bn_plan(M, C);
+  return ((size_t)2 * p.nblk * C + 2 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
+                                const float* residual, int relu, float eps, float momentum,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_train_fwd")) return rc;
+  SSV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "ssv_bn_train_fwd: null pointer");
+  SSV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "ssv_bn_train_fwd: running_mean/var must both be given or both NULL");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_FWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* pmean = (float*)ws;
+  float* pm2 = pmean + (size_t)p.nblk * C;
+  float* scale = pm2 + (size_t)p.nblk * C;
+  float* shift = scale + C;
+  const dim3 grid(p.nblk, p.GY);
+  hipLaunchKernelGGL(bn_stats_k, grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, pmean, pm2);
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, 64)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
+  if (relu) {
+    if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
+    else          hipLaunchKernelGGL((bn_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
+  } else {
+    if (residual) hipLaunchKernelGGL((bn_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
+    else          hipLaunchKernelGGL((bn_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
+  }
+  SSV_CHECK_LAUNCH("ssv_bn_train_fwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const float* x,
+                                const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+                                float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_train_bwd")) return rc;
+  SSV_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && ws, "ssv_bn_train_bwd: null pointer");
+  SSV_REQUIRE(!relu || y, "ssv_bn_train_bwd: relu mask needs y");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_BWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* psg = (float*)ws;
+  float* psgx = psg + (size_t)p.nblk * C;
+  float* k1 = psgx + (size_t)p.nblk * C;
+  float* k2 = k1 + C;
+  const dim3 grid(p.nblk, p.GY);
+  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
+  else      hipLaunchKernelGGL((bn_bwd_reduce_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
+                     dgamma, dbeta, accumulate, k1, k2);
+  const float* ck1 = k1; const float* ck2 = k2;
+  if (relu) {
+    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+    else           hipLaunchKernelGGL((bn_bwd_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+  } else {
+    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+    else           hipLaunchKernelGGL((bn_bwd_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+  }
+  SSV_CHECK_LAUNCH("ssv_bn_train_bwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int accumulate,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_colsum")) return rc;
+  SSV_REQUIRE(x && out && ws, "ssv_colsum: null pointer");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_colsum: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  const BnPlan p = bn_plan(M, C);
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(colsum_partial_k, dim3(p.nblk, p.GY), dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, part);
+  hipLaunchKernelGGL(colsum_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, s, C, p.nblk, (const float*)part, out, accumulate);
+  SSV_CHECK_LAUNCH("ssv_colsum");
+  return SSV_OK;
+}

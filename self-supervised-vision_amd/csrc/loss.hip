@@ -1,0 +1,340 @@
+// Loss-side kernels: row L2 normalisation, NT-Xent (Gram matrix on fp32 MFMA + lane-local online
+// log-sum-exp), the BYOL MSE pair, and small scalar helpers.
+//
+// NT-Xent layout trick: every 32x32 Gram tile is computed TRANSPOSED, T = Zc . Zr^T (A = column
+// tile, B = this block's 32 rows), so that the accumulator puts the block's row r on the LANE
+// (l & 31) and the 16 columns crow(j,h) = (j&3) + 8*(j>>2) + 4*(l>>5) in the lane's registers:
+//   * the row-wise log-sum-exp is lane-local over registers and tiles; the only cross-lane step is
+//     one shfl_xor(32) at the end (lanes l and l+32 hold the same row);
+//   * in the backward the weight tile W (same layout) is directly the A operand of the second
+//     product dZ += W . Zc (A[i = l&31][k = l>>5] = W[r][crow(j,h)] for MFMA step j), so the P
+//     matrix never touches LDS or HBM.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int crow(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+
+// ---- F.normalize ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+l2norm_fwd_k(int rows, int D, const float* __restrict__ z, int normalize, float eps, float* __restrict__ zhat, int ldo, float* __restrict__ inv_norm) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* zr = z + (size_t)row * D;
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = zr[d]; ss += v * v; }
+    ss = wave_sum(ss);
+    inv = 1.f / fmaxf(sqrtf(ss), eps);
+  }
+  for (int d = lane; d < ldo; d += 64) zhat[(size_t)row * ldo + d] = d < D ? zr[d] * inv : 0.f;
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+
+__global__ void __launch_bounds__(256)
+l2norm_bwd_k(int rows, int D, const float* __restrict__ zhat, int ldz, const float* __restrict__ inv_norm,
+             const float* __restrict__ dzhat, int ldd, int normalize, float* __restrict__ dz) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* zh = zhat + (size_t)row * ldz;
+  const float* dh = dzhat + (size_t)row * ldd;
+  if (!normalize) { for (int d = lane; d < D; d += 64) dz[(size_t)row * D + d] = dh[d]; return; }
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) dot += zh[d] * dh[d];
+  dot = wave_sum(dot);
+  const float inv = inv_norm[row];
+  for (int d = lane; d < D; d += 64) dz[(size_t)row * D + d] = (dh[d] - zh[d] * dot) * inv;
+}
+
+// ---- NT-Xent ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int global_row(int lr, int Bloc, int Nglob, int seg0) {
+  return lr < Bloc ? seg0 + lr : Nglob + seg0 + (lr - Bloc);
+}
+
+// T = Zc_tile . Zr^T for one 32-column tile; zr[q] are this lane's register-resident row fragments
+template <int DQ>
+__device__ __forceinline__ f32x16 gram_tile(const float* __restrict__ Z, int ldz, int crow_glob, int h, const f32x4 (&zr)[DQ]) {
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const float* zc = Z + (size_t)crow_glob * ldz + 4 * h;
+#pragma unroll
+  for (int q = 0; q < DQ; ++q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(zc + 8 * q);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], zr[q][t], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int DQ>
+__global__ void __launch_bounds__(256)
+ntxent_fwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z, float inv_temp, float* __restrict__ lse, float* __restrict__ pos) {
+  __shared__ float sm_m[4][32], sm_s[4][32], sm_p[4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int R2 = 2 * Nglob, rows_loc = 2 * Bloc;
+  const int lr = blockIdx.x * 32 + l31;
+  const bool rvalid = lr < rows_loc;
+  const int rg = global_row(rvalid ? lr : 0, Bloc, Nglob, seg0);
+  const int pg = rg < Nglob ? rg + Nglob : rg - Nglob;
+  f32x4 zr[DQ];
+#pragma unroll
+  for (int q = 0; q < DQ; ++q) zr[q] = *reinterpret_cast<const f32x4*>(Z + (size_t)rg * ldz + 8 * q + 4 * h);
+
+  float m = -INFINITY, s = 0.f, pv = 0.f;
+  const int ntile = (R2 + 31) / 32;
+  for (int ct = wave; ct < ntile; ct += 4) {
+    const int cl = ct * 32 + l31;
+    const f32x16 T = gram_tile<DQ>(Z, ldz, cl < R2 ? cl : R2 - 1, h, zr);
+    float sv[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cg = ct * 32 + crow(j, h);
+      const float v = T[j] * inv_temp;
+      if (cg == pg) pv += v;
+      sv[j] = (cg < R2 && cg != rg) ? v : -INFINITY;
+      tmax = fmaxf(tmax, sv[j]);
+    }
+    if (tmax > -INFINITY) {
+      const float mn = fmaxf(m, tmax);
+      float add = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) add += expf(sv[j] - mn);     // exp(-inf) = 0 for masked entries
+      s = s * expf(m - mn) + add;
+      m = mn;
+    }
+  }
+  // merge the two half-waves (same row, disjoint columns)
+  {
+    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
+    const float mn = fmaxf(m, m2);
+    s = (m > -INFINITY ? s * expf(m - mn) : 0.f) + (m2 > -INFINITY ? s2 * expf(m2 - mn) : 0.f);
+    m = mn;
+    pv += __shfl_xor(pv, 32, 64);
+  }
+  if (h == 0) { sm_m[wave][l31] = m; sm_s[wave][l31] = s; sm_p[wave][l31] = pv; }
+  __syncthreads();
+  if (wave == 0 && h == 0 && rvalid) {
+    float mm = sm_m[0][l31], ss = sm_s[0][l31], pp = sm_p[0][l31];
+    for (int w = 1; w < 4; ++w) {
+      const float m2 = sm_m[w][l31], s2 = sm_s[w][l31];
+      const float mn = fmaxf(mm, m2);
+      ss = (mm > -INFINITY ? ss * expf(mm - mn) : 0.f) + (m2 > -INFINITY ? s2 * expf(m2 - mn) : 0.f);
+      mm = mn;
+      pp += sm_p[w][l31];
+    }
+    lse[lr] = mm + logf(ss);
+    pos[lr] = pp;
+  }
+}
+
+template <int DQ>
+__global__ void __launch_bounds__(256)
+ntxent_bwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z, const float* __restrict__ lse_all,
+             float inv_temp, float gscale, float* __restrict__ dZ) {
+  constexpr int DC = DQ / 4;                 // 32-wide chunks of the embedding dimension
+  __shared__ float red[32][DQ * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int R2 = 2 * Nglob, rows_loc = 2 * Bloc;
+  const int lr = blockIdx.x * 32 + l31;
+  const bool rvalid = lr < rows_loc;
+  const int rg = global_row(rvalid ? lr : 0, Bloc, Nglob, seg0);
+  f32x4 zr[DQ];
+#pragma unroll
+  for (int q = 0; q < DQ; ++q) zr[q] = *reinterpret_cast<const f32x4*>(Z + (size_t)rg * ldz + 8 * q + 4 * h);
+  const float lse_r = lse_all[rg];
+
+  f32x16 out[DC];
+#pragma unroll
+  for (int dc = 0; dc < DC; ++dc)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[dc][j] = 0.f;
+
+  const int ntile = (R2 + 31) / 32;
+  for (int ct = wave; ct < ntile; ct += 4) {
+    const int cl = ct * 32 + l31;
+    const f32x16 T = gram_tile<DQ>(Z, ldz, cl < R2 ? cl : R2 - 1, h, zr);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cg = ct * 32 + crow(j, h);
+      const int cgc = cg < R2 ? cg : R2 - 1;
+      const float sv = T[j] * inv_temp;
+      float wgt = 0.f;
+      if (cg < R2 && cg != rg && rvalid) wgt = expf(sv - lse_r) + expf(sv - lse_all[cgc]);
+      const float* zc = Z + (size_t)cgc * ldz + l31;
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) out[dc] = __builtin_amdgcn_mfma_f32_32x32x2f32(wgt, zc[32 * dc], out[dc], 0, 0, 0);
+    }
+  }
+  // fixed-order cross-wave sum through LDS: out[dc][j] of lane l is (row crow(j,h), col 32*dc + l31)
+  for (int turn = 0; turn < 4; ++turn) {
+    if (wave == turn) {
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float* p = &red[crow(j, h)][32 * dc + l31];
+          *p = (turn == 0 ? 0.f : *p) + out[dc][j];
+        }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 32 * ldz; e += 256) {
+    const int r = e / ldz, d = e - r * ldz;
+    const int lrow = blockIdx.x * 32 + r;
+    if (lrow < rows_loc) {
+      const int g = global_row(lrow, Bloc, Nglob, seg0);
+      const int pg = g < Nglob ? g + Nglob : g - Nglob;
+      dZ[(size_t)lrow * ldz + d] = gscale * (red[r][d] - 2.f * Z[(size_t)pg * ldz + d]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ntxent_loss_k(int rows, const float* __restrict__ lse, const float* __restrict__ pos, float scale, float* __restrict__ loss) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < rows; i += 256) s += (double)lse[i] - (double)pos[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *loss = (float)(sm[0] * (double)scale);
+}
+
+// ---- BYOL MSE pair -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mse_pair_k(int64_t n, const float* __restrict__ o1, const float* __restrict__ o2, const float* __restrict__ t1, const float* __restrict__ t2,
+           float inv_count, float* __restrict__ do1, float* __restrict__ do2, double* __restrict__ part) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  const float g = 2.f * inv_count;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = o1[i] - t2[i], b = o2[i] - t1[i];
+    s += (double)(a * a) + (double)(b * b);
+    do1[i] = g * a; do2[i] = g * b;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+__global__ void sum_partials_k(int nblk, const double* __restrict__ part, float scale, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part[i];
+    *out = (float)(s * (double)scale);
+  }
+}
+
+__global__ void scale_k(int64_t n, float* __restrict__ x, const float* __restrict__ factor) {
+  const float f = *factor;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
+}
+
+int reduce_blocks(int64_t n) {
+  int64_t b = cdiv64(n, 1024);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int ssv_l2norm_fwd(int32_t rows, int32_t D, const float* z, int32_t normalize, float eps,
+                              float* zhat, int32_t ldo, float* inv_norm, void* stream) {
+  SSV_REQUIRE(rows > 0 && D > 0 && ldo >= D && z && zhat, "ssv_l2norm_fwd: bad arguments");
+  SSV_REQUIRE(!normalize || inv_norm, "ssv_l2norm_fwd: inv_norm required when normalising");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  hipLaunchKernelGGL(l2norm_fwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, D, z, normalize, eps, zhat, ldo, inv_norm);
+  SSV_CHECK_LAUNCH("ssv_l2norm_fwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_l2norm_bwd(int32_t rows, int32_t D, const float* zhat, int32_t ldz, const float* inv_norm,
+                              const float* dzhat, int32_t ldd, int32_t normalize, float* dz, void* stream) {
+  SSV_REQUIRE(rows > 0 && D > 0 && ldz >= D && ldd >= D && zhat && dzhat && dz, "ssv_l2norm_bwd: bad arguments");
+  SSV_REQUIRE(!normalize || inv_norm, "ssv_l2norm_bwd: inv_norm required when normalising");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  hipLaunchKernelGGL(l2norm_bwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, D, zhat, ldz, inv_norm, dzhat, ldd, normalize, dz);
+  SSV_CHECK_LAUNCH("ssv_l2norm_bwd");
+  return SSV_OK;
+}
+
+static int check_ntxent(int Nglob, int Bloc, int seg0, int ldz, const char* who) {
+  SSV_REQUIRE(Nglob > 0 && Bloc > 0 && seg0 >= 0 && seg0 + Bloc <= Nglob, "%s: bad row partition (Nglob=%d Bloc=%d seg0=%d)", who, Nglob, Bloc, seg0);
+  SSV_REQUIRE(ldz % 32 == 0 && ldz >= 32 && ldz <= 128, "%s: ldz must be 32, 64, 96 or 128 (got %d)", who, ldz);
+  SSV_REQUIRE(Nglob < (1 << 29), "%s: Nglob too large", who);
+  return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                              float inv_temp, float* lse, float* pos, void* stream) {
+  if (int rc = check_ntxent(Nglob, Bloc, seg0, ldz, "ssv_ntxent_fwd")) return rc;
+  SSV_REQUIRE(Z && lse && pos && ((uintptr_t)Z & 15) == 0, "ssv_ntxent_fwd: null or unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  const dim3 grid(cdiv(2 * Bloc, 32));
+  switch (ldz / 8) {
+    case 4:  hipLaunchKernelGGL((ntxent_fwd_k<4>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
+    case 8:  hipLaunchKernelGGL((ntxent_fwd_k<8>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
+    case 12: hipLaunchKernelGGL((ntxent_fwd_k<12>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
+    default: hipLaunchKernelGGL((ntxent_fwd_k<16>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
+  }
+  SSV_CHECK_LAUNCH("ssv_ntxent_fwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_loss(int32_t rows, const float* lse, const float* pos, float scale, float* loss, void* stream) {
+  SSV_REQUIRE(rows > 0 && lse && pos && loss, "ssv_ntxent_loss: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  hipLaunchKernelGGL(ntxent_loss_k, dim3(1), dim3(256), 0, s, rows, lse, pos, scale, loss);
+  SSV_CHECK_LAUNCH("ssv_ntxent_loss");
+  return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                              const float* lse_all, float inv_temp, float gscale, float* dZ, void* stream) {
+  if (int rc = check_ntxent(Nglob, Bloc, seg0, ldz, "ssv_ntxent_bwd")) return rc;
+  SSV_REQUIRE(Z && lse_all && dZ && ((uintptr_t)Z & 15) == 0, "ssv_ntxent_bwd: null or unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  const dim3 grid(cdiv(2 * Bloc, 32));
+  switch (ldz / 8) {
+    case 4:  hipLaunchKernelGGL((ntxent_bwd_k<4>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
+    case 8:  hipLaunchKernelGGL((ntxent_bwd_k<8>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
+    case 12: hipLaunchKernelGGL((ntxent_bwd_k<12>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
+    default: hipLaunchKernelGGL((ntxent_bwd_k<16>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
+  }
+  SSV_CHECK_LAUNCH("ssv_ntxent_bwd");
+  return SSV_OK;
+}
+
+extern "C" size_t ssv_reduce_workspace_bytes(int64_t n) { return (size_t)reduce_blocks(n) * sizeof(double); }
+
+extern "C" int ssv_mse_pair_fwd_bwd(int64_t n, const float* o1, const float* o2, const float* t1, const float* t2,
+                                    float inv_count, float* loss, float* do1, float* do2,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(n > 0 && o1 && o2 && t1 && t2 && loss && do1 && do2 && ws, "ssv_mse_pair_fwd_bwd: bad arguments");
+  if (ws_bytes < ssv_reduce_workspace_bytes(n)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_mse_pair_fwd_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  const int nb = reduce_blocks(n);
+  hipLaunchKernelGGL(mse_pair_k, dim3(nb), dim3(256), 0, s, n, o1, o2, t1, t2, inv_count, do1, do2, (double*)ws);
+  hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(64), 0, s, nb, (const double*)ws, inv_count, loss);
+  SSV_CHECK_LAUNCH("ssv_mse_pair_fwd_bwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_scale(int64_t n, float* x, const float* factor_dev, void* stream) {
+  SSV_REQUIRE(n > 0 && x && factor_dev, "ssv_scale: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  hipLaunchKernelGGL(scale_k, dim3(reduce_blocks(n)), dim3(256), 0, s, n, x, factor_dev);
+  SSV_CHECK_LAUNCH("ssv_scale");
+  return SSV_OK;
+}

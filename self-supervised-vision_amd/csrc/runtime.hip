@@ -1,0 +1,84 @@
+// Library runtime: error string, version, per-class HIP-event timing, fill.
+#include "common.h"
+#include <vector>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void ssv_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int ssv_version(void) { return 100; }
+extern "C" const char* ssv_last_error(void) { return g_err; }
+
+extern "C" int ssv_device_cus(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return prop.multiProcessorCount;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+struct ProfRec { int cls; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;          // records of the current collection window
+static std::vector<ProfRec> g_free;          // recycled event pairs
+static int g_open = -1;
+
+void ssv_prof_begin(int cls, hipStream_t s) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  if (!g_free.empty()) { r = g_free.back(); g_free.pop_back(); }
+  else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+  r.cls = cls;
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+  g_open = (int)g_recs.size() - 1;
+}
+void ssv_prof_end(int cls, hipStream_t s) {
+  if (!g_prof_on || g_open < 0) return;
+  (void)cls;
+  (void)hipEventRecord(g_recs[g_open].b, s);
+  g_open = -1;
+}
+extern "C" int ssv_prof_enable(int on) { g_prof_on = on != 0; return SSV_OK; }
+extern "C" int ssv_prof_reset(void) {
+  for (auto& r : g_recs) g_free.push_back(r);
+  g_recs.clear(); g_open = -1;
+  return SSV_OK;
+}
+extern "C" int ssv_prof_collect(double* ms, int64_t* n) {
+  for (int i = 0; i < SSV_PROF_NCLASS; ++i) { ms[i] = 0.0; n[i] = 0; }
+  for (auto& r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) SSV_FAIL(SSV_ERR_LAUNCH, "prof: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) SSV_FAIL(SSV_ERR_LAUNCH, "prof: elapsed failed");
+    ms[r.cls] += t; n[r.cls] += 1;
+  }
+  return ssv_prof_reset();
+}
+
+// ---- fill -----------------------------------------------------------------------------------
+__global__ void fill_k(int64_t n, float* p, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  f32x4 v4 = {v, v, v, v};
+  for (int64_t j = i; j < n4; j += stride) reinterpret_cast<f32x4*>(p)[j] = v4;
+  for (int64_t j = (n4 << 2) + i; j < n; j += stride) p[j] = v;
+}
+extern "C" int ssv_fill(int64_t n, float* p, float value, void* stream) {
+  if (n <= 0) return SSV_OK;
+  SSV_REQUIRE(p != nullptr && ((uintptr_t)p & 15) == 0, "ssv_fill: null or unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  int64_t blocks = cdiv64(n >> 2 ? n >> 2 : n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_k, dim3((unsigned)blocks), dim3(256), 0, s, n, p, value);
+  SSV_CHECK_LAUNCH("ssv_fill");
+  return SSV_OK;
+}

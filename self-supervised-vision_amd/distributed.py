@@ -1,0 +1,66 @@
+"""One process per GPU over RCCL (torch.distributed backend "nccl" on ROCm), launched with
+torch.distributed.run.  Only the exchange steps the path really has:
+  * all-gather of the projected embeddings (and their row log-sum-exps) so NT-Xent sees global negatives;
+  * one all-reduce(SUM) of the flat gradient arena before the optimizer update.
+BatchNorm statistics stay local (per rank, per view) - the reference has no SyncBN.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_on() else 1
+
+
+def rank():
+    return dist.get_rank() if is_on() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK if WORLD_SIZE > 1."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return rank(), world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def all_gather_rows(buf, rows_per_rank):
+    """``buf`` is [world*rows_per_rank, ...] with this rank's block already in place; fill the rest."""
+    if not is_on():
+        return buf
+    mine = buf[rank() * rows_per_rank:(rank() + 1) * rows_per_rank]
+    dist.all_gather_into_tensor(buf, mine.clone() if buf.device.type == "cpu" else mine.contiguous())
+    return buf
+
+
+def all_reduce_sum(t):
+    if is_on():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def attach_grad_sync(optimizer):
+    """Data parallel: every rank back-propagates the GLOBAL-mean loss through its own samples, so the
+    SUM of the per-rank gradients is the large-batch gradient.  One contiguous all-reduce."""
+    if is_on():
+        optimizer.grad_sync = all_reduce_sum
+    return optimizer
+
+
+def broadcast_parameters(flat):
+    if is_on():
+        dist.broadcast(flat, src=0)
+    return flat

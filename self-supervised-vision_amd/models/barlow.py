@@ -1,0 +1,35 @@
+"""Barlow Twins on the HIP path - drop-in for the reference trainer (models/barlow.py:39-167)."""
+from ..utils import losses, train_utils
+from .base import NETWORKS, TwoViewTrainer
+from .heads import BarlowProjectionHead as ProjectionHead  # noqa: F401
+
+
+class BarlowTwins(TwoViewTrainer):
+    algo = "barlow"
+
+    def _build(self, arch):
+        encoder, encoder_dim = NETWORKS[arch].values()
+        self.encoder = encoder(**self.config["encoder"]).to(self.device)
+        self.proj_head = ProjectionHead(encoder_dim, self.config["proj_dim"]).to(self.device)
+        self.optim = train_utils.get_optimizer(
+            self.config["optimizer"], params=list(self.encoder.parameters()) + list(self.proj_head.parameters()))
+        self.loss_fn = losses.BarlowLoss(**self.config["loss_fn"])
+
+    def _embed(self, img):
+        return self.proj_head(self.encoder(img))
+
+    def train_step(self, batch):
+        img_1, img_2 = batch["aug_1"].to(self.device), batch["aug_2"].to(self.device)
+        z_1, z_2 = self._embed(img_1), self._embed(img_2)
+        loss = self.loss_fn(z_1, z_2)
+        self.optim.zero_grad()
+        loss.backward()
+        self.optim.step()
+        return {"loss": loss.item()}
+
+    def _checkpoint_state(self):
+        return {"encoder": self.encoder.state_dict(), "proj_head": self.proj_head.state_dict()}
+
+    def _load_state(self, state):
+        self.encoder.load_state_dict(state["encoder"])
+        self.proj_head.load_state_dict(state["proj_head"])

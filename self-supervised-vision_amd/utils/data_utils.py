@@ -1,0 +1,90 @@
+"""GPU-resident two-view data path: replaces DoubleAugmentedDataset + PIL worker processes
+(reference utils/data_utils.py:56-73,113-121).
+
+The dataset lives in HBM as uint8 [N,H,W,3]; a "loader" iteration picks a permutation slice and
+the fused augmentation kernels (utils/augmentations.py) turn it into the two normalised fp32
+views, so there is no host->device copy of fp32 images and no CPU augmentation in the loop.
+Batches keep the reference keys: index, img, aug_1, aug_2, label.
+
+Datasets: CIFAR-10/100 are read from the standard python pickles under ``root`` if they are
+already there (no download: the target boxes have no network); ``synthetic: {...}`` in the
+``data`` block of the YAML generates a seeded uint8 dataset of the requested shape instead.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import augmentations
+
+
+def _load_cifar(root, name, train):
+    if name == "cifar10":
+        base = os.path.join(root, "cifar-10-batches-py")
+        files = [f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]
+        key = b"labels"
+    else:
+        base = os.path.join(root, "cifar-100-python")
+        files = ["train"] if train else ["test"]
+        key = b"fine_labels"
+    if not os.path.isdir(base):
+        raise FileNotFoundError(
+            f"{base} not found. There is no network on this box, so datasets are not downloaded: place the "
+            f"extracted CIFAR python archive there, or add a `synthetic:` block to the `data` section of the config")
+    xs, ys = [], []
+    for f in files:
+        with open(os.path.join(base, f), "rb") as fh:
+            d = pickle.load(fh, encoding="bytes")
+        xs.append(np.asarray(d[b"data"], dtype=np.uint8).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+        ys.append(np.asarray(d[key], dtype=np.int64))
+    return np.ascontiguousarray(np.concatenate(xs)), np.concatenate(ys)
+
+
+def _synthetic(spec, train, seed=420):
+    n = int(spec.get("num_train", 4096) if train else spec.get("num_test", 1024))
+    h, w = spec.get("image_size", [32, 32])
+    rng = np.random.default_rng(seed + (0 if train else 1))
+    return rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8), rng.integers(0, int(spec.get("num_classes", 10)), size=n)
+
+
+DATASETS = ("cifar10", "cifar100")
+
+
+class GpuTwoViewLoader:
+    """Iterates {index, img, aug_1, aug_2, label} batches produced on the GPU."""
+
+    def __init__(self, images_u8, labels, transforms, batch_size, shuffle, device, seed=420):
+        self.device = device
+        self.images = torch.from_numpy(images_u8).to(device)                 # uint8 [N,H,W,3] resident in HBM
+        self.labels = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(device)
+        self.batch_size, self.shuffle = int(batch_size), shuffle
+        self.train_tf = augmentations.get_transform(transforms["train"])
+        self.test_tf = augmentations.get_transform(transforms["test"])
+        self.gen = torch.Generator().manual_seed(seed)
+        self.step = 0
+
+    def __len__(self):
+        return (self.images.shape[0] + self.batch_size - 1) // self.batch_size     # last batch is NOT dropped
+
+    def __iter__(self):
+        n = self.images.shape[0]
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        for s in range(0, n, self.batch_size):
+            idx = order[s:s + self.batch_size].to(self.device)
+            aug_1, aug_2 = self.train_tf.two_views(self.images, idx, self.step)
+            img = self.test_tf.one_view(self.images, idx)
+            self.step += 1
+            yield {"index": idx, "img": img, "aug_1": aug_1, "aug_2": aug_2, "label": self.labels[idx]}
+
+
+def get_double_augment_dataloaders(dataset_name, root, transforms, batch_size, device=None, synthetic=None):
+    assert synthetic is not None or dataset_name in DATASETS, \
+        f"Unrecognized dataset {dataset_name}, expected one of {list(DATASETS)}"
+    if synthetic is not None:
+        (xtr, ytr), (xte, yte) = _synthetic(synthetic, True), _synthetic(synthetic, False)
+    else:
+        (xtr, ytr), (xte, yte) = _load_cifar(root, dataset_name, True), _load_cifar(root, dataset_name, False)
+    train_loader = GpuTwoViewLoader(xtr, ytr, transforms, batch_size, True, device)
+    test_loader = GpuTwoViewLoader(xte, yte, transforms, batch_size, False, device)
+    return train_loader, test_loader

@@ -1,0 +1,107 @@
+"""Loss modules of the accelerated path with the reference's constructor signatures
+(utils/losses.py:8-46 SimclrLoss, :120-142 BarlowLoss; BYOL uses nn.MSELoss, models/byol.py:89).
+
+Each forward runs the fused HIP kernels (forward AND the gradient w.r.t. the embeddings), and
+returns a 0-d tensor wired into torch.autograd so ``loss.backward()`` hands dz to the heads.
+With a process group, the embeddings are all-gathered over RCCL so NT-Xent sees global negatives.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .. import distributed as hdist
+
+
+def _pad32(d):
+    return (d + 31) // 32 * 32
+
+
+class _NTXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, zi, zj, normalize, temperature):
+        if not zi.is_cuda:
+            raise _lib.SsvError("SimclrLoss: the HIP path needs device tensors; there is no CPU fallback")
+        b, d = zi.shape
+        ld = _pad32(d)
+        if ld > 128:
+            raise _lib.SsvError(f"SimclrLoss: projection dim {d} > 128 is not supported by the register-resident NT-Xent kernel yet")
+        world, rank = hdist.world_size(), hdist.rank()
+        nglob, seg0 = b * world, b * rank
+        dev = zi.device
+        # normalised rows of this rank, written straight into their slots of the gathered matrix
+        zall = torch.empty((2 * nglob, ld), dtype=torch.float32, device=dev)
+        zi_c, zj_c = zi.detach().contiguous(), zj.detach().contiguous()
+        _, inv_i = ops.l2norm_fwd(zi_c, normalize, ld, out=zall[seg0:seg0 + b])
+        _, inv_j = ops.l2norm_fwd(zj_c, normalize, ld, out=zall[nglob + seg0:nglob + seg0 + b])
+        if world > 1:
+            hdist.all_gather_rows(zall[:nglob], b)
+            hdist.all_gather_rows(zall[nglob:], b)
+        inv_t = 1.0 / float(temperature)
+        lse_all = torch.empty((2 * nglob,), dtype=torch.float32, device=dev)
+        lse_loc = torch.empty((2 * b,), dtype=torch.float32, device=dev)
+        pos_loc = torch.empty((2 * b,), dtype=torch.float32, device=dev)
+        _lib.call("ssv_ntxent_fwd", nglob, b, seg0, ld, _lib.ptr(zall), inv_t, _lib.ptr(lse_loc), _lib.ptr(pos_loc), _lib.stream())
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.call("ssv_ntxent_loss", 2 * b, _lib.ptr(lse_loc), _lib.ptr(pos_loc), 1.0 / (2 * nglob), _lib.ptr(loss), _lib.stream())
+        if world > 1:
+            hdist.all_reduce_sum(loss)                       # every rank returns the global-batch loss
+            lse_all[seg0:seg0 + b].copy_(lse_loc[:b])
+            lse_all[nglob + seg0:nglob + seg0 + b].copy_(lse_loc[b:])
+            hdist.all_gather_rows(lse_all[:nglob], b)
+            hdist.all_gather_rows(lse_all[nglob:], b)
+        else:
+            lse_all = lse_loc
+        ctx.saved = (zall, lse_all, inv_i, inv_j, nglob, b, seg0, ld, d, inv_t, bool(normalize))
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        zall, lse_all, inv_i, inv_j, nglob, b, seg0, ld, d, inv_t, normalize = ctx.saved
+        dzall = torch.empty((2 * b, ld), dtype=torch.float32, device=zall.device)
+        _lib.call("ssv_ntxent_bwd", nglob, b, seg0, ld, _lib.ptr(zall), _lib.ptr(lse_all), inv_t, inv_t / (2 * nglob),
+                  _lib.ptr(dzall), _lib.stream())
+        ops.scale_(dzall, dloss.contiguous())                # chain rule with the upstream scalar, read on the device
+        dzi = ops.l2norm_bwd(zall[seg0:seg0 + b], inv_i, dzall[:b], d, normalize)
+        dzj = ops.l2norm_bwd(zall[nglob + seg0:nglob + seg0 + b], inv_j, dzall[b:], d, normalize)
+        return dzi, dzj, None, None
+
+
+class SimclrLoss(nn.Module):
+    """NT-Xent (utils/losses.py:8-46): defaults normalize=False, temperature=1.0 like the reference."""
+
+    def __init__(self, normalize=False, temperature=1.0):
+        super().__init__()
+        self.normalize = normalize
+        self.temperature = temperature
+
+    def forward(self, zi, zj):
+        if zi.shape != zj.shape or zi.dim() != 2:
+            raise ValueError(f"SimclrLoss expects two [N,D] matrices, got {tuple(zi.shape)} and {tuple(zj.shape)}")
+        return _NTXentFn.apply(zi, zj, self.normalize, self.temperature)
+
+
+class _MSEPairFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o1, o2, t1, t2):
+        if not o1.is_cuda:
+            raise _lib.SsvError("BYOL loss: the HIP path needs device tensors; there is no CPU fallback")
+        o1c, o2c, t1c, t2c = (t.detach().contiguous() for t in (o1, o2, t1, t2))
+        n = o1c.numel()
+        do1, do2 = torch.empty_like(o1c), torch.empty_like(o2c)
+        loss = torch.empty((), dtype=torch.float32, device=o1.device)
+        ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(n), o1.device)
+        _lib.call("ssv_mse_pair_fwd_bwd", n, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(t1c), _lib.ptr(t2c), 1.0 / n,
+                  _lib.ptr(loss), _lib.ptr(do1), _lib.ptr(do2), _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.saved = (do1, do2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        do1, do2 = ctx.saved
+        g = dloss.contiguous()
+        return ops.scale_(do1, g), ops.scale_(do2, g), None, None
+
+
+def byol_pair_loss(online_1, online_2, target_1, target_2):
+    """MSE(online_1, target_2) + MSE(online_2, target_1), each a mean over B*D (models/byol.py:129-130)."""
+    return _MSEPairFn.apply(online_1, online_2, target_1, target_2)

@@ -1,0 +1,104 @@
+"""Optimizer / scheduler factories with the reference's semantics (utils/train_utils.py:6-45),
+backed by one fused HIP kernel over a flat parameter arena.
+
+``get_optimizer`` keeps the reference quirks: SGD is always momentum 0.9 + Nesterov (the YAML
+``momentum`` / ``nesterov`` keys are ignored) and weight decay hits every tensor.  ``get_scheduler``
+keeps the warm-up lr seeding (lr := 1e-12 + lr/warmup_epochs BEFORE the cosine schedule is built).
+"""
+import torch
+import torch.optim.lr_scheduler as lr_scheduler
+
+from .. import _lib, ops
+
+_ALIGN = 64          # floats; every tensor starts on a 256-byte boundary inside the arena
+
+
+class ParamArena:
+    """Packs parameters into ONE contiguous fp32 buffer (and their gradients into another):
+    the optimizer update is a single launch, zero_grad a single fill, and the data-parallel
+    gradient exchange one contiguous RCCL all-reduce.  ``p.data`` / ``p.grad`` become views that
+    keep each parameter's logical shape and memory format (OHWI for conv filters)."""
+
+    def __init__(self, params, with_grads=True):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise _lib.SsvError("the fused optimizer needs parameters on the GPU (call .to(device) first); no CPU fallback")
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise _lib.SsvError("all parameters must be fp32 on one device")
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.data = ops.fill_(torch.empty(off, dtype=torch.float32, device=dev), 0.0)
+        self.grad = ops.fill_(torch.empty(off, dtype=torch.float32, device=dev), 0.0) if with_grads else None
+        for p, o in zip(self.params, self.offsets):
+            view = self._view(self.data, p, o)
+            view.copy_(p.data)                       # one-time relocation (plumbing)
+            p.data = view
+            if with_grads:
+                p.grad = self._view(self.grad, p, o)
+
+    @staticmethod
+    def _view(flat, p, off):
+        seg = flat[off:off + p.numel()]
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+            o, i, h, w = p.shape
+            return seg.view(o, h, w, i).permute(0, 3, 1, 2)
+        return seg.view(p.shape)
+
+    def zero_grad(self):
+        ops.fill_(self.grad, 0.0)
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """optim.SGD(momentum=0.9, nesterov=True, weight_decay=wd) as ONE ssv_sgd_nesterov launch."""
+
+    def __init__(self, params, lr, weight_decay, momentum=0.9):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, weight_decay=weight_decay, momentum=momentum, nesterov=True))
+        self.arena = ParamArena(params)
+        self.momentum_buffer = ops.fill_(torch.empty_like(self.arena.data), 0.0)
+        self._steps = 0
+        self.grad_sync = None        # set by the data-parallel wrapper: callable(flat_grad) before the update
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        if self.grad_sync is not None:
+            self.grad_sync(self.arena.grad)
+        a = self.arena
+        _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(self.momentum_buffer),
+                  float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), int(self._steps == 0), _lib.stream())
+        self._steps += 1
+
+
+def get_optimizer(config, params):
+    name = config.get("name", "sgd")
+    if name == "sgd":
+        return FusedSGD(params, lr=config["lr"], weight_decay=config["weight_decay"], momentum=0.9)
+    if name in ("adam", "adamw"):
+        raise NotImplementedError(f"optimizer {name} is used only by algorithms outside the accelerated path (DINO); not built yet")
+    raise NotImplementedError(f"Invalid optimizer {name}")
+
+
+def get_scheduler(config, optimizer):
+    name = config.get("name", None)
+    warmup_epochs = config.get("warmup_epochs", 0)
+    if warmup_epochs > 0:
+        peak = optimizer.param_groups[0]["lr"]
+        for group in optimizer.param_groups:
+            group["lr"] = 1e-12 + peak / warmup_epochs
+    if name is None:
+        return None, warmup_epochs
+    if name == "cosine":
+        return lr_scheduler.CosineAnnealingLR(optimizer, config["epochs"] - warmup_epochs, eta_min=0.0, last_epoch=-1), warmup_epochs
+    if name == "multistep":
+        return lr_scheduler.MultiStepLR(optimizer, config["milestones"], config["gamma"]), warmup_epochs
+    raise NotImplementedError(f"Invalid scheduler {name}")

@@ -1,0 +1,282 @@
+"""GPU parity of every HIP kernel (through the C ABI) against plain torch fp32 CPU ops / the oracle.
+Tolerances: fp32 MFMA is an exact fp32 fmaf chain, so differences are summation-order only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from conftest import seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from ssv_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def nhwc(x):      # CPU NCHW -> CPU NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, rtol=1e-4, atol=None, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = float(ref.abs().max()) + 1e-30
+    atol = 2e-5 * scale if atol is None else atol
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bool(bad.any()), f"{what}: max err {float(err.max()):.3e} (scale {scale:.3e}), {int(bad.sum())}/{bad.numel()} out of tolerance"
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 8, 8, 64, 64, 1, 1, 0),        # layer1 1x1 (256x64 tile)
+    (3, 9, 9, 64, 256, 1, 1, 0),       # ragged M (243 rows)
+    (2, 8, 8, 256, 64, 1, 1, 0),
+    (2, 8, 8, 64, 64, 3, 1, 1),        # 3x3 s1
+    (2, 10, 10, 128, 128, 3, 2, 1),    # 3x3 s2, even input
+    (2, 9, 9, 128, 128, 3, 2, 1),      # 3x3 s2, odd input
+    (2, 8, 8, 256, 512, 1, 2, 0),      # downsample 1x1 s2
+    (1, 14, 14, 32, 48, 3, 1, 1),      # K not a multiple of the tile
+    (5, 1, 1, 2048, 128, 1, 1, 0),     # Linear 2048 -> 128, tiny batch
+    (64, 1, 1, 512, 512, 1, 1, 0),     # Linear
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from ssv_amd import ops
+    n, h, w, c, k, r, st, pad = case
+    x = seeded_randn(1, n, c, h, w)
+    wt = seeded_randn(2, k, c, r, r) / (c * r * r) ** 0.5
+    x.requires_grad_(), wt.requires_grad_()
+    y = F.conv2d(x, wt, stride=st, padding=pad)
+    dy = seeded_randn(3, *y.shape)
+    y.backward(dy)
+    xd, wd, dyd = nhwc(x.detach()).to(dev), wt.detach().contiguous(memory_format=torch.channels_last).to(dev), nhwc(dy).to(dev)
+    yd = ops.conv2d_fwd(xd, wd, st, pad)
+    close(nchw(yd.cpu()), y, what="conv fwd")
+    dxd = ops.conv2d_dgrad(dyd, wd, xd.shape, st, pad)
+    close(nchw(dxd.cpu()), x.grad, what="conv dgrad")
+    dwd = torch.zeros_like(wd)
+    ops.conv2d_wgrad(xd, dyd, wd, dwd, st, pad, accumulate=False)
+    close(dwd.cpu(), wt.grad, what="conv wgrad")
+    # accumulate + fused addend / bias
+    ops.conv2d_wgrad(xd, dyd, wd, dwd, st, pad, accumulate=True)
+    close(dwd.cpu(), 2 * wt.grad, what="conv wgrad accumulate")
+    add = seeded_randn(4, *xd.shape).to(dev)
+    dx2 = ops.conv2d_dgrad(dyd, wd, xd.shape, st, pad, addend=add, out=add)
+    close(nchw(dx2.cpu()), x.grad + nchw(seeded_randn(4, *xd.shape)), what="conv dgrad addend")
+    bias = seeded_randn(5, k).to(dev)
+    yb = ops.conv2d_fwd(xd, wd, st, pad, bias=bias)
+    close(nchw(yb.cpu()), y + bias.cpu().view(1, -1, 1, 1), what="conv fwd bias")
+
+
+@pytest.mark.parametrize("case", [(2, 20, 20, 3, 64, 7, 2, 3), (3, 12, 12, 3, 64, 3, 1, 1), (2, 11, 13, 3, 64, 7, 2, 3)])
+def test_stem_conv_generic_gather(dev, case):
+    from ssv_amd import ops
+    n, h, w, c, k, r, st, pad = case
+    x = seeded_randn(6, n, c, h, w)
+    wt = (seeded_randn(7, k, c, r, r) / (c * r * r) ** 0.5).requires_grad_()
+    y = F.conv2d(x, wt, stride=st, padding=pad)
+    dy = seeded_randn(8, *y.shape)
+    y.backward(dy)
+    xd, wd, dyd = nhwc(x).to(dev), wt.detach().contiguous(memory_format=torch.channels_last).to(dev), nhwc(dy).to(dev)
+    close(nchw(ops.conv2d_fwd(xd, wd, st, pad).cpu()), y, what="stem fwd")
+    dwd = torch.zeros_like(wd)
+    ops.conv2d_wgrad(xd, dyd, wd, dwd, st, pad, accumulate=False)
+    close(dwd.cpu(), wt.grad, what="stem wgrad")
+
+
+@pytest.mark.parametrize("shape,relu,res", [((4, 6, 6, 64), True, False), ((3, 5, 5, 256), True, True), ((2, 7, 7, 128), False, False),
+                                             ((37, 1, 1, 2048), True, False), ((16, 1, 1, 128), False, False), ((2, 30, 30, 64), True, True)])
+def test_batchnorm_fwd_bwd(dev, shape, relu, res):
+    from ssv_amd import ops
+    n, h, w, c = shape
+    x = (seeded_randn(11, n, c, h, w) * 1.7 + 0.6).requires_grad_()
+    gamma = (seeded_randn(12, c) * 0.3 + 1.0).requires_grad_()
+    beta = (seeded_randn(13, c) * 0.2).requires_grad_()
+    r = seeded_randn(14, n, c, h, w).requires_grad_() if res else None
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    dy = seeded_randn(15, *y.shape)
+    y.backward(dy)
+    g = lambda t: t.to(dev)
+    rmd, rvd, nbt = g(torch.zeros(c)), g(torch.ones(c)), g(torch.zeros((), dtype=torch.long))
+    xd = g(nhwc(x.detach()))
+    yd, mean, invstd = ops.bn_train_fwd(xd, g(gamma.detach()), g(beta.detach()), rmd, rvd, nbt, relu=relu,
+                                        residual=g(nhwc(r.detach())) if res else None)
+    close(nchw(yd.cpu()), y, what="bn fwd")
+    close(rmd, rm, what="running_mean")
+    close(rvd, rv, what="running_var")
+    assert int(nbt.item()) == 1
+    dgamma, dbeta = g(torch.zeros(c)), g(torch.zeros(c))
+    dxd, dres = ops.bn_train_bwd(g(nhwc(dy)), yd, xd, g(gamma.detach()), mean, invstd, relu, dgamma, dbeta, want_dres=res, accumulate=True)
+    close(nchw(dxd.cpu()), x.grad, rtol=2e-4, what="bn dx")
+    close(dgamma, gamma.grad, rtol=2e-4, what="bn dgamma")
+    close(dbeta, beta.grad, rtol=2e-4, what="bn dbeta")
+    if res:
+        close(nchw(dres.cpu()), r.grad, what="bn dres")
+
+
+def test_pools_and_layout(dev):
+    from ssv_amd import ops
+    for (n, c, h, w) in ((2, 64, 12, 12), (3, 64, 9, 11), (1, 8, 2, 2)):
+        x = seeded_randn(21, n, c, h, w).relu().requires_grad_()        # ReLU'd input -> ties at zero, like the real net
+        y = F.max_pool2d(x, 3, 2, 1)
+        dy = seeded_randn(22, *y.shape)
+        y.backward(dy)
+        xd = nhwc(x.detach()).to(dev)
+        yd, am = ops.maxpool_fwd(xd)
+        close(nchw(yd.cpu()), y, rtol=0, atol=0, what="maxpool fwd")
+        dxd = ops.maxpool_bwd(nhwc(dy).to(dev), am, xd.shape)
+        mask = (x.detach() > 0).float()                                   # zero-valued ties are killed by the ReLU mask upstream
+        close(nchw(dxd.cpu()) * mask, x.grad * mask, what="maxpool bwd")
+        close(dxd.sum(), x.grad.sum(), rtol=1e-4, what="maxpool bwd mass")
+    x = seeded_randn(23, 5, 2048, 7, 7).requires_grad_()
+    y = x.mean(dim=(2, 3))
+    dy = seeded_randn(24, 5, 2048)
+    y.backward(dy)
+    xd = nhwc(x.detach()).to(dev)
+    close(ops.gap_fwd(xd), y, what="gap fwd")
+    close(nchw(ops.gap_bwd(dy.to(dev), xd.shape).cpu()), x.grad, what="gap bwd")
+    img = seeded_randn(25, 3, 3, 10, 14)
+    close(ops.nchw_to_nhwc(img.to(dev)), nhwc(img), rtol=0, atol=0, what="nchw->nhwc")
+    close(ops.nchw_to_nhwc(img.to(dev).contiguous(memory_format=torch.channels_last)), nhwc(img), rtol=0, atol=0, what="channels_last view")
+
+
+def test_colsum_add_scale_fill(dev):
+    from ssv_amd import ops
+    x = seeded_randn(31, 333, 128)
+    out = torch.ones(128, device=dev)
+    ops.colsum(x.to(dev), out, accumulate=True)
+    close(out, 1 + x.sum(0), what="colsum")
+    a, b = seeded_randn(32, 1001).to(dev), seeded_randn(33, 1001).to(dev)
+    ref = a.cpu() + b.cpu()
+    close(ops.add_(a, b), ref, rtol=0, atol=0, what="add")
+    f = torch.tensor(0.25, device=dev)
+    close(ops.scale_(a, f), ref * 0.25, rtol=0, atol=0, what="scale")
+    close(ops.fill_(a, 3.0), torch.full((1001,), 3.0), rtol=0, atol=0, what="fill")
+
+
+def test_sgd_and_ema_match_reference(dev, golden):
+    from ssv_amd import _lib
+    g = golden["optim_level"]
+    shapes = [g["sgd_p0_init"].shape, g["sgd_p1_init"].shape]
+    flat = torch.cat([torch.tensor(g["sgd_p0_init"]).flatten(), torch.tensor(g["sgd_p1_init"]).flatten()]).to(dev)
+    buf = torch.zeros_like(flat)
+    n0 = int(np.prod(shapes[0]))
+    for s in range(3):
+        grads = torch.cat([seeded_randn(50 + 10 * s + i, *shp).flatten() for i, shp in enumerate(shapes)]).to(dev)
+        _lib.call("ssv_sgd_nesterov", flat.numel(), _lib.ptr(flat), _lib.ptr(grads), _lib.ptr(buf), 0.3, 1e-2, 0.9, int(s == 0), _lib.stream())
+        close(flat[:n0].view(shapes[0]), torch.tensor(g[f"sgd_p0_step{s}"]), rtol=2e-6, atol=2e-7, what=f"sgd p0 step {s}")
+        close(flat[n0:], torch.tensor(g[f"sgd_p1_step{s}"]), rtol=2e-6, atol=2e-7, what=f"sgd p1 step {s}")
+    t, o = seeded_randn(41, 777), seeded_randn(42, 777)
+    td = t.to(dev)
+    _lib.call("ssv_ema", 777, _lib.ptr(td), _lib.ptr(o.to(dev)), 0.996, _lib.stream())
+    close(td, 0.996 * t + (1.0 - 0.996) * o, rtol=1e-6, what="ema")
+
+
+def test_l2norm(dev):
+    from ssv_amd import ops
+    z = seeded_randn(51, 37, 100).requires_grad_()
+    zh = F.normalize(z, p=2, dim=-1)
+    d = seeded_randn(52, 37, 100)
+    zh.backward(d)
+    zd = z.detach().to(dev)
+    zhat, inv = ops.l2norm_fwd(zd, True, ldo=128)
+    close(zhat[:, :100], zh, what="l2norm fwd")
+    assert float(zhat[:, 100:].abs().max()) == 0.0
+    dpad = torch.zeros(37, 128)
+    dpad[:, :100] = d
+    close(ops.l2norm_bwd(zhat, inv, dpad.to(dev), 100, True), z.grad, what="l2norm bwd")
+
+
+def test_ntxent_matches_reference_golden(dev, golden):
+    from ssv_amd.utils import losses
+    g = golden["loss_level"]
+    for tag, (n, d, seed, norm, temp) in zip("abcde", g["ntxent_cases"]):
+        n, d, seed = int(n), int(d), int(seed)
+        zi = seeded_randn(seed, n, d).to(dev).requires_grad_()
+        zj = seeded_randn(seed + 1000, n, d).to(dev).requires_grad_()
+        loss = losses.SimclrLoss(bool(norm), float(temp))(zi, zj)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"ntxent_{tag}_loss"], rtol=5e-6, err_msg=f"case {tag}")
+        close(zi.grad, torch.tensor(g[f"ntxent_{tag}_dzi"]), rtol=2e-4, what=f"ntxent dzi {tag}")
+        close(zj.grad, torch.tensor(g[f"ntxent_{tag}_dzj"]), rtol=2e-4, what=f"ntxent dzj {tag}")
+
+
+def test_ntxent_large_and_scaled_upstream(dev):
+    """N=256 (BASELINE config 2 loss shape) against the oracle, with a non-unit upstream gradient."""
+    from ssv_amd.utils import losses
+    zi, zj = seeded_randn(61, 256, 128), seeded_randn(62, 256, 128)
+    a, b = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+    ref = oracle.ntxent_loss(a, b, True, 0.5)
+    (ref * 0.37).backward()
+    zid, zjd = zi.to(dev).requires_grad_(), zj.to(dev).requires_grad_()
+    loss = losses.SimclrLoss(True, 0.5)(zid, zjd)
+    (loss * 0.37).backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    close(zid.grad, a.grad, rtol=2e-4, what="dzi")
+    close(zjd.grad, b.grad, rtol=2e-4, what="dzj")
+
+
+def test_ntxent_sharded_rows_equal_global(dev):
+    """Multi-GPU form on one device: each 'rank' computes its own row block against the gathered Z;
+    the per-rank losses sum to the global loss and the per-rank dZ blocks tile the global dZ."""
+    from ssv_amd import _lib, ops
+    nglob, d, world = 96, 64, 4
+    b = nglob // world
+    zi, zj = seeded_randn(71, nglob, d), seeded_randn(72, nglob, d)
+    a, c = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+    ref = oracle.ntxent_loss(a, c, True, 0.2)
+    ref.backward()
+    zall = torch.cat([oracle.l2_normalize(zi), oracle.l2_normalize(zj)]).to(dev).contiguous()
+    lse_all = torch.empty(2 * nglob, device=dev)
+    total = 0.0
+    parts = []
+    for r in range(world):
+        lse, pos = torch.empty(2 * b, device=dev), torch.empty(2 * b, device=dev)
+        _lib.call("ssv_ntxent_fwd", nglob, b, r * b, d, _lib.ptr(zall), 5.0, _lib.ptr(lse), _lib.ptr(pos), _lib.stream())
+        out = torch.empty((), device=dev)
+        _lib.call("ssv_ntxent_loss", 2 * b, _lib.ptr(lse), _lib.ptr(pos), 1.0 / (2 * nglob), _lib.ptr(out), _lib.stream())
+        total += out.item()
+        lse_all[r * b:(r + 1) * b] = lse[:b]
+        lse_all[nglob + r * b:nglob + (r + 1) * b] = lse[b:]
+    np.testing.assert_allclose(total, ref.item(), rtol=3e-6)
+    # reference dZhat from autograd on normalised inputs
+    zh_i, zh_j = oracle.l2_normalize(zi).detach().requires_grad_(), oracle.l2_normalize(zj).detach().requires_grad_()
+    oracle.ntxent_loss(zh_i, zh_j, False, 0.2).backward()
+    for r in range(world):
+        dz = torch.empty((2 * b, d), device=dev)
+        _lib.call("ssv_ntxent_bwd", nglob, b, r * b, d, _lib.ptr(zall), _lib.ptr(lse_all), 5.0, 5.0 / (2 * nglob), _lib.ptr(dz), _lib.stream())
+        close(dz[:b], zh_i.grad[r * b:(r + 1) * b], rtol=2e-4, what=f"rank {r} dzi")
+        close(dz[b:], zh_j.grad[r * b:(r + 1) * b], rtol=2e-4, what=f"rank {r} dzj")
+
+
+def test_byol_loss_matches_reference_golden(dev, golden):
+    from ssv_amd import ops
+    from ssv_amd.utils import losses
+    g = golden["loss_level"]
+    p1, p2 = seeded_randn(31, 16, 128), seeded_randn(32, 16, 128)
+    t1, t2 = oracle.l2_normalize(seeded_randn(33, 16, 128)).to(dev), oracle.l2_normalize(seeded_randn(34, 16, 128)).to(dev)
+    h1, i1 = ops.l2norm_fwd(p1.to(dev), True)
+    h2, i2 = ops.l2norm_fwd(p2.to(dev), True)
+    o1, o2 = h1.clone().requires_grad_(), h2.clone().requires_grad_()
+    loss = losses.byol_pair_loss(o1, o2, t1, t2)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["byol_loss"], rtol=3e-6)
+    close(ops.l2norm_bwd(h1, i1, o1.grad, 128, True), torch.tensor(g["byol_dp1"]), rtol=2e-4, what="byol dp1")
+    close(ops.l2norm_bwd(h2, i2, o2.grad, 128, True), torch.tensor(g["byol_dp2"]), rtol=2e-4, what="byol dp2")
