@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of the SimCLR ResNet-50 two-view training step on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference train_step (models/simclr.py:86-95) on one per-GPU batch: two views ->
+ResNet-50 (std 7x7/2 stem) + projector forward with per-view BatchNorm -> NT-Xent over the GLOBAL batch
+(RCCL all-gather of the embeddings) -> backward -> gradient all-reduce -> SGD-Nesterov -> loss.item().
+Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_macs_resnet50(h, w, proj_dim=128):
+    """Algorithmic MACs per VIEW: (conv fwd, conv bwd = dgrad + wgrad without the stem's dgrad, projector fwd)."""
+    macs, first = [], True
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    macs.append(ho * wo * 64 * 49 * 3)
+    ho, wo = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    cin = 64
+    for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for b in range(blocks):
+            s = stride if b == 0 else 1
+            macs.append(ho * wo * planes * cin)                                   # conv1 1x1
+            h2, w2 = (ho + 2 - 3) // s + 1, (wo + 2 - 3) // s + 1
+            macs.append(h2 * w2 * planes * planes * 9)                            # conv2 3x3 (stride here)
+            macs.append(h2 * w2 * planes * 4 * planes)                            # conv3 1x1
+            if b == 0:
+                macs.append(h2 * w2 * planes * 4 * cin)                           # downsample 1x1
+            cin, ho, wo = planes * 4, h2, w2
+    fwd = sum(macs)
+    bwd = 2 * fwd - macs[0]
+    proj = 2048 * 2048 + 2048 * proj_dim
+    return fwd, bwd, proj
+
+
+def build(device, batch):
+    from ssv_amd.models import heads
+    from ssv_amd.networks import resnet
+    from ssv_amd.utils import losses, train_utils
+    from ssv_amd import distributed as hdist
+    torch.manual_seed(420)                                     # identical weights on every rank
+    encoder = resnet.resnet50().to(device)
+    head = heads.SimclrProjectionHead(2048, 128).to(device)
+    optim = train_utils.get_optimizer({"name": "sgd", "lr": 2.0, "weight_decay": 1e-4},
+                                      list(encoder.parameters()) + list(head.parameters()))
+    train_utils.get_scheduler({"name": "cosine", "warmup_epochs": 10, "epochs": 1000}, optim)      # lr seeded to 0.2
+    hdist.attach_grad_sync(optim)
+    loss_fn = losses.SimclrLoss(normalize=True, temperature=0.5)
+
+    def step(v1, v2):
+        z1 = head(encoder(v1))
+        z2 = head(encoder(v2))
+        loss = loss_fn(z1, z2)
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        return loss.item()
+    return step, sum(p.numel() for p in optim.arena.params)
+
+
+def cpu_baseline(batch, size, steps):
+    """The oracle (CPU restatement of the reference step, pinned to reference fixtures) on this box's host cores."""
+    import oracle
+    from oracle.nets import ENCODER_DIM  # noqa: F401
+    # 256 host threads on a batch of 8-16 images is pathological (measured 0.02 images/s); 32 is what a
+    # dataloader-less single-socket run realistically uses.  `cores` below reports the threads actually used.
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    m = oracle.SimCLROracle("resnet50", False, 128, lr=0.2, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(7)
+    v1, v2 = torch.randn(batch, 3, size, size, generator=g), torch.randn(batch, 3, size, size, generator=g)
+    m.train_step(v1, v2)                                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step(v1, v2)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (1 warm-up) of the same SimCLR ResNet-50 {size}x{size} step at batch {batch}, torch fp32 CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSV_BENCH_BATCH", "512")), help="per-GPU batch (images)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=2, help="extra instrumented steps for the per-kernel-class roofline")
+    args = ap.parse_args()
+
+    from ssv_amd import _lib, distributed as hdist
+    rank, world = hdist.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    device = torch.device("cuda", torch.cuda.current_device())
+    _lib.load()
+
+    b, s = args.batch, args.size
+    step, nparams = build(device, b)
+    g = torch.Generator(device=device).manual_seed(420 + rank)
+    # synthetic views, NHWC in memory (channels_last), resident in HBM
+    v1 = torch.randn(b, s, s, 3, generator=g, device=device).permute(0, 3, 1, 2)
+    v2 = torch.randn(b, s, s, 3, generator=g, device=device).permute(0, 3, 1, 2)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = step(v1, v2)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(v1, v2)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    images_per_s = b * world * args.steps / dt
+
+    # ---- per-kernel-class timing (HIP events on the launch stream) over extra instrumented steps --------------
+    fwd, bwd, proj = conv_macs_resnet50(s, s)
+    conv_flop_step = 2.0 * (fwd + bwd + 3 * proj) * 2 * b                     # per GPU: 2 FLOP/MAC, 2 views
+    roof, classes = None, {}
+    if args.prof_steps > 0:
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        for _ in range(args.prof_steps):
+            step(v1, v2)
+        torch.cuda.synchronize()
+        prof = _lib.prof_collect()
+        _lib.prof_enable(False)
+        classes = {k: {"ms_per_step": round(v[0] / args.prof_steps, 3), "launches_per_step": v[1] // args.prof_steps} for k, v in prof.items() if v[1]}
+        conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
+        conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
+        ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv implicit-GEMM family (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
+                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
+                "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
+                "whole_step_mfma_frac": round(images_per_s / world * 2.0 * (fwd + bwd + 3 * proj) * 2 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "classes": classes}
+
+    out = {
+        "metric": "images/sec (whole node) SimCLR ResNet-50 two-view train step", "value": round(images_per_s, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SimCLR resnet50 (7x7/2 stem) synthetic 3x{s}x{s}, bs={b}/GPU, global batch {b * world}, "
+                               f"NT-Xent(normalize, T=0.5) over the global batch, SGD-Nesterov; fp32 views resident in HBM",
+                   "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
+                   "parallelism": f"dp{world}" if world > 1 else "single", "last_loss": loss},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(batch=16, size=s, steps=2)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

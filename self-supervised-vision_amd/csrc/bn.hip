@@ -43,7 +43,13 @@ bn_stats_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ 
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, K = {0, 0, 0, 0};
   if (active) {
     K = ld4(x + r0 * C + 4 * c4);
-    for (int64_t r = r0 + rt; r < r1; r += RT) {
+    int64_t r = r0 + rt;
+    for (; r + 3 * RT < r1; r += 4 * RT) {          // 4 independent 16-B loads in flight per lane
+      const f32x4 v0 = ld4(x + r * C + 4 * c4) - K, v1 = ld4(x + (r + RT) * C + 4 * c4) - K;
+      const f32x4 v2 = ld4(x + (r + 2 * RT) * C + 4 * c4) - K, v3 = ld4(x + (r + 3 * RT) * C + 4 * c4) - K;
+      s1 += (v0 + v1) + (v2 + v3); s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+    for (; r < r1; r += RT) {
       const f32x4 v = ld4(x + r * C + 4 * c4) - K;
       s1 += v; s2 += v * v;
     }
@@ -60,41 +66,39 @@ bn_stats_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ 
   }
 }
 
-// one thread per (channel, merge group); 4 groups merged through LDS in fixed order
+// Merge of the per-block (mean_b, M2_b): 32 channels x 8 groups of blocks per workgroup (128-B coalesced
+// rows of the partial arrays), two division-free passes in double:
+//   mean = sum_b n_b*mean_b / M ;  M2 = sum_b (M2_b + n_b*(mean_b-mean)^2)      (fixed summation order)
 __global__ void __launch_bounds__(256)
 bn_stats_finalize_k(int64_t M, int C, int rpb, int nblk, const float* __restrict__ pmean, const float* __restrict__ pm2,
                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* nbt,
                     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double sn[4][64], smean[4][64], sm2[4][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  if (c < C) {
-    const int per = (nblk + 3) / 4;
-    const int b0 = grp * per, b1 = min(b0 + per, nblk);
-    for (int b = b0; b < b1; ++b) {
-      const int64_t rb0 = (int64_t)b * rpb;
-      const double nb = (double)((rb0 + rpb < M ? rb0 + rpb : M) - rb0);
-      const double mb = (double)pmean[(size_t)b * C + c], m2b = (double)pm2[(size_t)b * C + c];
-      const double nt = n + nb, delta = mb - mean;
-      mean += delta * nb / nt;
-      m2 += m2b + delta * delta * n * nb / nt;
-      n = nt;
-    }
-  }
-  sn[grp][cl] = n; smean[grp][cl] = mean; sm2[grp][cl] = m2;
+  __shared__ double sm[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  const int per = (nblk + 7) / 8;
+  const int b0 = grp * per, b1 = min(b0 + per, nblk);
+  const double last_n = (double)(M - (int64_t)(nblk - 1) * rpb);
+  double acc = 0.0;
+  if (ok) for (int b = b0; b < b1; ++b) acc += (b == nblk - 1 ? last_n : (double)rpb) * (double)pmean[(size_t)b * C + c];
+  sm[grp][cl] = acc;
   __syncthreads();
-  if (grp == 0 && c < C) {
-    for (int g = 1; g < 4; ++g) {
-      const double nb = sn[g][cl];
-      if (nb > 0.0) {
-        const double nt = n + nb, delta = smean[g][cl] - mean;
-        mean += delta * nb / nt;
-        m2 += sm2[g][cl] + delta * delta * n * nb / nt;
-        n = nt;
-      }
-    }
+  double mean = 0.0;
+  for (int g = 0; g < 8; ++g) mean += sm[g][cl];
+  mean /= (double)M;
+  __syncthreads();
+  acc = 0.0;
+  if (ok) for (int b = b0; b < b1; ++b) {
+    const double d = (double)pmean[(size_t)b * C + c] - mean;
+    acc += (double)pm2[(size_t)b * C + c] + (b == nblk - 1 ? last_n : (double)rpb) * d * d;
+  }
+  sm[grp][cl] = acc;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    double m2 = 0.0;
+    for (int g = 0; g < 8; ++g) m2 += sm[g][cl];
     const double var = m2 / (double)M;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
@@ -123,13 +127,16 @@ bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ 
   const f32x4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
-  for (int64_t r = r0 + rt; r < r1; r += RT) {
+  auto body = [&](int64_t r) {
     const size_t o = (size_t)r * C + 4 * c4;
     f32x4 v = ld4(x + o) * sc + sh;
     if constexpr (RES) v += ld4(res + o);
     if constexpr (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     st4(y + o, v);
-  }
+  };
+  int64_t r = r0 + rt;
+  for (; r + 3 * RT < r1; r += 4 * RT) { body(r); body(r + RT); body(r + 2 * RT); body(r + 3 * RT); }
+  for (; r < r1; r += RT) body(r);
 }
 
 // ---- backward ----------------------------------------------------------------------------------
@@ -157,13 +164,16 @@ bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restri
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
   if (active) {
     const f32x4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
-    for (int64_t r = r0 + rt; r < r1; r += RT) {
+    auto body = [&](int64_t r) {
       const size_t o = (size_t)r * C + 4 * c4;
       f32x4 g = ld4(dy + o);
       if constexpr (RELU) g = masked<true>(g, ld4(y + o));
       const f32x4 xh = (ld4(x + o) - mu) * is;
       s1 += g; s2 += g * xh;
-    }
+    };
+    int64_t r = r0 + rt;
+    for (; r + 3 * RT < r1; r += 4 * RT) { body(r); body(r + RT); body(r + 2 * RT); body(r + 3 * RT); }
+    for (; r < r1; r += RT) body(r);
   }
   sm1[tid] = s1; sm2[tid] = s2;
   __syncthreads();
@@ -177,14 +187,24 @@ bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restri
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, const float* __restrict__ psgx,
                   float* dgamma, float* dbeta, int accumulate, float* __restrict__ k1, float* __restrict__ k2) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double s1[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  const int per = (nblk + 7) / 8;
+  const int b0 = grp * per, b1 = min(b0 + per, nblk);
   double sg = 0.0, sgx = 0.0;
-  for (int b = 0; b < nblk; ++b) { sg += (double)psg[(size_t)b * C + c]; sgx += (double)psgx[(size_t)b * C + c]; }
-  k1[c] = (float)(sg / (double)M);
-  k2[c] = (float)(sgx / (double)M);
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
+  if (ok) for (int b = b0; b < b1; ++b) { sg += (double)psg[(size_t)b * C + c]; sgx += (double)psgx[(size_t)b * C + c]; }
+  s1[grp][cl] = sg; s2[grp][cl] = sgx;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    sg = 0.0; sgx = 0.0;
+    for (int g = 0; g < 8; ++g) { sg += s1[g][cl]; sgx += s2[g][cl]; }
+    k1[c] = (float)(sg / (double)M);
+    k2[c] = (float)(sgx / (double)M);
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
+  }
 }
 
 template <bool RELU, bool DRES>
@@ -201,14 +221,17 @@ bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restric
   const f32x4 gi = ld4(gamma + 4 * c4) * is, a1 = ld4(k1 + 4 * c4), a2 = ld4(k2 + 4 * c4);
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
-  for (int64_t r = r0 + rt; r < r1; r += RT) {
+  auto body = [&](int64_t r) {
     const size_t o = (size_t)r * C + 4 * c4;
     f32x4 g = ld4(dy + o);
     if constexpr (RELU) g = masked<true>(g, ld4(y + o));
     const f32x4 xh = (ld4(x + o) - mu) * is;
     st4(dx + o, gi * (g - a1 - xh * a2));
     if constexpr (DRES) st4(dres + o, g);
-  }
+  };
+  int64_t r = r0 + rt;
+  for (; r + 3 * RT < r1; r += 4 * RT) { body(r); body(r + RT); body(r + 2 * RT); body(r + 3 * RT); }
+  for (; r < r1; r += RT) body(r);
 }
 
 // ---- column sum --------------------------------------------------------------------------------
@@ -230,12 +253,23 @@ colsum_partial_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restr
     st4(ps + (size_t)blockIdx.x * C + 4 * c4, s1);
   }
 }
-__global__ void colsum_finalize_k(int C, int nblk, const float* __restrict__ ps, float* out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256)
+colsum_finalize_k(int C, int nblk, const float* __restrict__ ps, float* out, int accumulate) {
+  __shared__ double s1[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  const int per = (nblk + 7) / 8;
+  const int b0 = grp * per, b1 = min(b0 + per, nblk);
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)ps[(size_t)b * C + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  if (ok) for (int b = b0; b < b1; ++b) s += (double)ps[(size_t)b * C + c];
+  s1[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    s = 0.0;
+    for (int g = 0; g < 8; ++g) s += s1[g][cl];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  }
 }
 
 int check_mc(int64_t M, int C, const char* who) {
@@ -269,7 +303,7 @@ extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const floa
   float* shift = scale + C;
   const dim3 grid(p.nblk, p.GY);
   hipLaunchKernelGGL(bn_stats_k, grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, pmean, pm2);
-  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, 64)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
                      gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   if (relu) {
     if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
@@ -300,7 +334,7 @@ extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const flo
   const dim3 grid(p.nblk, p.GY);
   if (relu) hipLaunchKernelGGL((bn_bwd_reduce_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
   else      hipLaunchKernelGGL((bn_bwd_reduce_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
                      dgamma, dbeta, accumulate, k1, k2);
   const float* ck1 = k1; const float* ck2 = k2;
   if (relu) {
@@ -324,7 +358,7 @@ extern "C" int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int 
   const BnPlan p = bn_plan(M, C);
   float* part = (float*)ws;
   hipLaunchKernelGGL(colsum_partial_k, dim3(p.nblk, p.GY), dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, part);
-  hipLaunchKernelGGL(colsum_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, s, C, p.nblk, (const float*)part, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, C, p.nblk, (const float*)part, out, accumulate);
   SSV_CHECK_LAUNCH("ssv_colsum");
   return SSV_OK;
 }

@@ -509,12 +509,27 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   }
 }
 
-__global__ void wgrad_reduce_k(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ dw, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? dw[i] : 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
-  dw[i] = s;
+// dw (+)= sum over split slabs, fixed order: 64 consecutive elements x 4 groups of slabs per workgroup
+__global__ void __launch_bounds__(256)
+wgrad_reduce_k(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ dw, int accumulate) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  const int per = (nsplit + 3) / 4;
+  const int k0 = grp * per, k1 = min(k0 + per, nsplit);
+  float s = 0.f;
+  if (i < n) {
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      const float a = partial[(size_t)k * n + i], b = partial[(size_t)(k + 1) * n + i];
+      const float c = partial[(size_t)(k + 2) * n + i], d = partial[(size_t)(k + 3) * n + i];
+      s += (a + b) + (c + d);
+    }
+    for (; k < k1; ++k) s += partial[(size_t)k * n + i];
+  }
+  sm[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) dw[i] = (accumulate ? dw[i] : 0.f) + ((sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -552,7 +567,7 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
   w.it = cdiv(d->K, w.bm);
   w.jt = cdiv(RSC, w.bn);
   const int tiles = w.it * w.jt;
-  int64_t ns = cdiv64(1024, tiles);
+  int64_t ns = cdiv64(768, tiles);            // ~3 workgroups per CU
   const int64_t max_by_rows = cdiv64(M, 256);
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
@@ -643,7 +658,7 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(partial)");
   const int64_t n = (int64_t)d->K * p.RSC;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, accumulate);
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(reduce)");
   return SSV_OK;
 }
