@@ -125,6 +125,14 @@ size_t ssv_reduce_workspace_bytes(int64_t n);
 /* x[i] *= *factor_dev (factor read on the device: no host sync) - chain-rule scale by an upstream grad */
 int ssv_scale(int64_t n, float* x, const float* factor_dev, void* stream);
 
+/* ---- Barlow Twins loss: BarlowLoss.forward utils/losses.py:127-142 --------------------------
+ * The column standardisation (unbiased std, no eps) is ssv_bn_train_fwd/bwd with gamma = sqrt((B-1)/B), beta = 0,
+ * eps = 0; the D x D cross-correlation and the two gradient products are ssv_conv2d_wgrad / _fwd / _dgrad (MFMA).
+ * This entry point is the element-wise middle: from Craw = zi_hat^T zj_hat to loss = sum W o (Craw/B - I)^2 and
+ * G = dloss/dCraw-side factor 2 W o (Craw/B - I) / B.  Workspace: ssv_reduce_workspace_bytes(D*D). */
+int ssv_barlow_cgrad(int32_t D, const float* craw, float inv_b, float lambda, float* loss, float* G,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimizer: optim.SGD(momentum=0.9, nesterov=True, weight_decay) utils/train_utils.py:11-13
  * over a flat arena of n floats.  first_step != 0 seeds buf = g. */
 int ssv_sgd_nesterov(int64_t n, float* p, const float* g, float* buf, float lr, float weight_decay,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ssv_reduce_workspace_bytes": (_sz, [_i64]),
     "ssv_mse_pair_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_scale": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "ssv_barlow_cgrad": (C.c_int, [_i32, _vp, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "ssv_sgd_nesterov": (C.c_int, [_i64, _vp, _vp, _vp, _f32, _f32, _f32, C.c_int, _vp]),
     "ssv_ema": (C.c_int, [_i64, _vp, _vp, _f32, _vp]),
     "ssv_fill": (C.c_int, [_i64, _vp, _f32, _vp]),

@@ -228,6 +228,28 @@ __global__ void sum_partials_k(int nblk, const double* __restrict__ part, float 
   }
 }
 
+// Barlow Twins: from the raw cross-correlation Craw = zi_hat^T zj_hat (D x D) to the loss and dL/dC.
+//   C = Craw * inv_b ; L = sum_ij W_ij (C_ij - delta_ij)^2, W = 1 on the diagonal, lambda elsewhere;
+//   G_ij = 2 W_ij (C_ij - delta_ij) * inv_b   (the 1/B of C = ./B is folded in, ready for the two GEMMs)
+__global__ void __launch_bounds__(256)
+barlow_cgrad_k(int D, const float* __restrict__ craw, float inv_b, float lambda, float* __restrict__ G, double* __restrict__ part) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  const int64_t n = (int64_t)D * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+    const bool diag = r == c;
+    const float d = craw[i] * inv_b - (diag ? 1.f : 0.f);
+    const float w = diag ? 1.f : lambda;
+    s += (double)(w * d * d);
+    G[i] = 2.f * w * d * inv_b;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
 __global__ void scale_k(int64_t n, float* __restrict__ x, const float* __restrict__ factor) {
   const float f = *factor;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
@@ -336,5 +358,19 @@ extern "C" int ssv_scale(int64_t n, float* x, const float* factor_dev, void* str
   ProfScope ps(SSV_PROF_MISC, s);
   hipLaunchKernelGGL(scale_k, dim3(reduce_blocks(n)), dim3(256), 0, s, n, x, factor_dev);
   SSV_CHECK_LAUNCH("ssv_scale");
+  return SSV_OK;
+}
+
+extern "C" int ssv_barlow_cgrad(int32_t D, const float* craw, float inv_b, float lambda, float* loss, float* G,
+                                void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(D > 0 && craw && loss && G && ws, "ssv_barlow_cgrad: bad arguments");
+  const int64_t n = (int64_t)D * D;
+  if (ws_bytes < ssv_reduce_workspace_bytes(n)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_barlow_cgrad: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  const int nb = reduce_blocks(n);
+  hipLaunchKernelGGL(barlow_cgrad_k, dim3(nb), dim3(256), 0, s, D, craw, inv_b, lambda, G, (double*)ws);
+  hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(64), 0, s, nb, (const double*)ws, 1.0f, loss);
+  SSV_CHECK_LAUNCH("ssv_barlow_cgrad");
   return SSV_OK;
 }

@@ -105,3 +105,78 @@ class _MSEPairFn(torch.autograd.Function):
 def byol_pair_loss(online_1, online_2, target_1, target_2):
     """MSE(online_1, target_2) + MSE(online_2, target_1), each a mean over B*D (models/byol.py:129-130)."""
     return _MSEPairFn.apply(online_1, online_2, target_1, target_2)
+
+
+class _BarlowFn(torch.autograd.Function):
+    """Whole Barlow Twins loss + its gradient w.r.t. both embedding matrices, composed from the C ABI:
+    [F.normalize] -> column standardisation (BN kernels, gamma = sqrt((B-1)/B), eps = 0 = unbiased std without eps)
+    -> Craw = zi_hat^T zj_hat (wgrad-shaped MFMA GEMM over the batch) -> loss / G (ssv_barlow_cgrad)
+    -> d zi_hat = zj_hat G^T (fwd-shaped GEMM), d zj_hat = zi_hat G (dgrad-shaped GEMM) -> BN backward [-> normalize backward].
+    Data parallel: the embeddings are all-gathered and every rank evaluates the global-batch loss redundantly
+    (3 GEMMs of B x D x D - cheaper than a 64 MB all-reduce of C), then keeps the gradient rows of its own samples."""
+
+    @staticmethod
+    def forward(ctx, zi, zj, normalize, lmbda):
+        if not zi.is_cuda:
+            raise _lib.SsvError("BarlowLoss: the HIP path needs device tensors; there is no CPU fallback")
+        bl, d = zi.shape
+        if d % 16:
+            raise _lib.SsvError(f"BarlowLoss: projection dim must be a multiple of 16 (got {d})")
+        world, rank = hdist.world_size(), hdist.rank()
+        b = bl * world
+        dev = zi.device
+        zs = []
+        for z in (zi, zj):
+            zall = torch.empty((b, d), dtype=torch.float32, device=dev)
+            zall[rank * bl:(rank + 1) * bl].copy_(z.detach())
+            if world > 1:
+                hdist.all_gather_rows(zall, bl)
+            zs.append(zall)
+        invs = [None, None]
+        if normalize:
+            for k in range(2):
+                zs[k], invs[k] = ops.l2norm_fwd(zs[k], True)
+        gamma = ops.fill_(torch.empty(d, dtype=torch.float32, device=dev), ((b - 1) / b) ** 0.5)
+        beta = ops.fill_(torch.empty(d, dtype=torch.float32, device=dev), 0.0)
+        hats, stats = [], []
+        for k in range(2):
+            y, mean, invstd = ops.bn_train_fwd(zs[k], gamma, beta, None, None, None, relu=False, eps=0.0)
+            hats.append(y)
+            stats.append((mean, invstd))
+        craw = torch.empty((d, d), dtype=torch.float32, device=dev)
+        ops.conv2d_wgrad(hats[1].view(b, 1, 1, d), hats[0].view(b, 1, 1, d), craw, craw, accumulate=False)   # craw[i][j] = sum_b zi_hat[b,i] zj_hat[b,j]
+        g = torch.empty((d, d), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(d * d), dev)
+        _lib.call("ssv_barlow_cgrad", d, _lib.ptr(craw), 1.0 / b, float(lmbda), _lib.ptr(loss), _lib.ptr(g), _lib.ptr(ws), ws.numel(), _lib.stream())
+        dhat_i = ops.conv2d_fwd(hats[1].view(b, 1, 1, d), g).view(b, d)                     # [b,i] = sum_j zj_hat[b,j] G[i,j]
+        dhat_j = ops.conv2d_dgrad(hats[0].view(b, 1, 1, d), g, (b, 1, 1, d)).view(b, d)     # [b,j] = sum_i zi_hat[b,i] G[i,j]
+        dgam, dbet = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
+        grads = []
+        for k, dh in enumerate((dhat_i, dhat_j)):
+            dz, _ = ops.bn_train_bwd(dh, None, zs[k], gamma, stats[k][0], stats[k][1], False, dgam, dbet, accumulate=False)
+            if normalize:
+                dz = ops.l2norm_bwd(zs[k], invs[k], dz, d, True)
+            grads.append(dz[rank * bl:(rank + 1) * bl])
+        ctx.saved = grads
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dzi, dzj = ctx.saved
+        g = dloss.contiguous()
+        return ops.scale_(dzi.contiguous(), g), ops.scale_(dzj.contiguous(), g), None, None
+
+
+class BarlowLoss(nn.Module):
+    """Barlow Twins loss (utils/losses.py:120-142): defaults normalize=True, off_diagonal_weight=0.005 like the reference."""
+
+    def __init__(self, normalize=True, off_diagonal_weight=0.005):
+        super().__init__()
+        self.normalize = normalize
+        self.lmbda = off_diagonal_weight
+
+    def forward(self, z_i, z_j):
+        if z_i.shape != z_j.shape or z_i.dim() != 2:
+            raise ValueError(f"BarlowLoss expects two [B,D] matrices, got {tuple(z_i.shape)} and {tuple(z_j.shape)}")
+        return _BarlowFn.apply(z_i, z_j, self.normalize, self.lmbda)

@@ -280,3 +280,32 @@ def test_byol_loss_matches_reference_golden(dev, golden):
     np.testing.assert_allclose(loss.item(), g["byol_loss"], rtol=3e-6)
     close(ops.l2norm_bwd(h1, i1, o1.grad, 128, True), torch.tensor(g["byol_dp1"]), rtol=2e-4, what="byol dp1")
     close(ops.l2norm_bwd(h2, i2, o2.grad, 128, True), torch.tensor(g["byol_dp2"]), rtol=2e-4, what="byol dp2")
+
+
+def test_barlow_matches_reference_golden(dev, golden):
+    from ssv_amd.utils import losses
+    g = golden["loss_level"]
+    for tag, (b, d, seed, norm, lm) in zip("abc", g["barlow_cases"]):
+        b, d, seed = int(b), int(d), int(seed)
+        zi = seeded_randn(seed, b, d).to(dev).requires_grad_()
+        zj = seeded_randn(seed + 1000, b, d).to(dev).requires_grad_()
+        loss = losses.BarlowLoss(bool(norm), float(lm))(zi, zj)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"barlow_{tag}_loss"], rtol=2e-5, err_msg=f"case {tag}")
+        close(zi.grad, torch.tensor(g[f"barlow_{tag}_dzi"]), rtol=5e-4, what=f"barlow dzi {tag}")
+        close(zj.grad, torch.tensor(g[f"barlow_{tag}_dzj"]), rtol=5e-4, what=f"barlow dzj {tag}")
+
+
+def test_barlow_config_shape_matches_oracle(dev):
+    """configs/barlow.yaml shape: D = 4096 (a 4096 x 4096 x B contraction on MFMA), B = 128, normalize=False."""
+    from ssv_amd.utils import losses
+    zi, zj = oracle.l2_normalize(seeded_randn(81, 128, 4096)), oracle.l2_normalize(seeded_randn(82, 128, 4096))   # head ends in L2-normalise
+    a, b = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+    ref = oracle.barlow_loss(a, b, False, 0.005)
+    ref.backward()
+    zid, zjd = zi.to(dev).requires_grad_(), zj.to(dev).requires_grad_()
+    loss = losses.BarlowLoss(False, 0.005)(zid, zjd)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    close(zid.grad, a.grad, rtol=1e-3, what="dzi")
+    close(zjd.grad, b.grad, rtol=1e-3, what="dzj")
