@@ -143,6 +143,33 @@ int ssv_fill(int64_t n, float* p, float value, void* stream);
 /* dst[i] += src[i]  (gradient accumulation where no producer kernel can fuse it) */
 int ssv_add(int64_t n, float* dst, const float* src, void* stream);
 
+/* ---- two-view augmentation (R1): the chain of configs/simclr.yaml:13-29 on the GPU ----------
+ * replaces DoubleAugmentedDataset.__getitem__ utils/data_utils.py:68-73 / get_transform
+ * utils/augmentations.py:128-144 (torchvision 0.9.1 + Pillow 8.3.1 in DataLoader workers).
+ * src: uint8 [nsrc][Hs][Ws][3] (PIL layout) resident in HBM; sample_ids (device int64[B], may be NULL = 0..B-1)
+ * selects the rows.  params: [nviews][B][SSV_AUG_NPARAM] float32 records
+ *   [0] jitter on, [1..4] op order (0 brightness 1 contrast 2 saturation 3 hue), [5..8] the four factors,
+ *   [9] gray on, [10..13] crop top,left,height,width, [14] flip on
+ * drawn by ssv_augment_params from Philox4x32-10 keyed (seed; sample id, view, step) with torchvision's
+ * distributions, or supplied by the caller.  out: fp32 NHWC [nviews][B][Ho][Wo][3], normalised.
+ * Pixel arithmetic is Pillow's, bit for bit (oracle/augment.py).  mean3/std3 are HOST pointers to 3 floats. */
+#define SSV_AUG_NPARAM 16
+typedef struct ssv_aug_cfg {
+  double brightness, contrast, saturation, hue;     /* ColorJitter ranges: factor in [max(0,1-x), 1+x], hue in [-h, h] */
+  double p_jitter, p_gray, p_flip;                  /* RandomApply p, RandomGrayscale p, RandomHorizontalFlip p */
+  double scale_min, scale_max, ratio_min, ratio_max;/* RandomResizedCrop */
+} ssv_aug_cfg;
+int ssv_augment_params(int32_t B, int32_t Hs, int32_t Ws, int32_t nviews, const ssv_aug_cfg* cfg, uint64_t seed, uint64_t step,
+                       const int64_t* sample_ids, int64_t sample0, float* params, void* stream);
+size_t ssv_augment_workspace_bytes(int32_t B, int32_t nviews, int32_t Ho, int32_t Wo);
+int ssv_augment_views(int32_t B, int32_t nviews, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
+                      const uint8_t* src, const int64_t* sample_ids, const float* params,
+                      const float* mean3_host, const float* std3_host, float* out,
+                      void* ws, size_t ws_bytes, void* stream);
+/* CenterCrop -> ToTensor -> Normalize: the "img" entry of the batch (configs/simclr.yaml:24-29) */
+int ssv_center_view(int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo, const uint8_t* src, const int64_t* sample_ids,
+                    const float* mean3_host, const float* std3_host, float* out, void* stream);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
  * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
  * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */

@@ -22,7 +22,14 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
 
 
+class AugCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("brightness", "contrast", "saturation", "hue", "p_jitter", "p_gray", "p_flip",
+                                          "scale_min", "scale_max", "ratio_min", "ratio_max")]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_u64 = C.c_uint64
+_f3 = C.POINTER(C.c_float)
 _cd = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/ssv_hip.h one to one
@@ -57,6 +64,10 @@ SIGNATURES = {
     "ssv_ema": (C.c_int, [_i64, _vp, _vp, _f32, _vp]),
     "ssv_fill": (C.c_int, [_i64, _vp, _f32, _vp]),
     "ssv_add": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "ssv_augment_params": (C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(AugCfg), _u64, _u64, _vp, _i64, _vp, _vp]),
+    "ssv_augment_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "ssv_augment_views": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f3, _f3, _vp, _vp, _sz, _vp]),
+    "ssv_center_view": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _f3, _f3, _vp, _vp]),
     "ssv_prof_enable": (C.c_int, [C.c_int]),
     "ssv_prof_reset": (C.c_int, []),
     "ssv_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
