@@ -73,6 +73,11 @@ def build(device, batch):
     return step, sum(p.numel() for p in optim.arena.params)
 
 
+AUG_CFG = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8},
+           "random_gray": {"p": 0.2}, "random_resized_crop": {"size": [224, 224], "scale": [0.2, 1.0]}, "random_flip": None,
+           "to_tensor": None, "normalize": {"mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225]}}
+
+
 def cpu_baseline(batch, size, steps):
     """The oracle (CPU restatement of the reference step, pinned to reference fixtures) on this box's host cores."""
     import oracle
@@ -115,11 +120,25 @@ def main():
     _lib.load()
 
     b, s = args.batch, args.size
-    step, nparams = build(device, b)
+    train_step, nparams = build(device, b)
+    # synthetic uint8 source images [B,S,S,3] ~ U{0..255}, resident in HBM before the timed region; every step draws
+    # fresh augmentation parameters (Philox keyed by global sample index and step) and builds the two views on the GPU
+    from ssv_amd.utils import augmentations
     g = torch.Generator(device=device).manual_seed(420 + rank)
-    # synthetic views, NHWC in memory (channels_last), resident in HBM
-    v1 = torch.randn(b, s, s, 3, generator=g, device=device).permute(0, 3, 1, 2)
-    v2 = torch.randn(b, s, s, 3, generator=g, device=device).permute(0, 3, 1, 2)
+    source = torch.randint(0, 256, (b, s, s, 3), generator=g, device=device, dtype=torch.uint8)
+    sample_ids = torch.arange(rank * b, (rank + 1) * b, device=device, dtype=torch.int64)
+    rows = torch.arange(b, device=device, dtype=torch.int64)
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in AUG_CFG.items()}
+    cfg["random_resized_crop"] = {"size": [s, s], "scale": [0.2, 1.0]}
+    tf = augmentations.get_transform(cfg)
+    counter = [0]
+
+    def step(_a=None, _b=None):
+        params = tf.draw(source, sample_ids, counter[0])          # RNG keyed by the GLOBAL sample id
+        views = tf.apply(source, rows, params)
+        counter[0] += 1
+        return train_step(views[0], views[1])
+    v1 = v2 = None
 
     def barrier():
         if world > 1:
@@ -170,7 +189,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"SimCLR resnet50 (7x7/2 stem) synthetic 3x{s}x{s}, bs={b}/GPU, global batch {b * world}, "
-                               f"NT-Xent(normalize, T=0.5) over the global batch, SGD-Nesterov; fp32 views resident in HBM",
+                               f"NT-Xent(normalize, T=0.5) over the global batch, SGD-Nesterov",
+                   "input": f"uint8 [B,{s},{s},3] source resident in HBM -> fused GPU two-view augmentation each step",
                    "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
                    "parallelism": f"dp{world}" if world > 1 else "single", "last_loss": loss},
         "roofline": roof,

@@ -144,6 +144,7 @@ def nchw_to_nhwc(x):
 
 
 def l2norm_fwd(z, normalize=True, ldo=None, eps=1e-12, out=None):
+    _lib._dev(z)
     rows, d = z.shape
     ldo = d if ldo is None else ldo
     zhat = out if out is not None else _empty((rows, ldo), z)
@@ -172,3 +173,25 @@ def fill_(x, value):
 def add_(dst, src):
     call("ssv_add", dst.numel(), ptr(dst), ptr(src), stream())
     return dst
+
+
+def ntxent_fwd(zall, nglob, b, seg0, inv_temp):
+    """Row log-sum-exp and positive logit of this rank's 2*b rows against the gathered [2*nglob, ld] matrix."""
+    _lib._dev(zall)
+    lse = _empty((2 * b,), zall)
+    pos = _empty((2 * b,), zall)
+    call("ssv_ntxent_fwd", nglob, b, seg0, zall.shape[1], ptr(zall), float(inv_temp), ptr(lse), ptr(pos), stream())
+    return lse, pos
+
+
+def ntxent_loss(lse, pos, scale):
+    loss = torch.empty((), dtype=torch.float32, device=lse.device)
+    call("ssv_ntxent_loss", lse.numel(), ptr(lse), ptr(pos), float(scale), ptr(loss), stream())
+    return loss
+
+
+def ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_temp, gscale):
+    _lib._dev(zall, lse_all)
+    dz = _empty((2 * b, zall.shape[1]), zall)
+    call("ssv_ntxent_bwd", nglob, b, seg0, zall.shape[1], ptr(zall), ptr(lse_all), float(inv_temp), float(gscale), ptr(dz), stream())
+    return dz

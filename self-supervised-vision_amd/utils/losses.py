@@ -17,49 +17,44 @@ def _pad32(d):
 
 
 class _NTXentFn(torch.autograd.Function):
+    """NT-Xent over the GLOBAL batch.  Each rank normalises its rows straight into their slots of the gathered
+    matrix Z = [zi_all ; zj_all], all-gathers the slots (RCCL), computes the log-sum-exp of ITS rows against all
+    columns, and - because S is symmetric - needs only the all-gathered row LSEs to form the exact gradient of the
+    global-mean loss w.r.t. its own rows (option iii): two tiny collectives, no redundant Gram work."""
+
     @staticmethod
     def forward(ctx, zi, zj, normalize, temperature):
-        if not zi.is_cuda:
-            raise _lib.SsvError("SimclrLoss: the HIP path needs device tensors; there is no CPU fallback")
         b, d = zi.shape
         ld = _pad32(d)
         if ld > 128:
             raise _lib.SsvError(f"SimclrLoss: projection dim {d} > 128 is not supported by the register-resident NT-Xent kernel yet")
         world, rank = hdist.world_size(), hdist.rank()
         nglob, seg0 = b * world, b * rank
-        dev = zi.device
-        # normalised rows of this rank, written straight into their slots of the gathered matrix
-        zall = torch.empty((2 * nglob, ld), dtype=torch.float32, device=dev)
-        zi_c, zj_c = zi.detach().contiguous(), zj.detach().contiguous()
-        _, inv_i = ops.l2norm_fwd(zi_c, normalize, ld, out=zall[seg0:seg0 + b])
-        _, inv_j = ops.l2norm_fwd(zj_c, normalize, ld, out=zall[nglob + seg0:nglob + seg0 + b])
+        zall = torch.empty((2 * nglob, ld), dtype=torch.float32, device=zi.device)
+        _, inv_i = ops.l2norm_fwd(zi.detach().contiguous(), normalize, ld, out=zall[seg0:seg0 + b])
+        _, inv_j = ops.l2norm_fwd(zj.detach().contiguous(), normalize, ld, out=zall[nglob + seg0:nglob + seg0 + b])
         if world > 1:
             hdist.all_gather_rows(zall[:nglob], b)
             hdist.all_gather_rows(zall[nglob:], b)
         inv_t = 1.0 / float(temperature)
-        lse_all = torch.empty((2 * nglob,), dtype=torch.float32, device=dev)
-        lse_loc = torch.empty((2 * b,), dtype=torch.float32, device=dev)
-        pos_loc = torch.empty((2 * b,), dtype=torch.float32, device=dev)
-        _lib.call("ssv_ntxent_fwd", nglob, b, seg0, ld, _lib.ptr(zall), inv_t, _lib.ptr(lse_loc), _lib.ptr(pos_loc), _lib.stream())
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.call("ssv_ntxent_loss", 2 * b, _lib.ptr(lse_loc), _lib.ptr(pos_loc), 1.0 / (2 * nglob), _lib.ptr(loss), _lib.stream())
+        lse_loc, pos_loc = ops.ntxent_fwd(zall, nglob, b, seg0, inv_t)
+        loss = ops.ntxent_loss(lse_loc, pos_loc, 1.0 / (2 * nglob))
         if world > 1:
             hdist.all_reduce_sum(loss)                       # every rank returns the global-batch loss
+            lse_all = torch.empty((2 * nglob,), dtype=torch.float32, device=zi.device)
             lse_all[seg0:seg0 + b].copy_(lse_loc[:b])
             lse_all[nglob + seg0:nglob + seg0 + b].copy_(lse_loc[b:])
             hdist.all_gather_rows(lse_all[:nglob], b)
             hdist.all_gather_rows(lse_all[nglob:], b)
         else:
             lse_all = lse_loc
-        ctx.saved = (zall, lse_all, inv_i, inv_j, nglob, b, seg0, ld, d, inv_t, bool(normalize))
+        ctx.saved = (zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, bool(normalize))
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        zall, lse_all, inv_i, inv_j, nglob, b, seg0, ld, d, inv_t, normalize = ctx.saved
-        dzall = torch.empty((2 * b, ld), dtype=torch.float32, device=zall.device)
-        _lib.call("ssv_ntxent_bwd", nglob, b, seg0, ld, _lib.ptr(zall), _lib.ptr(lse_all), inv_t, inv_t / (2 * nglob),
-                  _lib.ptr(dzall), _lib.stream())
+        zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, normalize = ctx.saved
+        dzall = ops.ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_t, inv_t / (2 * nglob))
         ops.scale_(dzall, dloss.contiguous())                # chain rule with the upstream scalar, read on the device
         dzi = ops.l2norm_bwd(zall[seg0:seg0 + b], inv_i, dzall[:b], d, normalize)
         dzj = ops.l2norm_bwd(zall[nglob + seg0:nglob + seg0 + b], inv_j, dzall[b:], d, normalize)

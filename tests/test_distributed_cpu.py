@@ -1,0 +1,148 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel host logic: row placement / all-gather of the
+embeddings, the LSE exchange, loss all-reduce and the SUM gradient convention.  The HIP kernels are
+replaced, in these tests only, by oracle-backed CPU emulations of the same tensor-level entry points
+(ssv_amd.ops.*), so what is exercised is the product's orchestration code in utils/losses.py and distributed.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from conftest import seeded_randn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+# ---- CPU emulations of the kernel entry points (restating include/ssv_hip.h semantics with the oracle) ------------
+def _emu_l2norm_fwd(z, normalize=True, ldo=None, eps=1e-12, out=None):
+    rows, d = z.shape
+    ldo = d if ldo is None else ldo
+    zhat = out if out is not None else torch.zeros(rows, ldo)
+    norm = z.norm(dim=1, keepdim=True).clamp_min(eps) if normalize else torch.ones(rows, 1)
+    zhat.zero_()
+    zhat[:, :d] = z / norm
+    return zhat, (1.0 / norm).flatten()
+
+
+def _emu_l2norm_bwd(zhat, inv, dzhat, d, normalize=True):
+    zh, dh = zhat[:, :d], dzhat[:, :d]
+    if not normalize:
+        return dh.clone()
+    return (dh - zh * (zh * dh).sum(1, keepdim=True)) * inv[:, None]
+
+
+def _rows(nglob, b, seg0):
+    return torch.cat([torch.arange(seg0, seg0 + b), nglob + torch.arange(seg0, seg0 + b)])
+
+
+def _emu_ntxent_fwd(zall, nglob, b, seg0, inv_temp):
+    r = _rows(nglob, b, seg0)
+    s = (zall[r] @ zall.t()) * inv_temp
+    pos = s[torch.arange(2 * b), (r + nglob) % (2 * nglob)]
+    s[torch.arange(2 * b), r] = float("-inf")
+    return torch.logsumexp(s, 1), pos
+
+
+def _emu_ntxent_loss(lse, pos, scale):
+    return ((lse - pos).sum() * scale).reshape(())
+
+
+def _emu_ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_temp, gscale):
+    r = _rows(nglob, b, seg0)
+    s = (zall[r] @ zall.t()) * inv_temp
+    w = torch.exp(s - lse_all[r][:, None]) + torch.exp(s - lse_all[None, :])
+    w[torch.arange(2 * b), r] = 0.0
+    return gscale * (w @ zall - 2.0 * zall[(r + nglob) % (2 * nglob)])
+
+
+def _patch_ops():
+    from ssv_amd import ops
+    ops.l2norm_fwd, ops.l2norm_bwd = _emu_l2norm_fwd, _emu_l2norm_bwd
+    ops.ntxent_fwd, ops.ntxent_loss, ops.ntxent_bwd = _emu_ntxent_fwd, _emu_ntxent_loss, _emu_ntxent_bwd
+    ops.scale_ = lambda x, f: x.mul_(f)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ssv_amd import distributed as hdist
+    from ssv_amd.utils import losses
+    hdist.init_from_env(backend="gloo")
+    assert hdist.is_on() and hdist.world_size() == world and hdist.rank() == rank
+    _patch_ops()
+    try:
+        # ---- 1. all_gather_rows: every rank's block lands in its slot
+        buf = torch.zeros(world * 3, 2)
+        buf[rank * 3:(rank + 1) * 3] = rank + 1
+        hdist.all_gather_rows(buf, 3)
+        assert torch.equal(buf[:, 0], torch.arange(1, world + 1).repeat_interleave(3).float())
+        # ---- 2. sharded NT-Xent == global NT-Xent (loss identical on every rank; dz rows = rows of the global gradient)
+        n, d = 12, 20                                             # d is padded to 32 inside
+        b = n // world
+        zi, zj = seeded_randn(1, n, d), seeded_randn(2, n, d)
+        a, c = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+        ref = oracle.ntxent_loss(a, c, True, 0.5)
+        ref.backward()
+        li, lj = zi[rank * b:(rank + 1) * b].clone().requires_grad_(), zj[rank * b:(rank + 1) * b].clone().requires_grad_()
+        loss = losses.SimclrLoss(True, 0.5)(li, lj)
+        (loss * 3.0).backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        np.testing.assert_allclose(li.grad.numpy() / 3.0, a.grad[rank * b:(rank + 1) * b].numpy(), rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(lj.grad.numpy() / 3.0, c.grad[rank * b:(rank + 1) * b].numpy(), rtol=2e-4, atol=1e-7)
+        # ---- 3. data-parallel step semantics: local BN per rank and view, global loss, SUM of gradients.
+        torch.manual_seed(0)
+        w1, w2 = torch.randn(8, 6), torch.randn(6, 8)
+        gam = torch.ones(8)
+
+        def net(x, w1_, w2_, g_):                                 # Linear -> BN(train, local stats) -> ReLU -> Linear
+            h = x @ w1_.t()
+            h = (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5) * g_
+            return torch.relu(h) @ w2_.t()
+
+        x1, x2 = seeded_randn(3, n, 6), seeded_randn(4, n, 6)
+        # single-process emulation: shards run one after the other through the same weights, loss on the concatenation
+        ps = [t.clone().requires_grad_() for t in (w1, w2, gam)]
+        z1 = torch.cat([net(x1[r * b:(r + 1) * b], *ps) for r in range(world)])
+        z2 = torch.cat([net(x2[r * b:(r + 1) * b], *ps) for r in range(world)])
+        oracle.ntxent_loss(z1, z2, True, 0.5).backward()
+        # this rank
+        pl = [t.clone().requires_grad_() for t in (w1, w2, gam)]
+        l = losses.SimclrLoss(True, 0.5)(net(x1[rank * b:(rank + 1) * b], *pl), net(x2[rank * b:(rank + 1) * b], *pl))
+        l.backward()
+        flat = torch.cat([p.grad.flatten() for p in pl])
+        hdist.all_reduce_sum(flat)                                # what FusedSGD.grad_sync does on the arena
+        np.testing.assert_allclose(flat.numpy(), torch.cat([p.grad.flatten() for p in ps]).numpy(), rtol=5e-4, atol=1e-6)
+        out.put((rank, "ok"))
+    except Exception as e:                                        # surface the failure to the parent
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_loss_and_gradient_sum():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_single_process_defaults():
+    from ssv_amd import distributed as hdist
+    assert not hdist.is_on() and hdist.world_size() == 1 and hdist.rank() == 0
+    t = torch.ones(3)
+    assert hdist.all_reduce_sum(t) is t and hdist.all_gather_rows(t, 3) is t
