@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libssv_hip.so")
+LIB_PATH = os.environ.get("SSV_HIP_LIB") or os.path.join(_HERE, "csrc", "libssv_hip.so")   # override: diagnostic builds only
 
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc")
 

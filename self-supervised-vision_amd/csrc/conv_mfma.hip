@@ -22,11 +22,19 @@
 //                                fragments are ds_read_b32, 32 consecutive banks per half-wave.
 // Both operands of one MFMA always take the same k = 8*ks + 4*(l>>5) + t, so any mix is consistent.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int LDT = 20;   // ROWK row stride (floats)
+constexpr int GBK = 16;   // K-step of the generic (scalar gather) path and the granularity of wgrad row chunks
+
+// blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous run of logical tiles so that tiles
+// sharing an operand panel hit the same L2.  Bijective for any grid size.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
 
 struct ConvKP {
   int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
@@ -35,12 +43,12 @@ struct ConvKP {
   FastDiv dHoWo, dWo, dC, dS;
 };
 
-template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB>
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const float* __restrict__ Bs,
                                           int wr0, int wc0, int lane, f32x16 (&acc)[TM][TN]) {
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < BK / 8; ++ks) {
     float a[TM][4], b[TN][4];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -82,93 +90,201 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+#ifdef SSV_STAMP
+__device__ unsigned long long g_stamps[8];
+#endif
+
+template <int TM, int TN> struct Frags { float a[TM][4], b[TN][4]; };
+
+// fragments of k-substep ks (8 k-values) of the staged tile: lane l takes k = 8*ks + 4*(l>>5) + t, t = 0..3
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB>
+__device__ __forceinline__ void load_frags(Frags<TM, TN>& f, const float* __restrict__ As, const float* __restrict__ Bs,
+                                           int wr0, int wc0, int lane, int ks) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if constexpr (A_ROWK) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&As[(wr0 + tm * 32 + l31) * LDA + ks * 8 + 4 * h]);
+      f.a[tm][0] = v[0]; f.a[tm][1] = v[1]; f.a[tm][2] = v[2]; f.a[tm][3] = v[3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) f.a[tm][t] = As[(ks * 8 + 4 * h + t) * LDA + wr0 + tm * 32 + l31];
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    if constexpr (B_ROWK) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[(wc0 + tn * 32 + l31) * LDB + ks * 8 + 4 * h]);
+      f.b[tn][0] = v[0]; f.b[tn][1] = v[1]; f.b[tn][2] = v[2]; f.b[tn][3] = v[3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) f.b[tn][t] = Bs[(ks * 8 + 4 * h + t) * LDB + wc0 + tn * 32 + l31];
+    }
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][t], f.b[tn][t], acc[tm][tn], 0, 0, 0);
+}
+
+// K loop over staged tiles.  load_tile() issues the next tile's global loads into registers, store_tile(buf)
+// writes those registers to LDS stage `buf`.
+//   PIPE = false : one LDS stage, two barriers per tile (small LDS footprint, 3 workgroups per CU).
+//   PIPE = true  : two LDS stages and two fragment register sets, ONE barrier per tile, software pipelined so that a
+//                  wave keeps its SIMD's matrix pipe fed on its own: the fragments of substep s+1 are read while the
+//                  16 MFMAs of substep s run, and the next tile's ds_writes sit in front of the last substep's MFMAs.
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int STAGE, bool PIPE, class LoadTile, class StoreTile>
+__device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs, int wr0, int wc0, int lane,
+                                       f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile) {
+  if (nkt <= 0) return;
+  constexpr int NS = BK / 8;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  if constexpr (!PIPE) {
+#ifdef SSV_STAMP   // diagnostic build only (tools/): where does one k-tile spend its cycles?  Never in the shipped library.
+    unsigned long long t_ld = 0, t_mma = 0, t_b1 = 0, t_st = 0, t_b2 = 0;
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); var += now_ - last_; last_ = now_; } while (0)
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define STAMP(var) do {} while (0)
+#endif
+    for (int kt = 0; kt < nkt; ++kt) {
+      const bool more = kt + 1 < nkt;
+      if (more) load_tile();                 // next tile's global loads fly under this tile's MFMAs
+      STAMP(t_ld);
+      mma_ktile<TM, TN, A_ROWK, B_ROWK, LDA, LDB, BK>(As, Bs, wr0, wc0, lane, acc);
+      STAMP(t_mma);
+      __syncthreads();
+      STAMP(t_b1);
+      if (more) { store_tile(0); STAMP(t_st); __syncthreads(); STAMP(t_b2); }
+    }
+#ifdef SSV_STAMP
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_stamps[0], t_ld); atomicAdd(&g_stamps[1], t_mma); atomicAdd(&g_stamps[2], t_b1);
+      atomicAdd(&g_stamps[3], t_st); atomicAdd(&g_stamps[4], t_b2); atomicAdd(&g_stamps[5], (unsigned long long)nkt);
+    }
+#endif
+#undef STAMP
+  } else {
+    static_assert(NS % 2 == 0, "pipelined loop alternates two fragment sets");
+    Frags<TM, TN> fr[2];
+    load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As, Bs, wr0, wc0, lane, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const bool more = kt + 1 < nkt;
+      if (more) load_tile();
+      const float* a = As + cur * STAGE;
+      const float* b = Bs + cur * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+        if (ks + 1 < NS) load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[(ks + 1) & 1], a, b, wr0, wc0, lane, ks + 1);
+        else if (more) store_tile(cur ^ 1);  // other stage: last read before the previous barrier
+        __builtin_amdgcn_sched_barrier(0);   // keep the LDS traffic IN FRONT of this substep's MFMAs (hipcc sinks it otherwise)
+        mma_frags<TM, TN>(fr[ks & 1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      cur ^= 1;
+      if (more) load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As + cur * STAGE, Bs + cur * STAGE, wr0, wc0, lane, 0);
+    }
+  }
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, bool VEC>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC>
 __global__ void __launch_bounds__(256)
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
+  constexpr int LDT = BK + 4;                   // ROWK row stride: 16-lane b128 read groups hit 16 distinct 16-B slots
+  constexpr int STAGE = (BM + BN) * LDT;
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
   float* As = smem;
   float* Bs = smem + BM * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr0 = (wave / WGN) * (BM / WGM), wc0 = (wave % WGN) * (BN / WGN);
   const int NT = (p.K + BN - 1) / BN;
-  const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
   if constexpr (VEC) {
-    // ---- C % 16 == 0: every 16-wide k-tile lies inside one filter tap; float4 staging ----
-    constexpr int AP = BM / 64, BP = BN / 64;
-    const int chunk = (tid & 3) * 4, rsub = tid >> 2;
-    int hi0[AP], wi0[AP];
-    size_t abase[AP];
+    // ---- C % BK == 0: every k-tile lies inside one filter tap; float4 staging, BK/4 lanes per row ----
+    constexpr int CH = BK / 4, RPP = 256 / CH;
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    const int chunk = (tid % CH) * 4, rsub = tid / CH;
+    // Loader state per staged row: 32-bit element offset of (n, hi0, wi0, chunk) from x (negative in the padding),
+    // top-left input coordinate, validity.  Per tile the tap contributes ONE uniform scalar offset; the loads are
+    // unconditional (invalid rows read x[0] and are zeroed by a select) so the loop has no exec-mask branches.
+    int hi0[AP], wi0[AP], aoff[AP];
+    bool aok[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int m = m0 + rsub + 64 * i;
-      if (m < p.M) {
-        const uint32_t n = fdiv((uint32_t)m, p.dHoWo);
-        const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Ho * p.Wo);
-        const uint32_t ho = fdiv(rem, p.dWo);
-        const uint32_t wo = rem - ho * (uint32_t)p.Wo;
-        hi0[i] = (int)ho * p.stride - p.pad;
-        wi0[i] = (int)wo * p.stride - p.pad;
-        abase[i] = (size_t)n * p.H * p.W * p.C + chunk;
-      } else { hi0[i] = -(1 << 28); wi0[i] = 0; abase[i] = 0; }
+      const int m = m0 + rsub + RPP * i;
+      aok[i] = m < p.M;
+      const uint32_t mm = aok[i] ? (uint32_t)m : 0u;
+      const uint32_t n = fdiv(mm, p.dHoWo);
+      const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
+      const uint32_t ho = fdiv(rem, p.dWo);
+      const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+      hi0[i] = (int)ho * p.stride - p.pad;
+      wi0[i] = (int)wo * p.stride - p.pad;
+      aoff[i] = (((int)n * p.H + hi0[i]) * p.W + wi0[i]) * p.C + chunk;
     }
-    size_t bbase[BP];
+    int boff[BP];
     bool bok[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      const int ko = n0 + rsub + 64 * i;
+      const int ko = n0 + rsub + RPP * i;
       bok[i] = ko < p.K;
-      bbase[i] = (size_t)(bok[i] ? ko : 0) * p.RSC + chunk;
+      boff[i] = (bok[i] ? ko : 0) * p.RSC + chunk;
     }
+    const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;     // 1x1 / no padding: every tap of a valid row is in bounds
     int lr = 0, ls = 0, lc0 = 0;   // loader position (tap r, s, first channel)
     f32x4 ra[AP], rb[BP];
+    unsigned okmask = 0;                                       // validity of the rows in flight; applied when they are stored
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&]() {
+      const int toff_x = (lr * p.W + ls) * p.C + lc0;          // uniform
+      const int toff_w = (lr * p.S + ls) * p.C + lc0;
+      okmask = 0;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        const int hi = hi0[i] + lr, wi = wi0[i] + ls;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(x + abase[i] + ((size_t)hi * p.W + wi) * p.C + lc0);
-        ra[i] = v;
+        const bool ok = aok[i] & (inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W)));
+        ra[i] = *reinterpret_cast<const f32x4*>(x + (ok ? aoff[i] + toff_x : 0));
+        okmask |= (unsigned)ok << i;
       }
-      const int tapoff = (lr * p.S + ls) * p.C + lc0;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (bok[i]) v = *reinterpret_cast<const f32x4*>(w + bbase[i] + tapoff);
-        rb[i] = v;
-      }
+      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w + boff[i] + toff_w);
       lc0 += BK;
       if (lc0 >= p.C) { lc0 = 0; if (++ls == p.S) { ls = 0; ++lr; } }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + 64 * i) * LDT + chunk]) = ra[i];
+      for (int i = 0; i < AP; ++i)
+        *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ((okmask >> i) & 1u) ? ra[i] : zero4;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + 64 * i) * LDT + chunk]) = rb[i];
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = bok[i] ? rb[i] : zero4;
     };
-    const int nkt = p.RSC / BK;
-    load_tile();
-    store_tile();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const bool more = kt + 1 < nkt;
-      if (more) load_tile();
-      mma_ktile<TM, TN, true, true, LDT, LDT>(As, Bs, wr0, wc0, lane, acc);
-      __syncthreads();
-      if (more) { store_tile(); __syncthreads(); }
-    }
+    k_loop<TM, TN, true, true, LDT, LDT, BK, STAGE, DB>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
+    static_assert(BK == GBK && !DB, "generic path is BK=16, single buffer");
     constexpr int AE = BM / 16, BE = BN / 16;
     const int kk = tid & 15, rsub = tid >> 4;
     int hw0[AE];        // packed (hi0 & 0xffff) | (wi0 << 16)
@@ -222,7 +338,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     for (int kt = 0; kt < nkt; ++kt) {
       const bool more = kt + 1 < nkt;
       if (more) load_tile();
-      mma_ktile<TM, TN, true, true, LDT, LDT>(As, Bs, wr0, wc0, lane, acc);
+      mma_ktile<TM, TN, true, true, LDT, LDT, BK>(As, Bs, wr0, wc0, lane, acc);
       __syncthreads();
       if (more) { store_tile(); __syncthreads(); }
     }
@@ -255,12 +371,13 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // dgrad: rows are the input pixels of ONE stride-parity class (blockIdx.y); only taps with
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB>
 __global__ void __launch_bounds__(256)
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  constexpr int A_FLOATS = BM * LDT, B_FLOATS = BK * BN;
-  __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+  constexpr int LDT = BK + 4;
+  constexpr int A_FLOATS = BM * LDT, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
   __shared__ unsigned rowpix[BM];
   __shared__ int taps[64 * 3];      // (dho, dwo, tapoff) per valid tap
   __shared__ int ntaps_s;
@@ -274,7 +391,8 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   const int Wq = pw < p.W ? (p.W - pw + st - 1) / st : 0;
   const int Mc = p.N * Hq * Wq;
   const int NT = (p.C + BN - 1) / BN;
-  const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= Mc) return;
 
@@ -312,69 +430,63 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
-  constexpr int AP = BM / 64;            // A passes: 64 rows x 4 float4 per pass
+  constexpr int CH = BK / 4, RPP = 256 / CH;
+  constexpr int AP = BM / RPP;           // A passes: RPP rows x CH float4 per pass
   constexpr int BCV = BN / 4;            // float4 per B row
   constexpr int BRP = 256 / BCV;         // B rows per pass
   constexpr int BP = BK / BRP;           // B passes
-  const int chunk = (tid & 3) * 4, rsub = tid >> 2;
-  int hq_[AP], wq_[AP], n_[AP];
+  const int chunk = (tid % CH) * 4, rsub = tid / CH;
+  // branch-free loader (see the forward kernel): 32-bit element offset of (n, hq, wq, chunk) in dY per staged row,
+  // one uniform scalar offset per (tap, k-tile)
+  int hq_[AP], wq_[AP], aoff[AP];
+  bool aok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int m = m0 + rsub + 64 * i;
-    if (m < Mc) {
-      const int n = m / (Hq * Wq);
-      const int rem = m - n * Hq * Wq;
-      hq_[i] = rem / Wq; wq_[i] = rem - hq_[i] * Wq; n_[i] = n;
-    } else { hq_[i] = -(1 << 28); wq_[i] = 0; n_[i] = 0; }
+    const int m = m0 + rsub + RPP * i;
+    aok[i] = m < Mc;
+    const int mm = aok[i] ? m : 0;
+    const int n = mm / (Hq * Wq);
+    const int rem = mm - n * Hq * Wq;
+    hq_[i] = rem / Wq; wq_[i] = rem - hq_[i] * Wq;
+    aoff[i] = ((n * p.Ho + hq_[i]) * p.Wo + wq_[i]) * p.K + chunk;
   }
   const int bcol = (tid % BCV) * 4, brow = tid / BCV;
   const bool bcok = n0 + bcol < p.C;
+  const int boff = brow * p.RSC + (bcok ? n0 + bcol : 0);
+  const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;       // 1x1: the single tap maps every class pixel onto a valid dY pixel
 
   int ti = 0, lk0 = 0;                   // loader position: tap index, first output channel
   int dho = 0, dwo = 0, tapoff = 0;
   if (ntaps > 0) { dho = taps[0]; dwo = taps[1]; tapoff = taps[2]; }
   f32x4 ra[AP], rb[BP];
+  unsigned okmask = 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_tile = [&]() {
+    const int toff_a = (dho * p.Wo + dwo) * p.K + lk0;         // uniform
+    const int toff_b = lk0 * p.RSC + tapoff;
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int ho = hq_[i] + dho, wo = wq_[i] + dwo;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo)
-        v = *reinterpret_cast<const f32x4*>(dy + (((size_t)n_[i] * p.Ho + ho) * p.Wo + wo) * p.K + lk0 + chunk);
-      ra[i] = v;
+      const bool ok = aok[i] & (inb | (((unsigned)(hq_[i] + dho) < (unsigned)p.Ho) & ((unsigned)(wq_[i] + dwo) < (unsigned)p.Wo)));
+      ra[i] = *reinterpret_cast<const f32x4*>(dy + (ok ? aoff[i] + toff_a : 0));
+      okmask |= (unsigned)ok << i;
     }
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int ko = lk0 + brow + BRP * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bcok) v = *reinterpret_cast<const f32x4*>(w + (size_t)ko * p.RSC + tapoff + n0 + bcol);
-      rb[i] = v;
-    }
+    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w + boff + toff_b + BRP * i * p.RSC);
     lk0 += BK;
     if (lk0 >= p.K) {
       lk0 = 0; ++ti;
       if (ti < ntaps) { dho = taps[3 * ti]; dwo = taps[3 * ti + 1]; tapoff = taps[3 * ti + 2]; }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + 64 * i) * LDT + chunk]) = ra[i];
+    for (int i = 0; i < AP; ++i)
+      *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ((okmask >> i) & 1u) ? ra[i] : zero4;
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rb[i];
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = bcok ? rb[i] : zero4;
   };
-  const int nkt = ntaps * (p.K / BK);
-  if (nkt > 0) {
-    load_tile();
-    store_tile();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const bool more = kt + 1 < nkt;
-      if (more) load_tile();
-      mma_ktile<TM, TN, true, false, LDT, BN>(As, Bs, wr0, wc0, lane, acc);
-      __syncthreads();
-      if (more) { store_tile(); __syncthreads(); }
-    }
-  }
+  k_loop<TM, TN, true, false, LDT, BN, BK, STAGE, DB>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -400,19 +512,21 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // =============================================================================================
 // wgrad: partial[split][K][RSC] over a chunk of the N*Ho*Wo contraction
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, bool VECB>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VECB>
 __global__ void __launch_bounds__(256)
-conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows) {
+conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
-  float* As = smem;               // [16][BM]
-  float* Bs = smem + BK * BM;     // [16][BN]
+  constexpr int STAGE = BK * (BM + BN);
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
+  float* As = smem;               // [BK][BM]
+  float* Bs = smem + BK * BM;     // [BK][BN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr0 = (wave / WGN) * (BM / WGM), wc0 = (wave % WGN) * (BN / WGN);
   const int JT = (p.RSC + BN - 1) / BN;
-  const int it = blockIdx.x / JT, jt = blockIdx.x - it * JT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);     // tiles of one row-slab are neighbours: they share dY / X rows in L2
+  const int split = bid / tiles, tile = bid - split * tiles;
+  const int it = tile / JT, jt = tile - it * JT;
   const int i0 = it * BM, j0 = jt * BN;
-  const int split = blockIdx.y;
   const int ms = split * chunk_rows;
   const int me = min(ms + chunk_rows, p.M);
 
@@ -437,60 +551,54 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   f32x4 ra[AP];
   f32x4 rbv[VECB ? BP : 1];
   float rbs[VECB ? 1 : BP];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int aoff0 = i0 + (acok ? acol : 0);
+  const bool lin = p.R == 1 && p.S == 1 && p.pad == 0 && p.stride == 1;     // 1x1/s1: row m of X is simply x + m*C
+  unsigned okmask = 0;
   auto load_tile = [&]() {
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int m = mcur + arow + ARP * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (acok && m < me) v = *reinterpret_cast<const f32x4*>(dy + (size_t)m * p.K + i0 + acol);
-      ra[i] = v;
+      const bool ok = acok & (m < me);
+      ra[i] = *reinterpret_cast<const f32x4*>(dy + (ok ? m * p.K + aoff0 : 0));
+      okmask |= (unsigned)ok << i;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       const int m = mcur + brow + BRP * i;
-      bool ok = jok && m < me;
-      size_t off = 0;
-      if (ok) {
-        const uint32_t n = fdiv((uint32_t)m, p.dHoWo);
-        const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Ho * p.Wo);
+      bool ok = jok & (m < me);
+      int off;
+      if (lin) {
+        off = m * p.C + cj;
+      } else {
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t n = fdiv(mm, p.dHoWo);
+        const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
         const uint32_t ho = fdiv(rem, p.dWo);
         const uint32_t wo = rem - ho * (uint32_t)p.Wo;
         const int hi = (int)ho * p.stride - p.pad + rj, wi = (int)wo * p.stride - p.pad + sj;
-        ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        off = (((size_t)n * p.H + hi) * p.W + wi) * p.C + cj;
+        ok = ok & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+        off = (((int)n * p.H + hi) * p.W + wi) * p.C + cj;
       }
-      if constexpr (VECB) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(x + off);
-        rbv[i] = v;
-      } else {
-        rbs[i] = ok ? x[off] : 0.f;
-      }
+      if constexpr (VECB) rbv[i] = *reinterpret_cast<const f32x4*>(x + (ok ? off : 0));
+      else rbs[i] = x[ok ? off : 0];
+      okmask |= (unsigned)ok << (8 + i);
     }
     mcur += BK;
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
+    for (int i = 0; i < AP; ++i)
+      *reinterpret_cast<f32x4*>(&As[buf * STAGE + (arow + ARP * i) * BM + acol]) = ((okmask >> i) & 1u) ? ra[i] : zero4;
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
-      else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
+      const bool ok = (okmask >> (8 + i)) & 1u;
+      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = ok ? rbv[i] : zero4;
+      else Bs[buf * STAGE + (brow + BRP * i) * BN + bcol] = ok ? rbs[i] : 0.f;
     }
   };
-  const int nkt = (me - ms + BK - 1) / BK;
-  if (nkt > 0) {
-    load_tile();
-    store_tile();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const bool more = kt + 1 < nkt;
-      if (more) load_tile();
-      mma_ktile<TM, TN, false, false, BM, BN>(As, Bs, wr0, wc0, lane, acc);
-      __syncthreads();
-      if (more) { store_tile(); __syncthreads(); }
-    }
-  }
+  k_loop<TM, TN, false, false, BM, BN, BK, STAGE, DB>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   float* out = partial + (size_t)split * p.K * p.RSC;
   const int l31 = lane & 31, h = lane >> 5;
@@ -541,6 +649,9 @@ int check_desc(const ssv_conv_desc* d, const char* who) {
   SSV_REQUIRE(Ho == d->Ho && Wo == d->Wo, "%s: Ho/Wo (%d,%d) inconsistent with input/filter/stride/pad (expect %d,%d)", who, d->Ho, d->Wo, Ho, Wo);
   SSV_REQUIRE((int64_t)d->N * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo < (1ll << 31), "%s: too many pixels", who);
   SSV_REQUIRE((int64_t)d->R * d->S * d->C < (1 << 24) && d->R * d->S <= 64 && d->H < 32768 && d->W < 32768, "%s: filter too large", who);
+  // the kernels address activations and filters with 32-bit element offsets
+  SSV_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 31) - (1 << 24) && (int64_t)d->N * d->Ho * d->Wo * d->K < (1ll << 31) - (1 << 24) &&
+              (int64_t)d->K * d->R * d->S * d->C < (1ll << 31), "%s: tensor above 2^31 elements (8 GiB) - split the batch", who);
   return SSV_OK;
 }
 
@@ -571,13 +682,36 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
   const int64_t max_by_rows = cdiv64(M, 256);
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
-  int64_t chunk = cdiv64(cdiv64(M, ns), BK) * BK;
+  int64_t chunk = cdiv64(cdiv64(M, ns), 32) * 32;     // whole K-steps for both BK = 16 and 32
   w.chunk = (int)chunk;
   w.nsplit = (int)cdiv64(M, chunk);
   return w;
 }
 
 }  // namespace
+
+// ---- variant selection -------------------------------------------------------------------------------------
+// SSV_CONV_CFG (comma list, read once): bk16 | bk32 (K-step), db | sb (double / single LDS buffer).  Default = tuned.
+struct ConvCfg { int bk; bool db; };
+static ConvCfg conv_cfg() {
+  static ConvCfg c = [] {
+    ConvCfg v{32, false};
+    if (const char* e = getenv("SSV_CONV_CFG")) {
+      if (strstr(e, "bk16")) v.bk = 16;
+      if (strstr(e, "bk32")) v.bk = 32;
+      if (strstr(e, "db")) v.db = true;
+      if (strstr(e, "sb")) v.db = false;
+    }
+    return v;
+  }();
+  return c;
+}
+
+#define SSV_DISPATCH_BK_DB(BKV, DBV, CALL)                        \
+  do {                                                            \
+    if ((BKV) == 32) { if (DBV) { CALL(32, true); } else { CALL(32, false); } } \
+    else             { if (DBV) { CALL(16, true); } else { CALL(16, false); } } \
+  } while (0)
 
 extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* addend, float* y, void* stream) {
@@ -587,18 +721,23 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   const ConvKP p = make_kp(d);
-  const bool vec = d->C % BK == 0;
-  if (vec) {
+  const ConvCfg cfg = conv_cfg();
+  const int bk = d->C % 32 == 0 ? cfg.bk : 16;
+  if (d->C % 16 == 0) {
     if (d->K >= 128) {
       const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-      hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
+#define CALL(B_, D_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, B_, D_, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+      SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
+#undef CALL
     } else {
       const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
+#define CALL(B_, D_) hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, B_, D_, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+      SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
+#undef CALL
     }
   } else {
     const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 64));
-    hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, false>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
+    hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, GBK, false, false>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd");
   return SSV_OK;
@@ -609,20 +748,26 @@ extern "C" int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const f
   if (int rc = check_desc(d, "ssv_conv2d_dgrad")) return rc;
   SSV_REQUIRE(dy && w && dx, "ssv_conv2d_dgrad: null pointer");
   SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0, "ssv_conv2d_dgrad: pointers must be 16-byte aligned");
-  SSV_REQUIRE(d->K % BK == 0 && d->C % 4 == 0, "ssv_conv2d_dgrad: needs K %% 16 == 0 and C %% 4 == 0 (got K=%d C=%d)", d->K, d->C);
+  SSV_REQUIRE(d->K % 16 == 0 && d->C % 4 == 0, "ssv_conv2d_dgrad: needs K %% 16 == 0 and C %% 4 == 0 (got K=%d C=%d)", d->K, d->C);
   SSV_REQUIRE(d->stride <= 8, "ssv_conv2d_dgrad: stride too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_DGRAD, s);
   const ConvKP p = make_kp(d);
+  const ConvCfg cfg = conv_cfg();
+  const int bk = d->K % 32 == 0 ? cfg.bk : 16;
   const int st = d->stride;
   const int Hq = cdiv(d->H, st), Wq = cdiv(d->W, st);            // class (0,0) is the largest
   const int64_t Mc = (int64_t)d->N * Hq * Wq;
   if (d->C >= 128) {
     const unsigned gx = (unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128));
-    hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2>), dim3(gx, st * st), dim3(256), 0, s, p, dy, w, addend, dx);
+#define CALL(B_, D_) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, B_, D_>), dim3(gx, st * st), dim3(256), 0, s, p, dy, w, addend, dx)
+    SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
+#undef CALL
   } else {
     const unsigned gx = (unsigned)(cdiv64(Mc, 256) * cdiv(d->C, 64));
-    hipLaunchKernelGGL((conv_dgrad_k<256, 64, 4, 1>), dim3(gx, st * st), dim3(256), 0, s, p, dy, w, addend, dx);
+#define CALL(B_, D_) hipLaunchKernelGGL((conv_dgrad_k<256, 64, 4, 1, B_, D_>), dim3(gx, st * st), dim3(256), 0, s, p, dy, w, addend, dx)
+    SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
+#undef CALL
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad");
   return SSV_OK;
@@ -646,15 +791,22 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_WGRAD, s);
   const ConvKP p = make_kp(d);
+  const ConvCfg cfg = conv_cfg();
   const bool vecb = d->C % 4 == 0;
-  const dim3 grid((unsigned)(wp.it * wp.jt), (unsigned)wp.nsplit);
+  const int tiles = wp.it * wp.jt;
+  const dim3 grid((unsigned)(tiles * wp.nsplit));
   float* part = (float*)ws;
-  if (wp.bm == 128) {
-    if (vecb) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk);
-    else      hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk);
+  if (!vecb) {
+    if (wp.bm == 128) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, GBK, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+    else              hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, GBK, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+  } else if (wp.bm == 128) {
+#define CALL(B_, D_) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+    SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
+#undef CALL
   } else {
-    if (vecb) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk);
-    else      hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk);
+#define CALL(B_, D_) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+    SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
+#undef CALL
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(partial)");
   const int64_t n = (int64_t)d->K * p.RSC;
@@ -662,3 +814,11 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(reduce)");
   return SSV_OK;
 }
+
+#ifdef SSV_STAMP
+extern "C" int ssv_debug_stamps(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
