@@ -62,15 +62,21 @@ def build(device, batch):
     hdist.attach_grad_sync(optim)
     loss_fn = losses.SimclrLoss(normalize=True, temperature=0.5)
 
+    from ssv_amd import nn as hnn
+    mode = {"dual": os.environ.get("SSV_SINGLE_STREAM", "0") != "1"}
+
     def step(v1, v2):
-        z1 = head(encoder(v1))
-        z2 = head(encoder(v2))
+        with hnn.parallel_views(device, enabled=mode["dual"]) as pv:      # same body as ssv_amd.models.simclr.SimCLR.train_step
+            with pv.view(0):
+                z1 = head(encoder(v1))
+            with pv.view(1):
+                z2 = head(encoder(v2))
         loss = loss_fn(z1, z2)
         optim.zero_grad()
         loss.backward()
         optim.step()
         return loss.item()
-    return step, sum(p.numel() for p in optim.arena.params)
+    return step, sum(p.numel() for p in optim.arena.params), mode
 
 
 AUG_CFG = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8},
@@ -120,7 +126,7 @@ def main():
     _lib.load()
 
     b, s = args.batch, args.size
-    train_step, nparams = build(device, b)
+    train_step, nparams, mode = build(device, b)
     # synthetic uint8 source images [B,S,S,3] ~ U{0..255}, resident in HBM before the timed region; every step draws
     # fresh augmentation parameters (Philox keyed by global sample index and step) and builds the two views on the GPU
     from ssv_amd.utils import augmentations
@@ -166,6 +172,10 @@ def main():
     conv_flop_step = 2.0 * (fwd + bwd + 3 * proj) * 2 * b                     # per GPU: 2 FLOP/MAC, 2 views
     roof, classes = None, {}
     if args.prof_steps > 0:
+        # per-kernel durations are only meaningful when kernels do not overlap: the instrumented steps run the two
+        # views back to back on ONE stream (the timed region above runs them on two streams)
+        was_dual, mode["dual"] = mode["dual"], False
+        step(); torch.cuda.synchronize()
         _lib.prof_enable(True)
         _lib.prof_reset()
         for _ in range(args.prof_steps):
@@ -173,6 +183,7 @@ def main():
         torch.cuda.synchronize()
         prof = _lib.prof_collect()
         _lib.prof_enable(False)
+        mode["dual"] = was_dual
         classes = {k: {"ms_per_step": round(v[0] / args.prof_steps, 3), "launches_per_step": v[1] // args.prof_steps} for k, v in prof.items() if v[1]}
         conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
         conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
@@ -181,6 +192,7 @@ def main():
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": None, "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
+                "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
                 "whole_step_mfma_frac": round(images_per_s / world * 2.0 * (fwd + bwd + 3 * proj) * 2 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "classes": classes}
 
@@ -192,7 +204,7 @@ def main():
                                f"NT-Xent(normalize, T=0.5) over the global batch, SGD-Nesterov",
                    "input": f"uint8 [B,{s},{s},3] source resident in HBM -> fused GPU two-view augmentation each step",
                    "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
-                   "parallelism": f"dp{world}" if world > 1 else "single", "last_loss": loss},
+                   "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if mode["dual"] else 1, "last_loss": loss},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -134,8 +134,9 @@ int ssv_barlow_cgrad(int32_t D, const float* craw, float inv_b, float lambda, fl
                      void* ws, size_t ws_bytes, void* stream);
 
 /* ---- optimizer: optim.SGD(momentum=0.9, nesterov=True, weight_decay) utils/train_utils.py:11-13
- * over a flat arena of n floats.  first_step != 0 seeds buf = g. */
-int ssv_sgd_nesterov(int64_t n, float* p, const float* g, float* buf, float lr, float weight_decay,
+ * over a flat arena of n floats.  first_step != 0 seeds buf = g.  g2 (may be NULL) is a second gradient slab that is
+ * added to g first: the two views' backward passes run on two HIP streams and accumulate into separate slabs. */
+int ssv_sgd_nesterov(int64_t n, float* p, const float* g, const float* g2, float* buf, float lr, float weight_decay,
                      float momentum, int first_step, void* stream);
 /* BYOL.momentum_update models/byol.py:120-123: t = tau*t + (1-tau)*o over n floats */
 int ssv_ema(int64_t n, float* target, const float* online, float tau, void* stream);

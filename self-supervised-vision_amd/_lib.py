@@ -60,7 +60,7 @@ SIGNATURES = {
     "ssv_mse_pair_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_scale": (C.c_int, [_i64, _vp, _vp, _vp]),
     "ssv_barlow_cgrad": (C.c_int, [_i32, _vp, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
-    "ssv_sgd_nesterov": (C.c_int, [_i64, _vp, _vp, _vp, _f32, _f32, _f32, C.c_int, _vp]),
+    "ssv_sgd_nesterov": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, C.c_int, _vp]),
     "ssv_ema": (C.c_int, [_i64, _vp, _vp, _f32, _vp]),
     "ssv_fill": (C.c_int, [_i64, _vp, _f32, _vp]),
     "ssv_add": (C.c_int, [_i64, _vp, _vp, _vp]),
@@ -117,16 +117,18 @@ def call(name, *args):
 
 # ------------------------------------------------------------------------------------------- workspace
 class _Workspace:
-    """One grow-only scratch buffer per device (torch caching allocator owns the memory)."""
+    """One grow-only scratch buffer per (device, HIP stream): kernels of two streams may run concurrently, so they
+    must never share scratch.  The torch caching allocator owns the memory."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes, device):
-        b = self.buf.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-            self.buf[device] = b
+            self.buf[key] = b
         return b
 
 

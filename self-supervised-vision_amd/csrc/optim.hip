@@ -5,21 +5,24 @@ namespace {
 
 // optim.SGD(momentum, nesterov=True, weight_decay): g' = g + wd*p; buf = g' (first step) or
 // momentum*buf + g'; p -= lr*(g' + momentum*buf).
+template <bool TWO>
 __global__ void __launch_bounds__(256)
-sgd_nesterov_k(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+sgd_nesterov_k(int64_t n, float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g2, float* __restrict__ buf,
                float lr, float wd, float mom, int first) {
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] + wd * pv;
+    f32x4 graw = reinterpret_cast<const f32x4*>(g)[i];
+    if constexpr (TWO) graw += reinterpret_cast<const f32x4*>(g2)[i];      // view-0 slab + view-1 slab, fixed order
+    f32x4 gv = graw + wd * pv;
     f32x4 bv = first ? gv : mom * reinterpret_cast<f32x4*>(buf)[i] + gv;
     reinterpret_cast<f32x4*>(buf)[i] = bv;
     reinterpret_cast<f32x4*>(p)[i] = pv - lr * (gv + mom * bv);
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float pv = p[i];
-    const float gv = g[i] + wd * pv;
+    const float gv = (TWO ? g[i] + g2[i] : g[i]) + wd * pv;
     const float bv = first ? gv : mom * buf[i] + gv;
     buf[i] = bv;
     p[i] = pv - lr * (gv + mom * bv);
@@ -54,13 +57,14 @@ unsigned grid_for(int64_t n) {
 
 }  // namespace
 
-extern "C" int ssv_sgd_nesterov(int64_t n, float* p, const float* g, float* buf, float lr, float weight_decay,
+extern "C" int ssv_sgd_nesterov(int64_t n, float* p, const float* g, const float* g2, float* buf, float lr, float weight_decay,
                                 float momentum, int first_step, void* stream) {
   SSV_REQUIRE(n > 0 && p && g && buf, "ssv_sgd_nesterov: bad arguments");
-  SSV_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "ssv_sgd_nesterov: pointers must be 16-byte aligned");
+  SSV_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)buf) & 15) == 0, "ssv_sgd_nesterov: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_OPTIM, s);
-  hipLaunchKernelGGL(sgd_nesterov_k, dim3(grid_for(n)), dim3(256), 0, s, n, p, g, buf, lr, weight_decay, momentum, first_step);
+  if (g2) hipLaunchKernelGGL((sgd_nesterov_k<true>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, lr, weight_decay, momentum, first_step);
+  else    hipLaunchKernelGGL((sgd_nesterov_k<false>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, lr, weight_decay, momentum, first_step);
   SSV_CHECK_LAUNCH("ssv_sgd_nesterov");
   return SSV_OK;
 }

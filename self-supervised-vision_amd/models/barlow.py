@@ -1,4 +1,5 @@
 """Barlow Twins on the HIP path - drop-in for the reference trainer (models/barlow.py:39-167)."""
+from .. import nn as hnn
 from ..utils import losses, train_utils
 from .base import NETWORKS, TwoViewTrainer
 from .heads import BarlowProjectionHead as ProjectionHead  # noqa: F401
@@ -20,7 +21,11 @@ class BarlowTwins(TwoViewTrainer):
 
     def train_step(self, batch):
         img_1, img_2 = batch["aug_1"].to(self.device), batch["aug_2"].to(self.device)
-        z_1, z_2 = self._embed(img_1), self._embed(img_2)
+        with hnn.parallel_views(self.device) as pv:
+            with pv.view(0):
+                z_1 = self._embed(img_1)
+            with pv.view(1):
+                z_2 = self._embed(img_2)
         loss = self.loss_fn(z_1, z_2)
         self.optim.zero_grad()
         loss.backward()

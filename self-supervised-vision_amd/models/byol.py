@@ -79,9 +79,15 @@ class BYOL(TwoViewTrainer):
 
     def train_step(self, batch):
         img_1, img_2 = batch["aug_1"].to(self.device), batch["aug_2"].to(self.device)
-        with torch.no_grad():                    # target params have requires_grad=False: no graph in the reference either
-            target_1, target_2 = self.target_network(img_1), self.target_network(img_2)
-        online_1, online_2 = self.online_network(img_1), self.online_network(img_2)
+        with hnn.parallel_views(self.device) as pv:
+            with pv.view(0):
+                with torch.no_grad():            # target params have requires_grad=False: no graph in the reference either
+                    target_1 = self.target_network(img_1)
+                online_1 = self.online_network(img_1)
+            with pv.view(1):
+                with torch.no_grad():
+                    target_2 = self.target_network(img_2)
+                online_2 = self.online_network(img_2)
         loss = self.loss_fn(online_1, online_2, target_1, target_2)
         self.optim.zero_grad()
         loss.backward()

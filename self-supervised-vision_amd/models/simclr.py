@@ -1,4 +1,5 @@
 """SimCLR on the HIP path - drop-in for the reference trainer (models/simclr.py:39-167)."""
+from .. import nn as hnn
 from ..utils import losses, train_utils
 from .base import NETWORKS, TwoViewTrainer
 from .heads import SimclrProjectionHead as ProjectionHead  # noqa: F401  (reference name)
@@ -21,8 +22,11 @@ class SimCLR(TwoViewTrainer):
     def train_step(self, batch):
         """Two separate forward passes - BatchNorm statistics are per view, like the reference."""
         img_1, img_2 = batch["aug_1"].to(self.device), batch["aug_2"].to(self.device)
-        z_1 = self._embed(img_1)
-        z_2 = self._embed(img_2)
+        with hnn.parallel_views(self.device) as pv:      # the two independent passes run on two HIP streams
+            with pv.view(0):
+                z_1 = self._embed(img_1)
+            with pv.view(1):
+                z_2 = self._embed(img_2)
         loss = self.loss_fn(z_1, z_2)
         self.optim.zero_grad()
         loss.backward()

@@ -13,6 +13,84 @@ from . import ops
 from ._lib import SsvError
 
 
+# ------------------------------------------------------------------------------------------- two-view concurrency
+# The two views of a step are independent until the loss: their forward (and backward) passes are enqueued on two
+# HIP streams so that the MFMA-bound convolutions of one view overlap the HBM-bound BatchNorm kernels - and the tail
+# waves - of the other.  What has to be kept apart:
+#   * scratch: _lib.workspace is per stream;
+#   * parameter gradients: view slot 1 accumulates into a second gradient slab (p._grad_alt), the optimizer adds the
+#     slabs in fixed order - bitwise the same result as one slab, no atomics;
+#   * BatchNorm running statistics: slot 1's BN waits (HIP event) for the same layer's BN of slot 0, so the update
+#     order is view 1 then view 2, exactly like the reference's sequential forward passes.
+_SLOT = 0
+_STREAMS = {}
+
+
+def current_slot():
+    return _SLOT
+
+
+def join_view_streams(device):
+    """Make the ambient stream wait for both view streams (kernels enqueued by Function.backward on them)."""
+    if device in _STREAMS:
+        cur = torch.cuda.current_stream(device)
+        for st in _STREAMS[device]:
+            if st != cur:
+                cur.wait_stream(st)
+
+
+class parallel_views:
+    """with parallel_views(device) as pv:  with pv.view(0): z1 = net(x1);  with pv.view(1): z2 = net(x2)
+    On exit the ambient stream waits for both view streams.  Backward needs nothing special: torch.autograd runs
+    each node on the stream of its forward and joins the streams at the end of backward()."""
+
+    def __init__(self, device, enabled=True):
+        self.device, self.enabled = device, enabled and device.type == "cuda"
+
+    def __enter__(self):
+        if self.enabled:
+            if self.device not in _STREAMS:
+                _STREAMS[self.device] = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            self.main = torch.cuda.current_stream(self.device)
+            self.start = torch.cuda.Event()
+            self.start.record(self.main)
+            self.used = set()
+        return self
+
+    def view(self, slot):
+        return _ViewCtx(self, slot)
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            for slot in self.used:
+                self.main.wait_stream(_STREAMS[self.device][slot])
+        return False
+
+
+class _ViewCtx:
+    def __init__(self, pv, slot):
+        self.pv, self.slot = pv, slot
+
+    def __enter__(self):
+        global _SLOT
+        self.prev = _SLOT
+        if self.pv.enabled:
+            st = _STREAMS[self.pv.device][self.slot]
+            st.wait_event(self.pv.start)
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+            self.pv.used.add(self.slot)
+            _SLOT = self.slot
+        return self
+
+    def __exit__(self, *exc):
+        global _SLOT
+        if self.pv.enabled:
+            self.ctx.__exit__(*exc)
+        _SLOT = self.prev
+        return False
+
+
 # ------------------------------------------------------------------------------------------- tape
 class Tape:
     """Records (inputs, output, backward closure) per op.  ``backward`` walks it in reverse; a
@@ -23,6 +101,7 @@ class Tape:
         self.ops = []
         self.root = root
         self.root_needs_grad = root_needs_grad
+        self.slot = _SLOT                     # which gradient slab this pass accumulates into
 
     def record(self, inputs, output, bwd):
         self.ops.append((inputs, output, bwd))
@@ -52,8 +131,15 @@ def _accum(existing, fresh):
     return ops.add_(existing, fresh)
 
 
-def grad_of(p):
-    """The kernels accumulate into p.grad; create it zeroed on first use (layout = p's layout)."""
+def grad_of(p, slot=0):
+    """The kernels accumulate into p.grad (view slot 0) or p._grad_alt (slot 1, when the optimizer provides the
+    second slab); created zeroed on first use (layout = p's layout)."""
+    if slot == 1:
+        alt = getattr(p, "_grad_alt", None)
+        if alt is not None:
+            return alt
+        raise SsvError("a pass in view slot 1 needs the optimizer's second gradient slab (build the optimizer with "
+                       "train_utils.get_optimizer before running parallel_views)")
     if p.grad is None:
         p.grad = ops.fill_(torch.empty_like(p), 0.0)
     return p.grad
@@ -65,10 +151,12 @@ def conv(tape, x, weight, stride, pad, bias=None):
     if tape is not None:
         need_dx = tape.needs_grad(x)
 
+        slot = tape.slot
+
         def bwd(dy, existing):
-            ops.conv2d_wgrad(x, dy, weight, grad_of(weight), stride, pad, accumulate=True)
+            ops.conv2d_wgrad(x, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True)
             if bias is not None:
-                ops.colsum(dy, grad_of(bias), accumulate=True)
+                ops.colsum(dy, grad_of(bias, slot), accumulate=True)
             if not need_dx:
                 return (None,)
             ex = existing[0]
@@ -79,11 +167,21 @@ def conv(tape, x, weight, stride, pad, bias=None):
 
 
 def batchnorm(tape, x, bn, relu=False, residual=None):
+    if _STREAMS:                               # running-stat update order across the two view streams: slot 0 first
+        st = torch.cuda.current_stream(x.device)
+        if _SLOT == 1 and bn._order_event is not None:
+            st.wait_event(bn._order_event)
     y, mean, invstd = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                        relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum)
+    if _STREAMS and _SLOT == 0 and torch.cuda.current_stream(x.device) != torch.cuda.default_stream(x.device):
+        if bn._order_event is None:
+            object.__setattr__(bn, "_order_event", torch.cuda.Event())
+        bn._order_event.record(torch.cuda.current_stream(x.device))
     if tape is not None:
+        slot = tape.slot
+
         def bwd(dy, existing):
-            dx, dres = ops.bn_train_bwd(dy, y, x, bn.weight, mean, invstd, relu, grad_of(bn.weight), grad_of(bn.bias),
+            dx, dres = ops.bn_train_bwd(dy, y, x, bn.weight, mean, invstd, relu, grad_of(bn.weight, slot), grad_of(bn.bias, slot),
                                         want_dres=residual is not None, accumulate=True)
             if residual is None:
                 return (_accum(existing[0], dx), None)
@@ -115,11 +213,13 @@ def linear(tape, x, weight, bias):
     if tape is not None:
         need_dx = tape.needs_grad(x)
 
+        slot = tape.slot
+
         def bwd(dy, existing):
             dy4 = dy.view(b, 1, 1, -1)
-            ops.conv2d_wgrad(x4, dy4, weight, grad_of(weight), 1, 0, accumulate=True)
+            ops.conv2d_wgrad(x4, dy4, weight, grad_of(weight, slot), 1, 0, accumulate=True)
             if bias is not None:
-                ops.colsum(dy, grad_of(bias), accumulate=True)
+                ops.colsum(dy, grad_of(bias, slot), accumulate=True)
             if not need_dx:
                 return (None,)
             ex = existing[0]
@@ -144,6 +244,8 @@ class _Bridge(torch.autograd.Function):
     def forward(ctx, anchor, x, module, record):
         if not x.is_cuda:
             raise SsvError(f"{type(module).__name__}: the HIP path needs device tensors; there is no CPU fallback")
+        if _STREAMS:
+            x.record_stream(torch.cuda.current_stream(x.device))      # produced on another stream, read on this one
         xin = module._prepare_input(x.detach())
         tape = Tape(xin, x.requires_grad) if record else None
         y = module._run(tape, xin)
@@ -156,6 +258,8 @@ class _Bridge(torch.autograd.Function):
         if tape is None:
             raise SsvError("backward through a forward that ran under torch.no_grad()")
         ctx.tape = None
+        if _STREAMS:
+            dy.record_stream(torch.cuda.current_stream(dy.device))
         dx = tape.backward(ctx.y, dy.contiguous())
         if dx is not None:
             dx = ctx.module._finish_input_grad(dx)
@@ -217,6 +321,7 @@ class HipBatchNorm(HipModule):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
         self.eps, self.momentum = eps, momentum
+        object.__setattr__(self, "_order_event", None)
 
     def _run(self, tape, x):
         return batchnorm(tape, x, self)

@@ -34,13 +34,17 @@ class ParamArena:
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = off
         self.data = ops.fill_(torch.empty(off, dtype=torch.float32, device=dev), 0.0)
-        self.grad = ops.fill_(torch.empty(off, dtype=torch.float32, device=dev), 0.0) if with_grads else None
+        # two gradient slabs, contiguous: slot 0 = p.grad, slot 1 = p._grad_alt (second view's stream); one fill zeroes both
+        self._grads = ops.fill_(torch.empty(2 * off, dtype=torch.float32, device=dev), 0.0) if with_grads else None
+        self.grad = self._grads[:off] if with_grads else None
+        self.grad_alt = self._grads[off:] if with_grads else None
         for p, o in zip(self.params, self.offsets):
             view = self._view(self.data, p, o)
             view.copy_(p.data)                       # one-time relocation (plumbing)
             p.data = view
             if with_grads:
                 p.grad = self._view(self.grad, p, o)
+                p._grad_alt = self._view(self.grad_alt, p, o)
 
     @staticmethod
     def _view(flat, p, off):
@@ -51,7 +55,7 @@ class ParamArena:
         return seg.view(p.shape)
 
     def zero_grad(self):
-        ops.fill_(self.grad, 0.0)
+        ops.fill_(self._grads, 0.0)
 
 
 class FusedSGD(torch.optim.Optimizer):
@@ -71,10 +75,15 @@ class FusedSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        if self.grad_sync is not None:
-            self.grad_sync(self.arena.grad)
         a = self.arena
-        _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(self.momentum_buffer),
+        from .. import nn as hnn
+        hnn.join_view_streams(a.data.device)         # backward kernels of the two view streams must have been ordered before us
+        g2 = a.grad_alt
+        if self.grad_sync is not None:               # data parallel: fold the slabs, then ONE contiguous all-reduce
+            ops.add_(a.grad, a.grad_alt)
+            self.grad_sync(a.grad)
+            g2 = None
+        _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.momentum_buffer),
                   float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), int(self._steps == 0), _lib.stream())
         self._steps += 1
 

@@ -180,7 +180,10 @@ def test_sgd_and_ema_match_reference(dev, golden):
     n0 = int(np.prod(shapes[0]))
     for s in range(3):
         grads = torch.cat([seeded_randn(50 + 10 * s + i, *shp).flatten() for i, shp in enumerate(shapes)]).to(dev)
-        _lib.call("ssv_sgd_nesterov", flat.numel(), _lib.ptr(flat), _lib.ptr(grads), _lib.ptr(buf), 0.3, 1e-2, 0.9, int(s == 0), _lib.stream())
+        half = (grads * 0.25).contiguous()                       # split the gradient over the two slabs: g + g2
+        rest = (grads - half).contiguous()
+        _lib.call("ssv_sgd_nesterov", flat.numel(), _lib.ptr(flat), _lib.ptr(rest), _lib.ptr(half) if s else 0, _lib.ptr(buf), 0.3, 1e-2, 0.9, int(s == 0), _lib.stream()) if s else \
+            _lib.call("ssv_sgd_nesterov", flat.numel(), _lib.ptr(flat), _lib.ptr(grads), 0, _lib.ptr(buf), 0.3, 1e-2, 0.9, 1, _lib.stream())
         close(flat[:n0].view(shapes[0]), torch.tensor(g[f"sgd_p0_step{s}"]), rtol=2e-6, atol=2e-7, what=f"sgd p0 step {s}")
         close(flat[n0:], torch.tensor(g[f"sgd_p1_step{s}"]), rtol=2e-6, atol=2e-7, what=f"sgd p1 step {s}")
     t, o = seeded_randn(41, 777), seeded_randn(42, 777)

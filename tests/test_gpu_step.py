@@ -113,13 +113,20 @@ class _Step:
         self.loss_fn = losses.SimclrLoss(normalize, temperature)
         self.dev = dev
 
-    def step(self, a1, a2):
-        z1 = self.proj_head(self.encoder(a1.to(self.dev)))
-        z2 = self.proj_head(self.encoder(a2.to(self.dev)))
+    def step(self, a1, a2, dual=False):
+        from ssv_amd import nn as hnn
+        a1, a2 = a1.to(self.dev), a2.to(self.dev)
+        with hnn.parallel_views(self.dev, enabled=dual) as pv:
+            with pv.view(0):
+                z1 = self.proj_head(self.encoder(a1))
+            with pv.view(1):
+                z2 = self.proj_head(self.encoder(a2))
         loss = self.loss_fn(z1, z2)
         self.optim.zero_grad()
         loss.backward()
-        self.grads = self.optim.arena.grad.clone()
+        from ssv_amd import nn as hnn
+        hnn.join_view_streams(self.dev)
+        self.grads = self.optim.arena.grad + self.optim.arena.grad_alt       # test-side read-out of the two slabs
         self.optim.step()
         return loss.item(), z1.detach(), z2.detach()
 
@@ -236,6 +243,26 @@ def test_features_match_reference(dev, golden):
         z = m.proj_head(m.encoder(seeded_randn(400, 16, 3, 32, 32).to(dev)))
         f = ops.l2norm_fwd(z.contiguous(), True)[0]
     close(f, g["features_r18"], rtol=1e-4, atol=1e-5, what="build_features")
+
+
+def test_two_stream_views_bitwise_equal_sequential(dev):
+    """The two views on two HIP streams (separate scratch, separate gradient slabs, BN running-stat order kept by
+    events) give the same bits as the sequential pass: loss, embeddings, every parameter and BN buffer after 2 steps."""
+    res = []
+    for dual in (False, True):
+        m = _Step(dev, "resnet18", True)
+        out = []
+        for s in range(2):
+            loss, z1, z2 = m.step(seeded_randn(900 + 2 * s, 48, 3, 32, 32), seeded_randn(901 + 2 * s, 48, 3, 32, 32), dual=dual)
+            out.append((loss, z1.cpu(), z2.cpu()))
+        torch.cuda.synchronize()
+        res.append((out, m.optim.arena.data.cpu().clone(), {k: v.cpu().clone() for k, v in m.state().items() if "running" in k or "num_batches" in k}))
+    (o0, p0, b0), (o1, p1, b1) = res
+    for (l0, a0, c0), (l1, a1, c1) in zip(o0, o1):
+        assert l0 == l1 and torch.equal(a0, a1) and torch.equal(c0, c1)
+    assert torch.equal(p0, p1)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
 
 
 def test_train_step_is_bitwise_repeatable(dev):
