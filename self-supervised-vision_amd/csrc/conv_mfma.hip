@@ -43,6 +43,20 @@ struct ConvKP {
   FastDiv dHoWo, dWo, dC, dS;
 };
 
+// Buffer loads: a 128-bit resource descriptor (base, byte size) in SGPRs + a 32-bit per-lane byte offset + a uniform
+// SGPR byte offset.  Anything out of [0, size) reads as ZERO in hardware, so padding taps, ragged tile edges and rows
+// past the end of a tensor cost one select on the OFFSET (or nothing) instead of exec-mask branches or data selects.
+// Needs tensors below 2 GiB (offsets stay non-negative ints; OOB_OFF + any in-range offset is still out of range).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int OOB_OFF = (int)0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(rsrc_t rs, int voff_bytes, int soff_bytes) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0));
+}
+
 template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const float* __restrict__ Bs,
                                           int wr0, int wc0, int lane, f32x16 (&acc)[TM][TN]) {
@@ -140,11 +154,32 @@ __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[
 //   PIPE = true  : two LDS stages and two fragment register sets, ONE barrier per tile, software pipelined so that a
 //                  wave keeps its SIMD's matrix pipe fed on its own: the fragments of substep s+1 are read while the
 //                  16 MFMAs of substep s run, and the next tile's ds_writes sit in front of the last substep's MFMAs.
-template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int STAGE, bool PIPE, class LoadTile, class StoreTile>
+// compile-time interleave of one MFMA group with N memory instructions of kind `mask` (LLVM sched groups:
+// 0x8 MFMA, 0x20 VMEM read, 0x100 DS read, 0x200 DS write): MFMA, mem, MFMA, mem, ... then the remaining MFMAs.
+// A VMEM / DS-write wave-instruction holds the wave's issue port for ~50-70 cycles - about one fp32 MFMA (64 cycles
+// on the matrix pipe) - so alternating them keeps the pipe fed while the wave issues its memory traffic.
+#define SSV_INTERLEAVE(NMFMA, NMEM, MASK)                                            \
+  do {                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NMEM) && i_ < (NMFMA); ++i_) {         \
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                               \
+      __builtin_amdgcn_sched_group_barrier((MASK), 1, 0);                            \
+    }                                                                                \
+    if ((NMFMA) > (NMEM)) __builtin_amdgcn_sched_group_barrier(0x8, (NMFMA) - (NMEM), 0); \
+  } while (0)
+
+// K loop over staged tiles.  load_tile() issues the next tile's global loads into registers, store_tile(buf)
+// writes those registers to LDS stage `buf`.
+//   PIPE = false : one LDS stage, two barriers per tile (small LDS footprint, 3 workgroups per CU).
+//   PIPE = true  : two LDS stages and two fragment register sets, ONE barrier per tile, software pipelined so that a
+//                  wave keeps its SIMD's matrix pipe fed on its own: the fragments of substep s+1 are read while the
+//                  MFMAs of substep s run, the next tile's NLD buffer loads are interleaved one-per-MFMA into the first
+//                  substep and its NLD ds_writes into the last one.
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int STAGE, bool PIPE, int NLD, class LoadTile, class StoreTile>
 __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs, int wr0, int wc0, int lane,
                                        f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile) {
   if (nkt <= 0) return;
   constexpr int NS = BK / 8;
+  constexpr int NM = 4 * TM * TN;            // MFMAs per substep
   load_tile();
   store_tile(0);
   __syncthreads();
@@ -180,22 +215,30 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
     Frags<TM, TN> fr[2];
     load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As, Bs, wr0, wc0, lane, 0);
     int cur = 0;
+    // The body is branch-free so that the whole substep is one scheduling region: after the LAST tile it still issues
+    // a tile's worth of loads and stores them to the idle stage - buffer loads cannot fault (out of range reads 0) and
+    // nobody reads that stage.
     for (int kt = 0; kt < nkt; ++kt) {
-      const bool more = kt + 1 < nkt;
-      if (more) load_tile();
       const float* a = As + cur * STAGE;
       const float* b = Bs + cur * STAGE;
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < NS) load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[(ks + 1) & 1], a, b, wr0, wc0, lane, ks + 1);
-        else if (more) store_tile(cur ^ 1);  // other stage: last read before the previous barrier
-        __builtin_amdgcn_sched_barrier(0);   // keep the LDS traffic IN FRONT of this substep's MFMAs (hipcc sinks it otherwise)
+        if (ks == 0) load_tile();                       // NLD buffer loads, one per MFMA of this substep
+        else if (ks == NS - 1) store_tile(cur ^ 1);     // other stage: last read before the previous barrier
         mma_frags<TM, TN>(fr[ks & 1], acc);
+        if (NLD > 0 && ks == 0) {
+          if (A_ROWK && B_ROWK) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // next substep's fragment reads first
+          SSV_INTERLEAVE(NM, NLD, 0x20);
+        } else if (NLD > 0 && ks == NS - 1) {
+          SSV_INTERLEAVE(NM, NLD, 0x200);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
       cur ^= 1;
-      if (more) load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As + cur * STAGE, Bs + cur * STAGE, wr0, wc0, lane, 0);
+      load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As + cur * STAGE, Bs + cur * STAGE, wr0, wc0, lane, 0);
     }
   }
 }
@@ -228,60 +271,59 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     constexpr int CH = BK / 4, RPP = 256 / CH;
     constexpr int AP = BM / RPP, BP = BN / RPP;
     const int chunk = (tid % CH) * 4, rsub = tid / CH;
-    // Loader state per staged row: 32-bit element offset of (n, hi0, wi0, chunk) from x (negative in the padding),
-    // top-left input coordinate, validity.  Per tile the tap contributes ONE uniform scalar offset; the loads are
-    // unconditional (invalid rows read x[0] and are zeroed by a select) so the loop has no exec-mask branches.
+    // Loader state per staged row: byte offset of (n, hi0, wi0, chunk) in x, top-left input coordinate.  Per tile the
+    // tap adds ONE uniform offset; invalid rows / taps get the out-of-range offset and come back as zeros.
+    const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * p.C * 4u);
+    const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.RSC * 4u);
     int hi0[AP], wi0[AP], aoff[AP];
-    bool aok[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int m = m0 + rsub + RPP * i;
-      aok[i] = m < p.M;
-      const uint32_t mm = aok[i] ? (uint32_t)m : 0u;
+      const bool ok = m < p.M;
+      const uint32_t mm = ok ? (uint32_t)m : 0u;
       const uint32_t n = fdiv(mm, p.dHoWo);
       const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
       const uint32_t ho = fdiv(rem, p.dWo);
       const uint32_t wo = rem - ho * (uint32_t)p.Wo;
-      hi0[i] = (int)ho * p.stride - p.pad;
+      hi0[i] = ok ? (int)ho * p.stride - p.pad : -(1 << 20);         // a row past M never passes the bounds test
       wi0[i] = (int)wo * p.stride - p.pad;
-      aoff[i] = (((int)n * p.H + hi0[i]) * p.W + wi0[i]) * p.C + chunk;
+      aoff[i] = ((((int)n * p.H + hi0[i]) * p.W + wi0[i]) * p.C + chunk) * 4;
+      if (!ok) aoff[i] = OOB_OFF;
     }
     int boff[BP];
-    bool bok[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       const int ko = n0 + rsub + RPP * i;
-      bok[i] = ko < p.K;
-      boff[i] = (bok[i] ? ko : 0) * p.RSC + chunk;
+      boff[i] = ko < p.K ? (ko * p.RSC + chunk) * 4 : OOB_OFF;
     }
     const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;     // 1x1 / no padding: every tap of a valid row is in bounds
     int lr = 0, ls = 0, lc0 = 0;   // loader position (tap r, s, first channel)
     f32x4 ra[AP], rb[BP];
-    unsigned okmask = 0;                                       // validity of the rows in flight; applied when they are stored
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&]() {
-      const int toff_x = (lr * p.W + ls) * p.C + lc0;          // uniform
-      const int toff_w = (lr * p.S + ls) * p.C + lc0;
-      okmask = 0;
+      const int toff_x = ((lr * p.W + ls) * p.C + lc0) * 4;    // uniform
+      const int toff_w = ((lr * p.S + ls) * p.C + lc0) * 4;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        const bool ok = aok[i] & (inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W)));
-        ra[i] = *reinterpret_cast<const f32x4*>(x + (ok ? aoff[i] + toff_x : 0));
-        okmask |= (unsigned)ok << i;
+        const bool ok = inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W));
+        ra[i] = bload4(rx, ok ? aoff[i] + toff_x : OOB_OFF, 0);
       }
 #pragma unroll
-      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w + boff[i] + toff_w);
-      lc0 += BK;
-      if (lc0 >= p.C) { lc0 = 0; if (++ls == p.S) { ls = 0; ++lr; } }
+      for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
+      lc0 += BK;                                               // straight-line advance (selects, no branches): keeps the
+      const bool w1 = lc0 >= p.C;                              // k-loop body a single scheduling region
+      lc0 = w1 ? 0 : lc0;
+      ls += w1 ? 1 : 0;
+      const bool w2 = ls == p.S;
+      ls = w2 ? 0 : ls;
+      lr += w2 ? 1 : 0;
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i)
-        *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ((okmask >> i) & 1u) ? ra[i] : zero4;
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
-      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = bok[i] ? rb[i] : zero4;
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, STAGE, DB>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+    k_loop<TM, TN, true, true, LDT, LDT, BK, STAGE, DB, AP + BP>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
     static_assert(BK == GBK && !DB, "generic path is BK=16, single buffer");
@@ -436,57 +478,54 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   constexpr int BRP = 256 / BCV;         // B rows per pass
   constexpr int BP = BK / BRP;           // B passes
   const int chunk = (tid % CH) * 4, rsub = tid / CH;
-  // branch-free loader (see the forward kernel): 32-bit element offset of (n, hq, wq, chunk) in dY per staged row,
-  // one uniform scalar offset per (tap, k-tile)
+  // buffer-load loader (see the forward kernel): byte offset of (n, hq, wq, chunk) in dY per staged row, one uniform
+  // offset per (tap, k-tile); rows outside the class / taps outside dY read as zeros
+  const rsrc_t rdy = make_rsrc(dy, (unsigned)p.N * p.Ho * p.Wo * p.K * 4u);
+  const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.RSC * 4u);
   int hq_[AP], wq_[AP], aoff[AP];
-  bool aok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = m0 + rsub + RPP * i;
-    aok[i] = m < Mc;
-    const int mm = aok[i] ? m : 0;
+    const bool ok = m < Mc;
+    const int mm = ok ? m : 0;
     const int n = mm / (Hq * Wq);
     const int rem = mm - n * Hq * Wq;
-    hq_[i] = rem / Wq; wq_[i] = rem - hq_[i] * Wq;
-    aoff[i] = ((n * p.Ho + hq_[i]) * p.Wo + wq_[i]) * p.K + chunk;
+    hq_[i] = ok ? rem / Wq : -(1 << 20);
+    wq_[i] = rem - (rem / Wq) * Wq;
+    aoff[i] = ok ? (((n * p.Ho + hq_[i]) * p.Wo + wq_[i]) * p.K + chunk) * 4 : OOB_OFF;
   }
   const int bcol = (tid % BCV) * 4, brow = tid / BCV;
-  const bool bcok = n0 + bcol < p.C;
-  const int boff = brow * p.RSC + (bcok ? n0 + bcol : 0);
+  const int boff = n0 + bcol < p.C ? (brow * p.RSC + n0 + bcol) * 4 : OOB_OFF;
   const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;       // 1x1: the single tap maps every class pixel onto a valid dY pixel
 
   int ti = 0, lk0 = 0;                   // loader position: tap index, first output channel
   int dho = 0, dwo = 0, tapoff = 0;
   if (ntaps > 0) { dho = taps[0]; dwo = taps[1]; tapoff = taps[2]; }
   f32x4 ra[AP], rb[BP];
-  unsigned okmask = 0;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_tile = [&]() {
-    const int toff_a = (dho * p.Wo + dwo) * p.K + lk0;         // uniform
-    const int toff_b = lk0 * p.RSC + tapoff;
-    okmask = 0;
+    const int toff_a = ((dho * p.Wo + dwo) * p.K + lk0) * 4;   // uniform (may be negative: folded into the lane offset)
+    const int toff_b = (lk0 * p.RSC + tapoff) * 4;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const bool ok = aok[i] & (inb | (((unsigned)(hq_[i] + dho) < (unsigned)p.Ho) & ((unsigned)(wq_[i] + dwo) < (unsigned)p.Wo)));
-      ra[i] = *reinterpret_cast<const f32x4*>(dy + (ok ? aoff[i] + toff_a : 0));
-      okmask |= (unsigned)ok << i;
+      const bool ok = inb | (((unsigned)(hq_[i] + dho) < (unsigned)p.Ho) & ((unsigned)(wq_[i] + dwo) < (unsigned)p.Wo));
+      ra[i] = bload4(rdy, ok ? aoff[i] + toff_a : OOB_OFF, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w + boff + toff_b + BRP * i * p.RSC);
-    lk0 += BK;
-    if (lk0 >= p.K) {
-      lk0 = 0; ++ti;
-      if (ti < ntaps) { dho = taps[3 * ti]; dwo = taps[3 * ti + 1]; tapoff = taps[3 * ti + 2]; }
-    }
+    for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff + BRP * i * p.RSC * 4, toff_b);
+    lk0 += BK;                                                 // straight-line advance to the next (tap, k-tile)
+    const bool w1 = lk0 >= p.K;
+    lk0 = w1 ? 0 : lk0;
+    ti += w1 ? 1 : 0;
+    const int tc = ti < ntaps ? ti : ntaps - 1;
+    dho = taps[3 * tc]; dwo = taps[3 * tc + 1]; tapoff = taps[3 * tc + 2];
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ((okmask >> i) & 1u) ? ra[i] : zero4;
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = bcok ? rb[i] : zero4;
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = rb[i];
   };
-  k_loop<TM, TN, true, false, LDT, BN, BK, STAGE, DB>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  k_loop<TM, TN, true, false, LDT, BN, BK, STAGE, DB, AP + BP>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -512,7 +551,7 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // =============================================================================================
 // wgrad: partial[split][K][RSC] over a chunk of the N*Ho*Wo contraction
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VECB>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VECB, bool LIN>
 __global__ void __launch_bounds__(256)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -547,31 +586,37 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   const int rj = (int)fdiv(tap, p.dS);
   const int sj = (int)tap - rj * p.S;
 
+  // buffer-load loaders: the row index m only enters through a UNIFORM byte offset (mcur * row pitch), the per-lane offsets
+  // are loop constants; rows past the end of the tensor read as zeros (a chunk is a whole number of K-steps, so rows
+  // >= me exist only at the tensor end), invalid columns carry the out-of-range offset.
+  const rsrc_t rdy = make_rsrc(dy, (unsigned)p.M * p.K * 4u);
+  const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * p.C * 4u);
   int mcur = ms;
   f32x4 ra[AP];
   f32x4 rbv[VECB ? BP : 1];
   float rbs[VECB ? 1 : BP];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int aoff0 = i0 + (acok ? acol : 0);
-  const bool lin = p.R == 1 && p.S == 1 && p.pad == 0 && p.stride == 1;     // 1x1/s1: row m of X is simply x + m*C
-  unsigned okmask = 0;
+  int avoff[AP], bvoff[BP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) avoff[i] = acok ? ((arow + ARP * i) * p.K + i0 + acol) * 4 : OOB_OFF;
+  // LIN: 1x1 / stride 1 / no padding - row m of X is simply x + m*C
+#pragma unroll
+  for (int i = 0; i < BP; ++i) bvoff[i] = jok ? ((brow + BRP * i) * p.C + cj) * 4 : OOB_OFF;
   auto load_tile = [&]() {
-    okmask = 0;
+    const int soff_a = mcur * p.K * 4;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int m = mcur + arow + ARP * i;
-      const bool ok = acok & (m < me);
-      ra[i] = *reinterpret_cast<const f32x4*>(dy + (ok ? m * p.K + aoff0 : 0));
-      okmask |= (unsigned)ok << i;
-    }
+    for (int i = 0; i < AP; ++i) ra[i] = bload4(rdy, avoff[i], soff_a);
+    if constexpr (LIN) {
+      const int soff_b = mcur * p.C * 4;
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int m = mcur + brow + BRP * i;
-      bool ok = jok & (m < me);
-      int off;
-      if (lin) {
-        off = m * p.C + cj;
-      } else {
+      for (int i = 0; i < BP; ++i) {
+        if constexpr (VECB) rbv[i] = bload4(rx, bvoff[i], soff_b);
+        else rbs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, bvoff[i], soff_b, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const int m = mcur + brow + BRP * i;
+        bool ok = jok & (m < p.M);
         const uint32_t mm = ok ? (uint32_t)m : 0u;
         const uint32_t n = fdiv(mm, p.dHoWo);
         const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
@@ -579,26 +624,23 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
         const uint32_t wo = rem - ho * (uint32_t)p.Wo;
         const int hi = (int)ho * p.stride - p.pad + rj, wi = (int)wo * p.stride - p.pad + sj;
         ok = ok & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-        off = (((int)n * p.H + hi) * p.W + wi) * p.C + cj;
+        const int off = ok ? ((((int)n * p.H + hi) * p.W + wi) * p.C + cj) * 4 : OOB_OFF;
+        if constexpr (VECB) rbv[i] = bload4(rx, off, 0);
+        else rbs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
       }
-      if constexpr (VECB) rbv[i] = *reinterpret_cast<const f32x4*>(x + (ok ? off : 0));
-      else rbs[i] = x[ok ? off : 0];
-      okmask |= (unsigned)ok << (8 + i);
     }
     mcur += BK;
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf * STAGE + (arow + ARP * i) * BM + acol]) = ((okmask >> i) & 1u) ? ra[i] : zero4;
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (arow + ARP * i) * BM + acol]) = ra[i];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      const bool ok = (okmask >> (8 + i)) & 1u;
-      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = ok ? rbv[i] : zero4;
-      else Bs[buf * STAGE + (brow + BRP * i) * BN + bcol] = ok ? rbs[i] : 0.f;
+      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = rbv[i];
+      else Bs[buf * STAGE + (brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
-  k_loop<TM, TN, false, false, BM, BN, BK, STAGE, DB>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  k_loop<TM, TN, false, false, BM, BN, BK, STAGE, DB, (VECB ? AP + BP : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   float* out = partial + (size_t)split * p.K * p.RSC;
   const int l31 = lane & 31, h = lane >> 5;
@@ -649,9 +691,9 @@ int check_desc(const ssv_conv_desc* d, const char* who) {
   SSV_REQUIRE(Ho == d->Ho && Wo == d->Wo, "%s: Ho/Wo (%d,%d) inconsistent with input/filter/stride/pad (expect %d,%d)", who, d->Ho, d->Wo, Ho, Wo);
   SSV_REQUIRE((int64_t)d->N * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo < (1ll << 31), "%s: too many pixels", who);
   SSV_REQUIRE((int64_t)d->R * d->S * d->C < (1 << 24) && d->R * d->S <= 64 && d->H < 32768 && d->W < 32768, "%s: filter too large", who);
-  // the kernels address activations and filters with 32-bit element offsets
-  SSV_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 31) - (1 << 24) && (int64_t)d->N * d->Ho * d->Wo * d->K < (1ll << 31) - (1 << 24) &&
-              (int64_t)d->K * d->R * d->S * d->C < (1ll << 31), "%s: tensor above 2^31 elements (8 GiB) - split the batch", who);
+  // the kernels address activations and filters through buffer descriptors with non-negative 32-bit byte offsets
+  SSV_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 29) - (1 << 22) && (int64_t)d->N * d->Ho * d->Wo * d->K < (1ll << 29) - (1 << 22) &&
+              (int64_t)d->K * d->R * d->S * d->C < (1ll << 29), "%s: tensor of 2 GiB or more - split the batch", who);
   return SSV_OK;
 }
 
@@ -796,15 +838,18 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   const int tiles = wp.it * wp.jt;
   const dim3 grid((unsigned)(tiles * wp.nsplit));
   float* part = (float*)ws;
+  const bool lin = d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1;
   if (!vecb) {
-    if (wp.bm == 128) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, GBK, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
-    else              hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, GBK, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+    if (wp.bm == 128) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, GBK, false, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+    else              hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, GBK, false, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
   } else if (wp.bm == 128) {
-#define CALL(B_, D_) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define CALL(B_, D_) do { if (lin) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
+                          else hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
     SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
 #undef CALL
   } else {
-#define CALL(B_, D_) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define CALL(B_, D_) do { if (lin) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
+                          else hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
     SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
 #undef CALL
   }
