@@ -66,39 +66,50 @@ bn_stats_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ 
   }
 }
 
-// Merge of the per-block (mean_b, M2_b): 32 channels x 8 groups of blocks per workgroup (128-B coalesced
-// rows of the partial arrays), two division-free passes in double:
-//   mean = sum_b n_b*mean_b / M ;  M2 = sum_b (M2_b + n_b*(mean_b-mean)^2)      (fixed summation order)
+// Merge of the per-block (mean_b, M2_b): 8 channels x 32 groups of partial blocks per workgroup, so that even the
+// narrowest layer (C = 64) gets 8 workgroups and a lane walks only nblk/32 partials (4 loads in flight); two
+// division-free passes in double, fixed summation order:
+//   mean = sum_b n_b*mean_b / M ;  M2 = sum_b (M2_b + n_b*(mean_b-mean)^2)
+constexpr int FIN_C = 8, FIN_G = 32;
+
+template <class F>
+__device__ __forceinline__ double fin_group_sum(int b0, int b1, F&& term) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) { a0 += term(b); a1 += term(b + 1); a2 += term(b + 2); a3 += term(b + 3); }
+  for (; b < b1; ++b) a0 += term(b);
+  return (a0 + a1) + (a2 + a3);
+}
+
 __global__ void __launch_bounds__(256)
 bn_stats_finalize_k(int64_t M, int C, int rpb, int nblk, const float* __restrict__ pmean, const float* __restrict__ pm2,
                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* nbt,
                     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double sm[8][32];
-  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double sm[FIN_G][FIN_C];
+  const int cl = threadIdx.x % FIN_C, grp = threadIdx.x / FIN_C;
+  const int c = blockIdx.x * FIN_C + cl;
   const bool ok = c < C;
-  const int per = (nblk + 7) / 8;
-  const int b0 = grp * per, b1 = min(b0 + per, nblk);
-  const double last_n = (double)(M - (int64_t)(nblk - 1) * rpb);
+  const int per = (nblk + FIN_G - 1) / FIN_G;
+  const int b0 = min(grp * per, nblk), b1 = min(b0 + per, nblk);
+  const double last_n = (double)(M - (int64_t)(nblk - 1) * rpb), full_n = (double)rpb;
   double acc = 0.0;
-  if (ok) for (int b = b0; b < b1; ++b) acc += (b == nblk - 1 ? last_n : (double)rpb) * (double)pmean[(size_t)b * C + c];
+  if (ok) acc = fin_group_sum(b0, b1, [&](int b) { return (b == nblk - 1 ? last_n : full_n) * (double)pmean[(size_t)b * C + c]; });
   sm[grp][cl] = acc;
   __syncthreads();
   double mean = 0.0;
-  for (int g = 0; g < 8; ++g) mean += sm[g][cl];
+  for (int g = 0; g < FIN_G; ++g) mean += sm[g][cl];
   mean /= (double)M;
   __syncthreads();
   acc = 0.0;
-  if (ok) for (int b = b0; b < b1; ++b) {
+  if (ok) acc = fin_group_sum(b0, b1, [&](int b) {
     const double d = (double)pmean[(size_t)b * C + c] - mean;
-    acc += (double)pm2[(size_t)b * C + c] + (b == nblk - 1 ? last_n : (double)rpb) * d * d;
-  }
+    return (double)pm2[(size_t)b * C + c] + (b == nblk - 1 ? last_n : full_n) * d * d; });
   sm[grp][cl] = acc;
   __syncthreads();
   if (grp == 0 && ok) {
     double m2 = 0.0;
-    for (int g = 0; g < 8; ++g) m2 += sm[g][cl];
+    for (int g = 0; g < FIN_G; ++g) m2 += sm[g][cl];
     const double var = m2 / (double)M;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
@@ -187,19 +198,22 @@ bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restri
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, const float* __restrict__ psgx,
                   float* dgamma, float* dbeta, int accumulate, float* __restrict__ k1, float* __restrict__ k2) {
-  __shared__ double s1[8][32], s2[8][32];
-  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double s1[FIN_G][FIN_C], s2[FIN_G][FIN_C];
+  const int cl = threadIdx.x % FIN_C, grp = threadIdx.x / FIN_C;
+  const int c = blockIdx.x * FIN_C + cl;
   const bool ok = c < C;
-  const int per = (nblk + 7) / 8;
-  const int b0 = grp * per, b1 = min(b0 + per, nblk);
+  const int per = (nblk + FIN_G - 1) / FIN_G;
+  const int b0 = min(grp * per, nblk), b1 = min(b0 + per, nblk);
   double sg = 0.0, sgx = 0.0;
-  if (ok) for (int b = b0; b < b1; ++b) { sg += (double)psg[(size_t)b * C + c]; sgx += (double)psgx[(size_t)b * C + c]; }
+  if (ok) {
+    sg = fin_group_sum(b0, b1, [&](int b) { return (double)psg[(size_t)b * C + c]; });
+    sgx = fin_group_sum(b0, b1, [&](int b) { return (double)psgx[(size_t)b * C + c]; });
+  }
   s1[grp][cl] = sg; s2[grp][cl] = sgx;
   __syncthreads();
   if (grp == 0 && ok) {
     sg = 0.0; sgx = 0.0;
-    for (int g = 0; g < 8; ++g) { sg += s1[g][cl]; sgx += s2[g][cl]; }
+    for (int g = 0; g < FIN_G; ++g) { sg += s1[g][cl]; sgx += s2[g][cl]; }
     k1[c] = (float)(sg / (double)M);
     k2[c] = (float)(sgx / (double)M);
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
@@ -255,19 +269,19 @@ colsum_partial_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restr
 }
 __global__ void __launch_bounds__(256)
 colsum_finalize_k(int C, int nblk, const float* __restrict__ ps, float* out, int accumulate) {
-  __shared__ double s1[8][32];
-  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double s1[FIN_G][FIN_C];
+  const int cl = threadIdx.x % FIN_C, grp = threadIdx.x / FIN_C;
+  const int c = blockIdx.x * FIN_C + cl;
   const bool ok = c < C;
-  const int per = (nblk + 7) / 8;
-  const int b0 = grp * per, b1 = min(b0 + per, nblk);
+  const int per = (nblk + FIN_G - 1) / FIN_G;
+  const int b0 = min(grp * per, nblk), b1 = min(b0 + per, nblk);
   double s = 0.0;
-  if (ok) for (int b = b0; b < b1; ++b) s += (double)ps[(size_t)b * C + c];
+  if (ok) s = fin_group_sum(b0, b1, [&](int b) { return (double)ps[(size_t)b * C + c]; });
   s1[grp][cl] = s;
   __syncthreads();
   if (grp == 0 && ok) {
     s = 0.0;
-    for (int g = 0; g < 8; ++g) s += s1[g][cl];
+    for (int g = 0; g < FIN_G; ++g) s += s1[g][cl];
     out[c] = (accumulate ? out[c] : 0.f) + (float)s;
   }
 }
@@ -303,7 +317,7 @@ extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const floa
   float* shift = scale + C;
   const dim3 grid(p.nblk, p.GY);
   hipLaunchKernelGGL(bn_stats_k, grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, pmean, pm2);
-  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
                      gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   if (relu) {
     if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
@@ -334,7 +348,7 @@ extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const flo
   const dim3 grid(p.nblk, p.GY);
   if (relu) hipLaunchKernelGGL((bn_bwd_reduce_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
   else      hipLaunchKernelGGL((bn_bwd_reduce_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
                      dgamma, dbeta, accumulate, k1, k2);
   const float* ck1 = k1; const float* ck2 = k2;
   if (relu) {
@@ -358,7 +372,7 @@ extern "C" int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int 
   const BnPlan p = bn_plan(M, C);
   float* part = (float*)ws;
   hipLaunchKernelGGL(colsum_partial_k, dim3(p.nblk, p.GY), dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, part);
-  hipLaunchKernelGGL(colsum_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, C, p.nblk, (const float*)part, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, C, p.nblk, (const float*)part, out, accumulate);
   SSV_CHECK_LAUNCH("ssv_colsum");
   return SSV_OK;
 }
