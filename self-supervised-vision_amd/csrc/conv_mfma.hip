@@ -193,6 +193,7 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 #else
 #define STAMP(var) do {} while (0)
 #endif
+#ifdef SSV_STAMP
     for (int kt = 0; kt < nkt; ++kt) {
       const bool more = kt + 1 < nkt;
       if (more) load_tile();                 // next tile's global loads fly under this tile's MFMAs
@@ -203,6 +204,30 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
       STAMP(t_b1);
       if (more) { store_tile(0); STAMP(t_st); __syncthreads(); STAMP(t_b2); }
     }
+#else
+    // Branch-free body (one scheduling region per tile): the next tile's NLD buffer loads are issued one per MFMA of
+    // the first substep instead of in front of the MFMAs (a VMEM wave-instruction holds the issue port ~65 cycles).
+    // The loads issued during the last tile fall outside the operands and are never stored (buffer loads cannot fault).
+    Frags<TM, TN> fr;
+    for (int kt = 0; kt < nkt; ++kt) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr, As, Bs, wr0, wc0, lane, 0);
+      load_tile();
+      mma_frags<TM, TN>(fr, acc);
+      if (NLD > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x100, A_ROWK && B_ROWK ? TM + TN : (A_ROWK ? TM + 4 * TN : 4 * (TM + TN)), 0);
+        SSV_INTERLEAVE(NM, NLD, 0x20);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 1; ks < NS; ++ks) {
+        load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr, As, Bs, wr0, wc0, lane, ks);
+        mma_frags<TM, TN>(fr, acc);
+      }
+      __syncthreads();
+      if (kt + 1 < nkt) { store_tile(0); __syncthreads(); }
+    }
+#endif
 #ifdef SSV_STAMP
     if (threadIdx.x == 0) {
       atomicAdd(&g_stamps[0], t_ld); atomicAdd(&g_stamps[1], t_mma); atomicAdd(&g_stamps[2], t_b1);
