@@ -64,16 +64,18 @@ int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, fl
  * replaces nn.BatchNorm2d / nn.BatchNorm1d (+ReLU, + residual add) at networks/resnet.py:39-44,
  * 68-74,147 and models/simclr.py:34-35.  C % 4 == 0.
  * fwd: mean/var per channel (shifted sums per block, Chan merge in double), running stats with
- * unbiased var, y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ). */
+ * unbiased var, y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ).
+ * relu_mask (may be NULL; M*C/4 bytes): one byte per group of four channels, bit e set where output e is positive -
+ * the backward then reads 1 byte instead of 16 bytes of y (pass the same buffer to ssv_bn_train_bwd, or y). */
 size_t ssv_bn_workspace_bytes(int64_t M, int32_t C);
 int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
                      const float* residual, int relu, float eps, float momentum,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     float* y, float* save_mean, float* save_invstd,
+                     float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd,
                      void* ws, size_t ws_bytes, void* stream);
 /* bwd: g = dy * (y>0 if relu); dgamma (+)= sum g*xhat; dbeta (+)= sum g;
  * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dresidual = g if not NULL. */
-int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const float* x,
+int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const uint8_t* relu_mask, const float* x,
                      const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                      float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);

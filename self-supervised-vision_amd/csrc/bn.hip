@@ -127,10 +127,12 @@ bn_stats_finalize_k(int64_t M, int C, int rpb, int nblk, const float* __restrict
   }
 }
 
+// With RELU the kernel can also write the ReLU mask, one byte per float4 (bit e = element e was positive): the backward
+// then reads 1 byte instead of the 16 bytes of y for each group of four elements.
 template <bool RELU, bool RES>
 __global__ void __launch_bounds__(256)
 bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ x, const float* __restrict__ scale,
-           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y) {
+           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, uint8_t* __restrict__ mask) {
   const int tid = threadIdx.x;
   const int ct = tid % CT, rt = tid / CT;
   const int c4 = blockIdx.y * CT + ct;
@@ -142,7 +144,10 @@ bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ 
     const size_t o = (size_t)r * C + 4 * c4;
     f32x4 v = ld4(x + o) * sc + sh;
     if constexpr (RES) v += ld4(res + o);
-    if constexpr (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if constexpr (RELU) {
+      if (mask) mask[o >> 2] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
     st4(y + o, v);
   };
   int64_t r = r0 + rt;
@@ -159,11 +164,20 @@ __device__ __forceinline__ f32x4 masked(f32x4 g, f32x4 yv) {
   }
   return g;
 }
+// g masked by ReLU: from the byte mask when the forward wrote one, else from the sign of y
+__device__ __forceinline__ f32x4 relu_grad(f32x4 g, const float* __restrict__ y, const uint8_t* __restrict__ mask, size_t o) {
+  if (mask) {
+    const unsigned b = mask[o >> 2];
+    g[0] = (b & 1u) ? g[0] : 0.f; g[1] = (b & 2u) ? g[1] : 0.f; g[2] = (b & 4u) ? g[2] : 0.f; g[3] = (b & 8u) ? g[3] : 0.f;
+    return g;
+  }
+  return masked<true>(g, ld4(y + o));
+}
 
 template <bool RELU>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
-                const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                const uint8_t* __restrict__ mask, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                 float* __restrict__ psg, float* __restrict__ psgx) {
   __shared__ f32x4 sm1[256], sm2[256];
   const int tid = threadIdx.x;
@@ -178,7 +192,7 @@ bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restri
     auto body = [&](int64_t r) {
       const size_t o = (size_t)r * C + 4 * c4;
       f32x4 g = ld4(dy + o);
-      if constexpr (RELU) g = masked<true>(g, ld4(y + o));
+      if constexpr (RELU) g = relu_grad(g, y, mask, o);
       const f32x4 xh = (ld4(x + o) - mu) * is;
       s1 += g; s2 += g * xh;
     };
@@ -224,7 +238,7 @@ bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, con
 template <bool RELU, bool DRES>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
-               const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+               const uint8_t* __restrict__ mask, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
                const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
                float* __restrict__ dx, float* __restrict__ dres) {
   const int tid = threadIdx.x;
@@ -238,7 +252,7 @@ bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restric
   auto body = [&](int64_t r) {
     const size_t o = (size_t)r * C + 4 * c4;
     f32x4 g = ld4(dy + o);
-    if constexpr (RELU) g = masked<true>(g, ld4(y + o));
+    if constexpr (RELU) g = relu_grad(g, y, mask, o);
     const f32x4 xh = (ld4(x + o) - mu) * is;
     st4(dx + o, gi * (g - a1 - xh * a2));
     if constexpr (DRES) st4(dres + o, g);
@@ -303,7 +317,7 @@ extern "C" size_t ssv_bn_workspace_bytes(int64_t M, int32_t C) {
 extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
                                 const float* residual, int relu, float eps, float momentum,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+                                float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_mc(M, C, "ssv_bn_train_fwd")) return rc;
   SSV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "ssv_bn_train_fwd: null pointer");
   SSV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "ssv_bn_train_fwd: running_mean/var must both be given or both NULL");
@@ -320,23 +334,23 @@ extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const floa
   hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
                      gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   if (relu) {
-    if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
-    else          hipLaunchKernelGGL((bn_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
+    if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
+    else          hipLaunchKernelGGL((bn_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
   } else {
-    if (residual) hipLaunchKernelGGL((bn_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
-    else          hipLaunchKernelGGL((bn_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y);
+    if (residual) hipLaunchKernelGGL((bn_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
+    else          hipLaunchKernelGGL((bn_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
   }
   SSV_CHECK_LAUNCH("ssv_bn_train_fwd");
   return SSV_OK;
 }
 
-extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const float* x,
+extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const uint8_t* relu_mask, const float* x,
                                 const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                                 float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,
                                 void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_mc(M, C, "ssv_bn_train_bwd")) return rc;
   SSV_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && ws, "ssv_bn_train_bwd: null pointer");
-  SSV_REQUIRE(!relu || y, "ssv_bn_train_bwd: relu mask needs y");
+  SSV_REQUIRE(!relu || y || relu_mask, "ssv_bn_train_bwd: the ReLU mask needs y or relu_mask");
   if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_BN_BWD, s);
@@ -346,17 +360,17 @@ extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const flo
   float* k1 = psgx + (size_t)p.nblk * C;
   float* k2 = k1 + C;
   const dim3 grid(p.nblk, p.GY);
-  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
-  else      hipLaunchKernelGGL((bn_bwd_reduce_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, save_mean, save_invstd, psg, psgx);
+  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, save_mean, save_invstd, psg, psgx);
+  else      hipLaunchKernelGGL((bn_bwd_reduce_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, save_mean, save_invstd, psg, psgx);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
                      dgamma, dbeta, accumulate, k1, k2);
   const float* ck1 = k1; const float* ck2 = k2;
   if (relu) {
-    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
-    else           hipLaunchKernelGGL((bn_bwd_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+    else           hipLaunchKernelGGL((bn_bwd_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
   } else {
-    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
-    else           hipLaunchKernelGGL((bn_bwd_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
+    else           hipLaunchKernelGGL((bn_bwd_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
   }
   SSV_CHECK_LAUNCH("ssv_bn_train_bwd");
   return SSV_OK;

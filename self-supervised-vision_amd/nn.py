@@ -171,8 +171,9 @@ def batchnorm(tape, x, bn, relu=False, residual=None):
         st = torch.cuda.current_stream(x.device)
         if _SLOT == 1 and bn._order_event is not None:
             st.wait_event(bn._order_event)
-    y, mean, invstd = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                       relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum)
+    y, mean, invstd, mask = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                             relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
+                                             want_mask=True, skip_mask=tape is None)   # 1 byte per 4 elements for the backward
     if _STREAMS and _SLOT == 0 and torch.cuda.current_stream(x.device) != torch.cuda.default_stream(x.device):
         if bn._order_event is None:
             object.__setattr__(bn, "_order_event", torch.cuda.Event())
@@ -182,7 +183,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None):
 
         def bwd(dy, existing):
             dx, dres = ops.bn_train_bwd(dy, y, x, bn.weight, mean, invstd, relu, grad_of(bn.weight, slot), grad_of(bn.bias, slot),
-                                        want_dres=residual is not None, accumulate=True)
+                                        want_dres=residual is not None, accumulate=True, relu_mask=mask)
             if residual is None:
                 return (_accum(existing[0], dx), None)
             return (_accum(existing[0], dx), _accum(existing[1], dres))

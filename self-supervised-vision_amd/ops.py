@@ -71,24 +71,26 @@ def _rows(x):
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, nbt, relu=False, residual=None,
-                 eps=BN_EPS, momentum=BN_MOMENTUM):
+                 eps=BN_EPS, momentum=BN_MOMENTUM, want_mask=False, skip_mask=False):
+    """Returns (y, mean, invstd[, relu_mask]).  relu_mask: uint8, one byte per four channels, for the backward."""
     _lib._dev(x, gamma, beta, residual)
     m, c = _rows(x)
     y = torch.empty_like(x)
     mean, invstd = _empty((c,), x), _empty((c,), x)
+    mask = torch.empty((m * c // 4,), dtype=torch.uint8, device=x.device) if (want_mask and relu and not skip_mask) else None
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
     call("ssv_bn_train_fwd", m, c, ptr(x), ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
-         ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws.numel(), stream())
-    return y, mean, invstd
+         ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mask), ptr(mean), ptr(invstd), ptr(ws), ws.numel(), stream())
+    return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
 
 
-def bn_train_bwd(dy, y, x, gamma, mean, invstd, relu, dgamma, dbeta, want_dres=False, accumulate=True):
+def bn_train_bwd(dy, y, x, gamma, mean, invstd, relu, dgamma, dbeta, want_dres=False, accumulate=True, relu_mask=None):
     _lib._dev(dy, y, x)
     m, c = _rows(x)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
-    call("ssv_bn_train_bwd", m, c, ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu),
+    call("ssv_bn_train_bwd", m, c, ptr(dy), ptr(y), ptr(relu_mask), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu),
          ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
     return dx, dres
 

@@ -116,8 +116,9 @@ def test_batchnorm_fwd_bwd(dev, shape, relu, res):
     g = lambda t: t.to(dev)
     rmd, rvd, nbt = g(torch.zeros(c)), g(torch.ones(c)), g(torch.zeros((), dtype=torch.long))
     xd = g(nhwc(x.detach()))
-    yd, mean, invstd = ops.bn_train_fwd(xd, g(gamma.detach()), g(beta.detach()), rmd, rvd, nbt, relu=relu,
-                                        residual=g(nhwc(r.detach())) if res else None)
+    yd, mean, invstd, mask = ops.bn_train_fwd(xd, g(gamma.detach()), g(beta.detach()), rmd, rvd, nbt, relu=relu,
+                                              residual=g(nhwc(r.detach())) if res else None, want_mask=True)
+    assert (mask is not None) == relu
     close(nchw(yd.cpu()), y, what="bn fwd")
     close(rmd, rm, what="running_mean")
     close(rvd, rv, what="running_var")
@@ -129,6 +130,12 @@ def test_batchnorm_fwd_bwd(dev, shape, relu, res):
     close(dbeta, beta.grad, rtol=2e-4, what="bn dbeta")
     if res:
         close(nchw(dres.cpu()), r.grad, what="bn dres")
+    if relu:      # same backward from the byte mask instead of y: identical bits
+        dg2, db2 = g(torch.zeros(c)), g(torch.zeros(c))
+        dx2, dres2 = ops.bn_train_bwd(g(nhwc(dy)), None, xd, g(gamma.detach()), mean, invstd, relu, dg2, db2, want_dres=res, accumulate=True, relu_mask=mask)
+        assert torch.equal(dx2, dxd) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+        if res:
+            assert torch.equal(dres2, dres)
 
 
 def test_pools_and_layout(dev):
