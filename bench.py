@@ -28,23 +28,30 @@ HBM_PEAK_GBS = 8000.0
 def conv_macs_resnet50(h, w, proj_dim=128):
     """Algorithmic MACs per VIEW: (conv fwd, conv bwd = dgrad + wgrad without the stem's dgrad, projector fwd)."""
     macs, first = [], True
+    io = []                                   # (input elements, output elements) per conv, for the algorithmic byte count
     ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
     macs.append(ho * wo * 64 * 49 * 3)
+    io.append((h * w * 3, ho * wo * 64))
     ho, wo = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
     cin = 64
     for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
         for b in range(blocks):
             s = stride if b == 0 else 1
             macs.append(ho * wo * planes * cin)                                   # conv1 1x1
+            io.append((ho * wo * cin, ho * wo * planes))
             h2, w2 = (ho + 2 - 3) // s + 1, (wo + 2 - 3) // s + 1
             macs.append(h2 * w2 * planes * planes * 9)                            # conv2 3x3 (stride here)
+            io.append((ho * wo * planes, h2 * w2 * planes))
             macs.append(h2 * w2 * planes * 4 * planes)                            # conv3 1x1
+            io.append((h2 * w2 * planes, h2 * w2 * planes * 4))
             if b == 0:
                 macs.append(h2 * w2 * planes * 4 * cin)                           # downsample 1x1
+                io.append((ho * wo * cin, h2 * w2 * planes * 4))
             cin, ho, wo = planes * 4, h2, w2
     fwd = sum(macs)
     bwd = 2 * fwd - macs[0]
     proj = 2048 * 2048 + 2048 * proj_dim
+    conv_macs_resnet50.algo_bytes_per_view = 4 * (3 * sum(i + o for i, o in io) - sum(io[0]))   # fwd + dgrad + wgrad, each operand once
     return fwd, bwd, proj
 
 
@@ -188,9 +195,18 @@ def main():
         conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
         conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
         ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; corrected as the guide prescribes)
+            with open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic_b%d.json" % b)) as fh:
+                pmc = json.load(fh)["per_step_gb"]
+            traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")), 1)
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "mfma", "kernel": "conv implicit-GEMM family (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
+                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/r01_c_pmc_hbm_traffic_b%d.json)" % b,
+                "algorithmic_gb_per_step": round(conv_macs_resnet50.algo_bytes_per_view * 2 * b / 1e9, 1),
+                "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
                 "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
                 "whole_step_mfma_frac": round(images_per_s / world * 2.0 * (fwd + bwd + 3 * proj) * 2 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

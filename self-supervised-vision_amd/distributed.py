@@ -41,8 +41,8 @@ def all_gather_rows(buf, rows_per_rank):
     """``buf`` is [world*rows_per_rank, ...] with this rank's block already in place; fill the rest."""
     if not is_on():
         return buf
-    mine = buf[rank() * rows_per_rank:(rank() + 1) * rows_per_rank]
-    dist.all_gather_into_tensor(buf, mine.clone() if buf.device.type == "cpu" else mine.contiguous())
+    mine = buf[rank() * rows_per_rank:(rank() + 1) * rows_per_rank].clone()      # input must not alias the output
+    dist.all_gather_into_tensor(buf, mine)
     return buf
 
 
