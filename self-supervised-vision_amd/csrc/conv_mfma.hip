@@ -576,7 +576,10 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // =============================================================================================
 // wgrad: partial[split][K][RSC] over a chunk of the N*Ho*Wo contraction
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VECB, bool LIN>
+// GATHER: 0 generic (fastdiv per staged row and tile), 1 LIN (1x1 / stride 1 / no padding: X row m is x + m*C),
+//         2 S1 (stride 1, any filter/padding: X row of tap (r,s) is x + (m + (r-pad)*W + (s-pad))*C, validity from
+//           (ho, wo) kept incrementally per staged row - no division in the loop)
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VECB, int GATHER>
 __global__ void __launch_bounds__(256)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -623,19 +626,49 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   int avoff[AP], bvoff[BP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) avoff[i] = acok ? ((arow + ARP * i) * p.K + i0 + acol) * 4 : OOB_OFF;
-  // LIN: 1x1 / stride 1 / no padding - row m of X is simply x + m*C
 #pragma unroll
   for (int i = 0; i < BP; ++i) bvoff[i] = jok ? ((brow + BRP * i) * p.C + cj) * 4 : OOB_OFF;
+  // S1 state: (ho, wo) of each staged row, byte offset of (row, tap shift, channel) relative to row 0 of the tile
+  int s1_ho[BP], s1_wo[BP], s1_base[BP];
+  const int s1_qw = BK / p.Wo, s1_rw = BK - s1_qw * p.Wo;
+  if constexpr (GATHER == 2) {
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const uint32_t mm = (uint32_t)min(ms + brow + BRP * i, p.M - 1);
+      const uint32_t n = fdiv(mm, p.dHoWo);
+      const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
+      s1_ho[i] = (int)fdiv(rem, p.dWo);
+      s1_wo[i] = (int)rem - s1_ho[i] * p.Wo;
+      s1_base[i] = ((brow + BRP * i + (rj - p.pad) * p.W + (sj - p.pad)) * p.C + cj) * 4;
+    }
+  }
   auto load_tile = [&]() {
     const int soff_a = mcur * p.K * 4;
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[i] = bload4(rdy, avoff[i], soff_a);
-    if constexpr (LIN) {
+    if constexpr (GATHER == 1) {
       const int soff_b = mcur * p.C * 4;
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         if constexpr (VECB) rbv[i] = bload4(rx, bvoff[i], soff_b);
         else rbs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, bvoff[i], soff_b, 0));
+      }
+    } else if constexpr (GATHER == 2) {
+      const int moff = mcur * p.C * 4;
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const int m = mcur + brow + BRP * i;
+        const bool ok = jok & (m < p.M) & ((unsigned)(s1_ho[i] + rj - p.pad) < (unsigned)p.H) & ((unsigned)(s1_wo[i] + sj - p.pad) < (unsigned)p.W);
+        const int off = ok ? s1_base[i] + moff : OOB_OFF;
+        if constexpr (VECB) rbv[i] = bload4(rx, off, 0);
+        else rbs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+        // advance (ho, wo) by BK output pixels: BK = qW*Wo + rW with a single carry, then wrap ho per image
+        int wo = s1_wo[i] + s1_rw;
+        const int carry = wo >= p.Wo ? 1 : 0;
+        wo -= carry ? p.Wo : 0;
+        int ho = s1_ho[i] + s1_qw + carry;
+        ho -= ho >= p.Ho ? p.Ho : 0;
+        s1_wo[i] = wo; s1_ho[i] = ho;
       }
     } else {
 #pragma unroll
@@ -863,18 +896,22 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   const int tiles = wp.it * wp.jt;
   const dim3 grid((unsigned)(tiles * wp.nsplit));
   float* part = (float*)ws;
-  const bool lin = d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1;
+  // gather mode of the X operand (see conv_wgrad_k): LIN, S1 (needs one carry per K-step: BK/Wo + 1 <= Ho, Ho == H, Wo == W) or generic
+  const bool s1ok = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && cfg.bk / d->Wo + 1 <= d->Ho;
+  const int gather = (d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1) ? 1 : (s1ok ? 2 : 0);
   if (!vecb) {
-    if (wp.bm == 128) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, GBK, false, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
-    else              hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, GBK, false, false, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+    if (wp.bm == 128) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, GBK, false, false, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+    else              hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, GBK, false, false, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
   } else if (wp.bm == 128) {
-#define CALL(B_, D_) do { if (lin) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
-                          else hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
+#define CALL(B_, D_) do { if (gather == 1) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, 1>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
+                          else if (gather == 2) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, 2>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
+                          else hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
     SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
 #undef CALL
   } else {
-#define CALL(B_, D_) do { if (lin) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
-                          else hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
+#define CALL(B_, D_) do { if (gather == 1) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, 1>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
+                          else if (gather == 2) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, 2>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
+                          else hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
     SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
 #undef CALL
   }
