@@ -30,9 +30,10 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        backend = os.environ.get("SSV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # one process per GPU; the modulo only matters for the single-GPU functional test of this path (gloo, 2 ranks on cuda:0)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
@@ -42,7 +43,10 @@ def all_gather_rows(buf, rows_per_rank):
     if not is_on():
         return buf
     mine = buf[rank() * rows_per_rank:(rank() + 1) * rows_per_rank].clone()      # input must not alias the output
-    dist.all_gather_into_tensor(buf, mine)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(buf, mine)                                   # one RCCL all-gather straight into place
+    else:
+        dist.all_gather([buf[r * rows_per_rank:(r + 1) * rows_per_rank] for r in range(world_size())], mine)
     return buf
 
 
