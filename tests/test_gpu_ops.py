@@ -319,3 +319,18 @@ def test_barlow_config_shape_matches_oracle(dev):
     np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
     close(zid.grad, a.grad, rtol=1e-3, what="dzi")
     close(zjd.grad, b.grad, rtol=1e-3, what="dzj")
+
+
+def test_ntxent_global_batch_4096(dev):
+    """BASELINE config 3 loss shape: N = 4096 per view (8192 x 8192 x 128 Gram), one rank computing every row."""
+    from ssv_amd.utils import losses
+    zi, zj = seeded_randn(91, 4096, 128), seeded_randn(92, 4096, 128)
+    a, b = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+    ref = oracle.ntxent_loss(a, b, True, 0.5)
+    ref.backward()
+    zid, zjd = zi.to(dev).requires_grad_(), zj.to(dev).requires_grad_()
+    loss = losses.SimclrLoss(True, 0.5)(zid, zjd)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    close(zid.grad, a.grad, rtol=5e-4, what="dzi")
+    close(zjd.grad, b.grad, rtol=5e-4, what="dzj")

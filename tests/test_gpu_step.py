@@ -328,3 +328,34 @@ def test_byol_r18_steps_match_reference(dev, golden):
             np.testing.assert_allclose(got[0], ref[0], rtol=1e-4, atol=(2e-2 if k.endswith("bias") else 1e-3) * (float(np.sqrt(ref[1])) + 1e-6), err_msg=k)
         elif "running" in k:
             np.testing.assert_allclose(got[1], ref[1], rtol=2e-3, err_msg=k)
+
+
+def test_bench_shape_r50_224_step0_matches_oracle(dev):
+    """The BENCH workload's own shape (ResNet-50, 7x7/2 stem, 224x224) at a small ragged batch: step-0 loss within
+    1e-4 relative and projected features within the CPU path's own fp64 distance (north-star bars)."""
+    b = 6
+    a1, a2 = seeded_randn(1000, b, 3, 224, 224), seeded_randn(1001, b, 3, 224, 224)
+    m = _Step(dev, "resnet50", False)
+    make = lambda: oracle.SimCLROracle("resnet50", False, 128, lr=0.2, weight_decay=1e-4)
+    o32, o64 = make(), _oracle64_like(make)
+    loss, z1, z2 = m.step(a1, a2, dual=True)
+    r32 = o32.train_step(a1, a2, return_z=True)
+    r64 = o64.train_step(a1.double(), a2.double(), return_z=True)
+    np.testing.assert_allclose(loss, r32["loss"], rtol=1e-4)
+    e_hip = float((z1.cpu().double() - r64["z_1"]).abs().max())
+    e_cpu = float((r32["z_1"].double() - r64["z_1"]).abs().max())
+    assert e_hip <= 3 * e_cpu + 1e-5, (e_hip, e_cpu)      # batch 6 feeds 6-sample BatchNorm1d columns: ill-conditioned for both
+    _check_grads(m, o32, flip_tol=1e-1)
+
+
+def test_ragged_last_batch(dev):
+    """50000 mod 512 = 336 in the reference's loader (last batch is not dropped): a batch that is no multiple of
+    any tile size must work and match."""
+    b = 21
+    a1, a2 = seeded_randn(1100, b, 3, 32, 32), seeded_randn(1101, b, 3, 32, 32)
+    m = _Step(dev, "resnet18", True)
+    o = oracle.SimCLROracle("resnet18", True, 128, lr=0.2, weight_decay=1e-4)
+    loss, z1, _ = m.step(a1, a2)
+    ref = o.train_step(a1, a2, return_z=True)
+    np.testing.assert_allclose(loss, ref["loss"], rtol=1e-5)
+    close(z1, ref["z_1"], rtol=1e-4, atol=1e-4, what="z_1")
