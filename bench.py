@@ -26,8 +26,9 @@ HBM_PEAK_GBS = 8000.0
 
 
 def conv_macs_resnet50(h, w, proj_dim=128):
-    """Algorithmic MACs per VIEW: (conv fwd, conv bwd = dgrad + wgrad without the stem's dgrad, projector fwd)."""
-    macs, first = [], True
+    """Algorithmic work per VIEW: MACs of (conv fwd, conv bwd = dgrad + wgrad without the stem's dgrad, projector fwd)
+    and the HBM bytes of the conv family when every operand is moved exactly once (fwd + dgrad + wgrad)."""
+    macs = []
     io = []                                   # (input elements, output elements) per conv, for the algorithmic byte count
     ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
     macs.append(ho * wo * 64 * 49 * 3)
@@ -51,8 +52,8 @@ def conv_macs_resnet50(h, w, proj_dim=128):
     fwd = sum(macs)
     bwd = 2 * fwd - macs[0]
     proj = 2048 * 2048 + 2048 * proj_dim
-    conv_macs_resnet50.algo_bytes_per_view = 4 * (3 * sum(i + o for i, o in io) - sum(io[0]))   # fwd + dgrad + wgrad, each operand once
-    return fwd, bwd, proj
+    algo_bytes = 4 * (3 * sum(i + o for i, o in io) - sum(io[0]))   # fwd + dgrad + wgrad, each operand once; no stem dgrad
+    return fwd, bwd, proj, algo_bytes
 
 
 def build(device, batch):
@@ -146,12 +147,11 @@ def main():
     tf = augmentations.get_transform(cfg)
     counter = [0]
 
-    def step(_a=None, _b=None):
+    def step():
         params = tf.draw(source, sample_ids, counter[0])          # RNG keyed by the GLOBAL sample id
         views = tf.apply(source, rows, params)
         counter[0] += 1
         return train_step(views[0], views[1])
-    v1 = v2 = None
 
     def barrier():
         if world > 1:
@@ -160,11 +160,11 @@ def main():
 
     loss = None
     for _ in range(args.warmup):
-        loss = step(v1, v2)
+        loss = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(v1, v2)
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -175,7 +175,7 @@ def main():
     images_per_s = b * world * args.steps / dt
 
     # ---- per-kernel-class timing (HIP events on the launch stream) over extra instrumented steps --------------
-    fwd, bwd, proj = conv_macs_resnet50(s, s)
+    fwd, bwd, proj, algo_bytes = conv_macs_resnet50(s, s)
     conv_flop_step = 2.0 * (fwd + bwd + 3 * proj) * 2 * b                     # per GPU: 2 FLOP/MAC, 2 views
     roof, classes = None, {}
     if args.prof_steps > 0:
@@ -186,7 +186,7 @@ def main():
         _lib.prof_enable(True)
         _lib.prof_reset()
         for _ in range(args.prof_steps):
-            step(v1, v2)
+            step()
         torch.cuda.synchronize()
         prof = _lib.prof_collect()
         _lib.prof_enable(False)
@@ -205,7 +205,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "conv implicit-GEMM family (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/r01_c_pmc_hbm_traffic_b%d.json)" % b,
-                "algorithmic_gb_per_step": round(conv_macs_resnet50.algo_bytes_per_view * 2 * b / 1e9, 1),
+                "algorithmic_gb_per_step": round(algo_bytes * 2 * b / 1e9, 1),
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
                 "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
