@@ -268,6 +268,42 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
   }
 }
 
+// Vectorised epilogue: a wave's accumulators hold one COLUMN per lane (32 consecutive columns per 32x32 tile), so a direct
+// store is 4 bytes per lane and 16*TM*TN instructions.  Staging 32-row slabs of the wave's tile through its own LDS
+// region turns that into 16-byte-per-lane stores of whole 256-byte row segments (4x fewer store instructions, and the
+// bias / residual addend are read 16 bytes per lane too).  LDS traffic of one wave is in order, so no barrier is needed
+// inside; the caller has passed the barrier that ends the K loop.  row_off(r) gives the element offset of output row r of
+// the wave tile, or -1.
+template <int TM, int TN, class RowOff>
+__device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
+                                             const float* __restrict__ bias, const float* addend, float* out, RowOff&& row_off) {
+  constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int r_in = lane / C4, c4 = lane % C4;
+  const int gcol = col0 + c4 * 4;
+  const bool cok = gcol < ncols;
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias && cok) b4 = *reinterpret_cast<const f32x4*>(bias + gcol);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int r = q * RPI + r_in;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&ep[r * LDE + c4 * 4]);
+      const long long off = row_off(tm * 32 + r);
+      if (off >= 0 && cok) {
+        v += b4;
+        if (addend) v += *reinterpret_cast<const f32x4*>(addend + off + gcol);
+        *reinterpret_cast<f32x4*>(out + off + gcol) = v;
+      }
+    }
+  }
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -412,6 +448,15 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   }
 
   // ---- epilogue: acc reg j of lane l is (row (j&3)+8*(j>>2)+4*(l>>5), col l&31) of its 32x32 tile ----
+  constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
+  if constexpr (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE) {
+    if ((p.K & 3) == 0) {             // 16-byte stores need K % 4 == 0 (uniform): whole rows segments through LDS
+      const int rbase = m0 + wr0;
+      epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; });
+      return;
+    }
+  }
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -552,6 +597,12 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   };
   k_loop<TM, TN, true, false, LDT, BN, BK, STAGE, DB, AP + BP>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
+  constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
+  if constexpr (EP_FLOATS <= (DB ? 2 : 1) * STAGE) {       // C % 4 == 0 is a precondition of this kernel
+    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
+                         [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; });
+    return;
+  }
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -774,7 +825,7 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
   const int RSC = d->R * d->S * d->C;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   w.bm = d->K >= 128 ? 128 : 64;
-  w.bn = 128;
+  w.bn = RSC <= 64 ? 64 : 128;              // 1x1 convs on 64 channels: a 128-wide tile would be half empty
   w.it = cdiv(d->K, w.bm);
   w.jt = cdiv(RSC, w.bn);
   const int tiles = w.it * w.jt;
@@ -899,22 +950,28 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   // gather mode of the X operand (see conv_wgrad_k): LIN, S1 (needs one carry per K-step: BK/Wo + 1 <= Ho, Ho == H, Wo == W) or generic
   const bool s1ok = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && cfg.bk / d->Wo + 1 <= d->Ho;
   const int gather = (d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1) ? 1 : (s1ok ? 2 : 0);
+#define WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, V_, G_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, B_, D_, V_, G_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define WG_GATHER(BM_, BN_, WM_, WN_, B_, D_) \
+  do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, true, 1); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, true, 2); \
+       else WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, true, 0); } while (0)
   if (!vecb) {
-    if (wp.bm == 128) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, GBK, false, false, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
-    else              hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, GBK, false, false, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles);
+    if (wp.bm == 128) WG_LAUNCH(128, 128, 2, 2, GBK, false, false, 0);
+    else              WG_LAUNCH(64, 128, 1, 4, GBK, false, false, 0);
+  } else if (wp.bn == 64) {                       // RSC <= 64 (and C % 4 == 0): 64-wide column tile
+    if (wp.bm == 128) { if (cfg.bk == 32) WG_GATHER(128, 64, 2, 2, 32, false); else WG_GATHER(128, 64, 2, 2, 16, false); }
+    else              { if (cfg.bk == 32) WG_GATHER(64, 64, 2, 2, 32, false); else WG_GATHER(64, 64, 2, 2, 16, false); }
   } else if (wp.bm == 128) {
-#define CALL(B_, D_) do { if (gather == 1) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, 1>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
-                          else if (gather == 2) hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, 2>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
-                          else hipLaunchKernelGGL((conv_wgrad_k<128, 128, 2, 2, B_, D_, true, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
+#define CALL(B_, D_) WG_GATHER(128, 128, 2, 2, B_, D_)
     SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
 #undef CALL
   } else {
-#define CALL(B_, D_) do { if (gather == 1) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, 1>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
-                          else if (gather == 2) hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, 2>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); \
-                          else hipLaunchKernelGGL((conv_wgrad_k<64, 128, 1, 4, B_, D_, true, 0>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles); } while (0)
+#define CALL(B_, D_) WG_GATHER(64, 128, 1, 4, B_, D_)
     SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
 #undef CALL
   }
+#undef WG_GATHER
+#undef WG_LAUNCH
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(partial)");
   const int64_t n = (int64_t)d->K * p.RSC;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, accumulate);
