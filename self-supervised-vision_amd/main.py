@@ -1,63 +1,67 @@
-"""Command line of the accelerated path - the reference's flags and choices, verbatim
-(main.py:11-12,38-43): -c/--config -m/--arch -a/--algo -t/--task [-o/--output] [-l/--load].
+"""Command line of the accelerated path.
 
-Algorithms outside the accelerated two-view path (moco, dino, pirl, simsiam, relic, deep_cluster,
-swav, sela) and the ViT encoder stay on the flag surface but raise NotImplementedError.
-Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`.
+The flag surface is the reference's (main.py:11-12,38-43), verbatim: -c/--config, -m/--arch, -a/--algo, -t/--task,
+-o/--output, -l/--load with the same choices, so scripts written for the reference keep working.  Algorithms outside the
+accelerated two-view path (moco, dino, pirl, simsiam, relic, deep_cluster, swav, sela) and the ViT encoder stay on the
+surface and raise NotImplementedError.  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N main.py ...`.
 """
 import argparse
+import importlib
 import os
-from datetime import datetime as dt
+import time
 
 import numpy as np
 
-TASKS = ["train", "linear_eval", "get_features"]
-NETWORKS = ["resnet18", "resnet50", "resnext50", "resnext101", "wide_resnet50", "wide_resnet101", "vit"]
-ACCELERATED = ("simclr", "byol", "barlow")
-ALGO_NAMES = ["simclr", "moco", "byol", "dino", "pirl", "barlow", "simsiam", "relic", "deep_cluster", "swav", "sela"]
+TASKS = ("train", "linear_eval", "get_features")
+NETWORKS = ("resnet18", "resnet50", "resnext50", "resnext101", "wide_resnet50", "wide_resnet101", "vit")
+# algo -> (module, class) for what is built; None marks flag values that exist but are not accelerated
+ALGORITHMS = {"simclr": ("simclr", "SimCLR"), "moco": None, "byol": ("byol", "BYOL"), "dino": None, "pirl": None,
+              "barlow": ("barlow", "BarlowTwins"), "simsiam": None, "relic": None, "deep_cluster": None, "swav": None, "sela": None}
+
+_FLAGS = (
+    ("-c", "--config", dict(required=True, help="YAML configuration file")),
+    ("-m", "--arch", dict(required=True, choices=NETWORKS, help="encoder architecture")),
+    ("-a", "--algo", dict(required=True, choices=tuple(ALGORITHMS), help="self-supervised algorithm")),
+    ("-t", "--task", dict(required=True, choices=TASKS, help="what to run")),
+    ("-o", "--output", dict(default=None, help="name of the output directory (default: a timestamp)")),
+    ("-l", "--load", dict(default=None, help="directory holding a best_model.pt to load")),
+)
 
 
-def _trainer(algo):
-    if algo == "simclr":
-        from .models.simclr import SimCLR as cls
-    elif algo == "byol":
-        from .models.byol import BYOL as cls
-    elif algo == "barlow":
-        from .models.barlow import BarlowTwins as cls
-    else:
-        raise NotImplementedError(f"--algo {algo} is not on the accelerated path (built: {', '.join(ACCELERATED)})")
-    return cls
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for short, long_, kw in _FLAGS:
+        ap.add_argument(short, long_, type=str, **kw)
+    args = vars(ap.parse_args(argv))
+    if args["output"] is None:
+        args["output"] = time.strftime("%d-%m-%Y_%H-%M")
+    return args
 
 
-def _require_checkpoint(args):
-    if args["load"] is None:
-        raise NotImplementedError("For inference tasks, model checkpoint must be specified using --load")
+def trainer_class(algo):
+    entry = ALGORITHMS[algo]
+    if entry is None:
+        built = ", ".join(k for k, v in ALGORITHMS.items() if v)
+        raise NotImplementedError(f"--algo {algo} is not on the accelerated path (built: {built})")
+    module, name = entry
+    return getattr(importlib.import_module(f"{__package__}.models.{module}"), name)
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-c", "--config", required=True, type=str, help="Path to configuration file")
-    ap.add_argument("-m", "--arch", required=True, type=str, choices=NETWORKS, help="Encoder architecture to use")
-    ap.add_argument("-a", "--algo", required=True, type=str, choices=ALGO_NAMES, help="Self-supervised algorithm to work with")
-    ap.add_argument("-t", "--task", required=True, type=str, choices=TASKS, help="Task to perform for chosen algorithm")
-    ap.add_argument("-o", "--output", default=dt.now().strftime("%d-%m-%Y_%H-%M"), type=str, help="Path to output directory")
-    ap.add_argument("-l", "--load", default=None, type=str, help="Path to directory containing trained checkpoints to be loaded")
-    args = vars(ap.parse_args(argv))
+    args = parse(argv)
     if args["arch"] == "vit":
         raise NotImplementedError("--arch vit belongs to DINO, which is not on the accelerated path yet")
-
-    model = _trainer(args["algo"])(args=args)
-    task = args["task"]
-    if task == "train":
+    if args["task"] != "train" and args["load"] is None:
+        raise NotImplementedError("For inference tasks, model checkpoint must be specified using --load")
+    model = trainer_class(args["algo"])(args=args)
+    if args["task"] == "train":
         model.train()
-    elif task == "linear_eval":
-        _require_checkpoint(args)
+    elif args["task"] == "linear_eval":
         model.perform_linear_eval()
-    elif task == "get_features":
-        _require_checkpoint(args)
+    else:   # get_features: <split>_fvecs.npy / <split>_gt.npy in the run directory (binary files; the reference opens them in text mode)
         for split in ("train", "test"):
             fvecs, gt = model.build_features(split=split)
-            np.save(os.path.join(model.output_dir, f"{split}_fvecs.npy"), fvecs)      # binary mode (the reference opens "w")
+            np.save(os.path.join(model.output_dir, f"{split}_fvecs.npy"), fvecs)
             np.save(os.path.join(model.output_dir, f"{split}_gt.npy"), gt)
     return model
 

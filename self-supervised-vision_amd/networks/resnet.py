@@ -30,94 +30,96 @@ class _Downsample(nn.Sequential):
         super().__init__(_fresh_conv(cin, cout, 1, stride, 0), hnn.HipBatchNorm(cout))
 
 
-class BasicBlock(hnn.HipModule):
+class _ResidualUnit(hnn.HipModule):
+    """conv/BN chain described by `plan(in, planes, stride, base_width) -> [(cin, cout, k, stride, pad), ...]`, registered as
+    conv1/bn1 .. convN/bnN; the last BN kernel also adds the shortcut and applies the closing ReLU."""
     expansion = 1
 
+    @staticmethod
+    def plan(cin, planes, stride, base_width):
+        raise NotImplementedError
+
     def __init__(self, in_planes, planes, stride=1, downsample=None, base_width=64):
         super().__init__()
+        specs = self.plan(in_planes, planes, stride, base_width)
+        self.depth = len(specs)
+        for i, spec in enumerate(specs, start=1):
+            setattr(self, f"conv{i}", _fresh_conv(*spec))
+            setattr(self, f"bn{i}", hnn.HipBatchNorm(spec[1]))
+        self.downsample = downsample
+
+    def last_bn(self):
+        return getattr(self, f"bn{self.depth}")
+
+    def _run(self, tape, x):
+        shortcut = x if self.downsample is None else hnn.batchnorm(tape, self.downsample[0]._run(tape, x), self.downsample[1])
+        h = x
+        for i in range(1, self.depth + 1):
+            h = getattr(self, f"conv{i}")._run(tape, h)
+            closing = i == self.depth
+            h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None)
+        return h
+
+
+class BasicBlock(_ResidualUnit):
+    @staticmethod
+    def plan(cin, planes, stride, base_width):
         if base_width != 64:
             raise ValueError("BasicBlock only supports base_width = 64")
-        self.conv1 = _fresh_conv(in_planes, planes, 3, stride, 1)
-        self.bn1 = hnn.HipBatchNorm(planes)
-        self.conv2 = _fresh_conv(planes, planes, 3, 1, 1)
-        self.bn2 = hnn.HipBatchNorm(planes)
-        self.downsample = downsample
-
-    def _run(self, tape, x):
-        out = hnn.batchnorm(tape, self.conv1._run(tape, x), self.bn1, relu=True)
-        out = self.conv2._run(tape, out)
-        identity = x
-        if self.downsample is not None:
-            identity = hnn.batchnorm(tape, self.downsample[0]._run(tape, x), self.downsample[1])
-        return hnn.batchnorm(tape, out, self.bn2, relu=True, residual=identity)
+        return [(cin, planes, 3, stride, 1), (planes, planes, 3, 1, 1)]
 
 
-class Bottleneck(hnn.HipModule):
+class Bottleneck(_ResidualUnit):
     expansion = 4
 
-    def __init__(self, in_planes, planes, stride=1, downsample=None, base_width=64):
-        super().__init__()
-        width = int(planes * base_width / 64)
-        self.conv1 = _fresh_conv(in_planes, width, 1, 1, 0)
-        self.bn1 = hnn.HipBatchNorm(width)
-        self.conv2 = _fresh_conv(width, width, 3, stride, 1)       # stride sits on the 3x3
-        self.bn2 = hnn.HipBatchNorm(width)
-        self.conv3 = _fresh_conv(width, planes * 4, 1, 1, 0)
-        self.bn3 = hnn.HipBatchNorm(planes * 4)
-        self.downsample = downsample
+    @staticmethod
+    def plan(cin, planes, stride, base_width):
+        mid = planes * base_width // 64
+        return [(cin, mid, 1, 1, 0), (mid, mid, 3, stride, 1), (mid, 4 * planes, 1, 1, 0)]      # stride sits on the 3x3
 
-    def _run(self, tape, x):
-        out = hnn.batchnorm(tape, self.conv1._run(tape, x), self.bn1, relu=True)
-        out = hnn.batchnorm(tape, self.conv2._run(tape, out), self.bn2, relu=True)
-        out = self.conv3._run(tape, out)
-        identity = x
-        if self.downsample is not None:
-            identity = hnn.batchnorm(tape, self.downsample[0]._run(tape, x), self.downsample[1])
-        return hnn.batchnorm(tape, out, self.bn3, relu=True, residual=identity)
+
+_STAGE_PLANES = (64, 128, 256, 512)
+_UNSUPPORTED = {"groups": (1,), "replace_stride_with_dilation": (None, [False] * 3, (False,) * 3), "norm_layer": (None,)}
 
 
 class ResNet(hnn.HipModule):
-    """forward(img [B,3,H,W] fp32, NCHW or channels_last) -> features [B, 512*expansion]."""
+    """forward(img [B,3,H,W] fp32, NCHW or channels_last) -> features [B, 512*expansion].  Keyword surface of the
+    reference constructor; grouped / dilated / custom-norm variants are refused rather than silently computed differently."""
 
     def __init__(self, block, layers, num_classes=10, zero_init_residual=False, groups=1, width_per_group=64,
                  replace_stride_with_dilation=None, norm_layer=None, reduce_bottom_conv=False):
         super().__init__()
-        if groups != 1:
-            raise NotImplementedError("grouped convolutions (resnext) are outside the accelerated path")
-        if replace_stride_with_dilation not in (None, [False, False, False], (False, False, False)):
-            raise NotImplementedError("dilated ResNets are outside the accelerated path")
-        if norm_layer is not None:
-            raise NotImplementedError("custom norm layers are outside the accelerated path")
-        self.in_planes, self.base_width = 64, width_per_group
-        self.conv1 = _fresh_conv(3, 64, 3, 1, 1) if reduce_bottom_conv else _fresh_conv(3, 64, 7, 2, 3)
-        self.bn1 = hnn.HipBatchNorm(64)
-        self.layer1 = self._make_layer(block, 64, layers[0], 1)
-        self.layer2 = self._make_layer(block, 128, layers[1], 2)
-        self.layer3 = self._make_layer(block, 256, layers[2], 2)
-        self.layer4 = self._make_layer(block, 512, layers[3], 2)
-        self.out_dim = 512 * block.expansion
-        # second pass of the reference ctor: every conv re-drawn with kaiming_normal_(fan_out, relu)
+        given = dict(groups=groups, replace_stride_with_dilation=replace_stride_with_dilation, norm_layer=norm_layer)
+        for key, allowed in _UNSUPPORTED.items():
+            if given[key] not in allowed:
+                raise NotImplementedError(f"{key}={given[key]!r} is outside the accelerated path")
+        stem = (3, 64, 3, 1, 1) if reduce_bottom_conv else (3, 64, 7, 2, 3)
+        self.conv1, self.bn1 = _fresh_conv(*stem), hnn.HipBatchNorm(64)
+        cin = 64
+        for idx, (planes, depth) in enumerate(zip(_STAGE_PLANES, layers), start=1):
+            stage, cin = self._stage(block, cin, planes, depth, 1 if idx == 1 else 2, width_per_group)
+            setattr(self, f"layer{idx}", stage)
+        self.out_dim = cin
+        self._reference_init(zero_init_residual)
+
+    @staticmethod
+    def _stage(block, cin, planes, depth, stride, base_width):
+        cout = planes * block.expansion
+        # the projection shortcut is constructed (and its weights drawn) BEFORE the unit's own convs
+        shortcut = _Downsample(cin, cout, stride) if (stride != 1 or cin != cout) else None
+        units = [block(cin, planes, stride, shortcut, base_width)]
+        units += [block(cout, planes, base_width=base_width) for _ in range(depth - 1)]
+        return nn.Sequential(*units), cout
+
+    def _reference_init(self, zero_init_residual):
+        """Second pass of the reference ctor: every conv re-drawn with kaiming_normal_(fan_out, relu) in modules() order."""
         for m in self.modules():
             if isinstance(m, hnn.HipConv2d):
                 w = torch.empty(m.weight.shape)              # draw on a contiguous tensor, like nn.Conv2d.weight
                 nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
                 m.weight.data = w.contiguous(memory_format=torch.channels_last)
-        if zero_init_residual:
-            for m in self.modules():
-                if isinstance(m, Bottleneck):
-                    nn.init.constant_(m.bn3.weight, 0)
-                elif isinstance(m, BasicBlock):
-                    nn.init.constant_(m.bn2.weight, 0)
-
-    def _make_layer(self, block, planes, blocks, stride):
-        downsample = None
-        if stride != 1 or self.in_planes != planes * block.expansion:
-            downsample = _Downsample(self.in_planes, planes * block.expansion, stride)   # drawn BEFORE the block's convs
-        layers = [block(self.in_planes, planes, stride, downsample, self.base_width)]
-        self.in_planes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.in_planes, planes, base_width=self.base_width))
-        return nn.Sequential(*layers)
+            elif zero_init_residual and isinstance(m, _ResidualUnit):
+                nn.init.zeros_(m.last_bn().weight)
 
     def _prepare_input(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
@@ -126,45 +128,37 @@ class ResNet(hnn.HipModule):
         return ops.nchw_to_nhwc(x)
 
     def _run(self, tape, x):
-        x = hnn.batchnorm(tape, self.conv1._run(tape, x), self.bn1, relu=True)
-        x = hnn.maxpool(tape, x)
-        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in stage:
-                x = blk._run(tape, x)
+        x = hnn.maxpool(tape, hnn.batchnorm(tape, self.conv1._run(tape, x), self.bn1, relu=True))
+        for idx in range(1, len(_STAGE_PLANES) + 1):
+            for unit in getattr(self, f"layer{idx}"):
+                x = unit._run(tape, x)
         return hnn.global_avgpool(tape, x)
 
 
-def resnet18(**kwargs):
-    return ResNet(BasicBlock, [2, 2, 2, 2], **kwargs)
+# name -> (unit, units per stage, fixed constructor keywords); resnext rows exist so the reference names resolve and then refuse
+_ZOO = {
+    "resnet18": (BasicBlock, (2, 2, 2, 2), {}),
+    "resnet34": (BasicBlock, (3, 4, 6, 3), {}),
+    "resnet50": (Bottleneck, (3, 4, 6, 3), {}),
+    "resnet101": (Bottleneck, (3, 4, 23, 3), {}),
+    "resnet152": (Bottleneck, (3, 8, 36, 3), {}),
+    "resnext50_32x4d": (Bottleneck, (3, 4, 6, 3), dict(groups=32, width_per_group=4)),
+    "resnext101_32x8d": (Bottleneck, (3, 4, 23, 3), dict(groups=32, width_per_group=8)),
+    "wide_resnet50_2": (Bottleneck, (3, 4, 6, 3), dict(width_per_group=128)),
+    "wide_resnet101_2": (Bottleneck, (3, 4, 23, 3), dict(width_per_group=128)),
+}
 
 
-def resnet34(**kwargs):
-    return ResNet(BasicBlock, [3, 4, 6, 3], **kwargs)
+def _register(name):
+    unit, depths, fixed = _ZOO[name]
+
+    def build(**kwargs):
+        return ResNet(unit, list(depths), **{**kwargs, **fixed})
+    build.__name__ = build.__qualname__ = name
+    build.__doc__ = f"{name} encoder (reference networks/resnet.py factory of the same name)."
+    return build
 
 
-def resnet50(**kwargs):
-    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)
-
-
-def resnet101(**kwargs):
-    return ResNet(Bottleneck, [3, 4, 23, 3], **kwargs)
-
-
-def resnet152(**kwargs):
-    return ResNet(Bottleneck, [3, 8, 36, 3], **kwargs)
-
-
-def resnext50_32x4d(**kwargs):
-    return ResNet(Bottleneck, [3, 4, 6, 3], groups=32, width_per_group=4, **kwargs)
-
-
-def resnext101_32x8d(**kwargs):
-    return ResNet(Bottleneck, [3, 4, 23, 3], groups=32, width_per_group=8, **kwargs)
-
-
-def wide_resnet50_2(**kwargs):
-    return ResNet(Bottleneck, [3, 4, 6, 3], width_per_group=128, **kwargs)
-
-
-def wide_resnet101_2(**kwargs):
-    return ResNet(Bottleneck, [3, 4, 23, 3], width_per_group=128, **kwargs)
+for _name in _ZOO:
+    globals()[_name] = _register(_name)
+del _name

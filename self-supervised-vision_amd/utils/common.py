@@ -1,55 +1,63 @@
-"""Experiment plumbing with the reference's behaviour (utils/common.py): seed 420, YAML config,
-output directory with trainlogs.txt + hyperparameters.txt, running-mean meter, progress bar."""
-import logging
+"""Experiment plumbing around the accelerated path.
+
+Behavioural contract taken from the reference (utils/common.py): seed 420 everywhere, the YAML config is loaded
+as nested dicts and echoed to stdout, every run owns outputs/<algo>/<arch>/<name>/ with ``trainlogs.txt`` and
+``hyperparameters.txt``; meters report running means as ``[key] value`` pairs; the progress line is redrawn in place.
+Written independently: meters keep running sums, the logger owns its file handle, and there is no CPU device - the
+path needs the GPU and says so.
+"""
 import os
 import random
+import sys
+import time
 
 import numpy as np
 import torch
 import yaml
 
-_C = {"yellow": "\x1b[33m", "blue": "\x1b[94m", "green": "\x1b[32m", "end": "\033[0m"}
+_ANSI = dict(info="\x1b[33m", val="\x1b[94m", bar="\x1b[32m", off="\033[0m")
+_TAGS = dict(info="[INFO] ", train="[TRAIN] ", val="[VALID] ")
 
 
 class AverageMeter:
+    """Running mean per metric name."""
+
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.metrics = {}
+        self._sum, self._n = {}, {}
 
     def add(self, metrics):
-        for key, value in metrics.items():
-            self.metrics.setdefault(key, []).append(value)
+        for name, value in metrics.items():
+            self._sum[name] = self._sum.get(name, 0.0) + float(value)
+            self._n[name] = self._n.get(name, 0) + 1
+
+    @property
+    def metrics(self):
+        return {k: self._sum[k] / self._n[k] for k in self._sum}
 
     def return_dict(self):
-        return {key: np.mean(value) for key, value in self.metrics.items()}
+        return self.metrics
 
     def return_msg(self):
-        return "".join("[{}] {:.4f} ".format(k, v) for k, v in self.return_dict().items())
+        return "".join(f"[{k}] {v:.4f} " for k, v in self.metrics.items())
 
 
 class Logger:
-    _PREFIX = {"info": "[INFO] ", "train": "[TRAIN] ", "val": "[VALID] "}
+    """Tagged lines to <output_dir>/trainlogs.txt (write) and / or the terminal (print); record does both."""
 
     def __init__(self, output_dir):
-        for handler in logging.root.handlers[:]:
-            logging.root.removeHandler(handler)
-        logging.basicConfig(level=logging.INFO, format="%(message)s",
-                            handlers=[logging.FileHandler(os.path.join(output_dir, "trainlogs.txt"))])
+        self._fh = open(os.path.join(output_dir, "trainlogs.txt"), "a", buffering=1)
 
     def print(self, msg, mode=""):
-        if mode == "info":
-            print(f"{_C['yellow']}[INFO] {msg}{_C['end']}")
-        elif mode == "train":
-            print(f"[TRAIN] {msg}")
-        elif mode == "val":
-            print(f"{_C['blue']}[VALID] {msg}{_C['end']}")
-        else:
-            print(f"{msg}")
+        tag = _TAGS.get(mode, "")
+        colour = _ANSI.get(mode)
+        line = f"{tag}{msg}"
+        sys.stdout.write((f"{colour}{line}{_ANSI['off']}" if colour else line) + "\n")
 
     def write(self, msg, mode):
-        logging.info(self._PREFIX.get(mode, "") + str(msg))
+        self._fh.write(f"{_TAGS.get(mode, '')}{msg}\n")
 
     def record(self, msg, mode):
         self.print(msg, mode)
@@ -61,45 +69,43 @@ def count_parameters(model):
 
 
 def progress_bar(progress=0, desc="Progress", status="", barlen=20):
-    status = status.ljust(30)
-    filled = int(round(barlen * progress))
-    bar = _C["green"] + "=" * (filled - 1) + ">" + _C["end"] + " " * (barlen - filled)
-    print("\r{}: [{}] {:.2f}% {}".format(desc, bar, progress * 100, status), end="")
+    done = int(round(barlen * progress))
+    arrow = "=" * max(done - 1, 0) + ">"
+    sys.stdout.write("\r{}: [{}{}{}{}] {:.2f}% {}".format(desc, _ANSI["bar"], arrow, _ANSI["off"], " " * (barlen - done),
+                                                       100.0 * progress, status.ljust(30)))
+    sys.stdout.flush()
 
 
 def open_config(file):
-    with open(file, "r") as f:
-        return yaml.safe_load(f)
+    with open(file) as fh:
+        return yaml.safe_load(fh)
 
 
 def seed_everything(seed=420):
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
 
 
 def initialize_experiment(args, output_root, seed=420):
-    """Returns (config, output_dir, logger, device).  Unlike the reference there is no CPU device:
-    the accelerated path needs the GPU and says so."""
-    seed_everything(seed)
-    config = open_config(args["config"])
-    output_dir = os.path.join(output_root, args["output"])
-    os.makedirs(output_dir, exist_ok=True)
-    logger = Logger(output_dir)
-    logger.print("Logging at {}".format(output_dir), mode="info")
-    logger.print("-" * 40)
-    logger.print("{:>20}".format("Configuration"))
-    logger.print("-" * 40)
-    logger.print(yaml.dump(config))
-    logger.print("-" * 40)
-    with open(os.path.join(output_dir, "hyperparameters.txt"), "w") as f:
-        f.write(yaml.dump(config))
+    """-> (config, output_dir, logger, device); initialises the process group first when launched by torch.distributed.run."""
     if not torch.cuda.is_available():
         raise RuntimeError("self-supervised-vision_amd needs an AMD GPU (MI355X): no HIP device is visible and there is no CPU fallback")
     from .. import distributed as hdist
     hdist.init_from_env()
+    seed_everything(seed)
+    config = open_config(args["config"])
+    output_dir = os.path.join(output_root, args["output"])
+    os.makedirs(output_dir, exist_ok=True)
+    dumped = yaml.dump(config)
+    with open(os.path.join(output_dir, "hyperparameters.txt"), "w") as fh:
+        fh.write(dumped)
+    logger = Logger(output_dir)
+    rule = "-" * 40
+    logger.print(f"Logging at {output_dir}", mode="info")
+    for line in (rule, "{:>20}".format("Configuration"), rule, dumped, rule):
+        logger.print(line)
     device = torch.device("cuda", torch.cuda.current_device())
-    logger.print("Found GPU device: {}".format(torch.cuda.get_device_name(device)), mode="info")
+    logger.print(f"Found GPU device: {torch.cuda.get_device_name(device)} ({time.strftime('%Y-%m-%d %H:%M:%S')})", mode="info")
     return config, output_dir, logger, device
