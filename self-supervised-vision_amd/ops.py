@@ -197,3 +197,25 @@ def ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_temp, gscale):
     dz = _empty((2 * b, zall.shape[1]), zall)
     call("ssv_ntxent_bwd", nglob, b, seg0, zall.shape[1], ptr(zall), ptr(lse_all), float(inv_temp), float(gscale), ptr(dz), stream())
     return dz
+
+
+def mse_pair(o1, o2, t1, t2, scale):
+    """loss = scale * (|o1 - t2|^2 + |o2 - t1|^2) summed over all elements; returns (loss 0-d, dloss/do1, dloss/do2)."""
+    _lib._dev(o1, o2, t1, t2)
+    n = o1.numel()
+    do1, do2 = torch.empty_like(o1), torch.empty_like(o2)
+    loss = torch.empty((), dtype=torch.float32, device=o1.device)
+    ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(n), o1.device)
+    call("ssv_mse_pair_fwd_bwd", n, ptr(o1), ptr(o2), ptr(t1), ptr(t2), float(scale), ptr(loss), ptr(do1), ptr(do2), ptr(ws), ws.numel(), stream())
+    return loss, do1, do2
+
+
+def barlow_cgrad(craw, inv_b, lmbda):
+    """C = craw * inv_b; loss = sum_ii (C-1)^2 + lmbda * sum_{i!=j} C^2; returns (loss 0-d, G = dloss/dcraw [D,D])."""
+    _lib._dev(craw)
+    d = craw.shape[0]
+    g = torch.empty_like(craw)
+    loss = torch.empty((), dtype=torch.float32, device=craw.device)
+    ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(d * d), craw.device)
+    call("ssv_barlow_cgrad", d, ptr(craw), float(inv_b), float(lmbda), ptr(loss), ptr(g), ptr(ws), ws.numel(), stream())
+    return loss, g

@@ -76,17 +76,14 @@ class SimclrLoss(nn.Module):
 
 
 class _MSEPairFn(torch.autograd.Function):
+    """Data parallel: the mean runs over the GLOBAL batch (scale 1/(B_local*world*D)) and the scalar is all-reduced, so the
+    SUM of per-rank parameter gradients is the large-batch gradient - the same convention as the other two losses."""
+
     @staticmethod
     def forward(ctx, o1, o2, t1, t2):
-        if not o1.is_cuda:
-            raise _lib.SsvError("BYOL loss: the HIP path needs device tensors; there is no CPU fallback")
         o1c, o2c, t1c, t2c = (t.detach().contiguous() for t in (o1, o2, t1, t2))
-        n = o1c.numel()
-        do1, do2 = torch.empty_like(o1c), torch.empty_like(o2c)
-        loss = torch.empty((), dtype=torch.float32, device=o1.device)
-        ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(n), o1.device)
-        _lib.call("ssv_mse_pair_fwd_bwd", n, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(t1c), _lib.ptr(t2c), 1.0 / n,
-                  _lib.ptr(loss), _lib.ptr(do1), _lib.ptr(do2), _lib.ptr(ws), ws.numel(), _lib.stream())
+        loss, do1, do2 = ops.mse_pair(o1c, o2c, t1c, t2c, 1.0 / (o1c.numel() * hdist.world_size()))
+        hdist.all_reduce_sum(loss)
         ctx.saved = (do1, do2)
         return loss
 
@@ -112,8 +109,6 @@ class _BarlowFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, zi, zj, normalize, lmbda):
-        if not zi.is_cuda:
-            raise _lib.SsvError("BarlowLoss: the HIP path needs device tensors; there is no CPU fallback")
         bl, d = zi.shape
         if d % 16:
             raise _lib.SsvError(f"BarlowLoss: projection dim must be a multiple of 16 (got {d})")
@@ -140,10 +135,7 @@ class _BarlowFn(torch.autograd.Function):
             stats.append((mean, invstd))
         craw = torch.empty((d, d), dtype=torch.float32, device=dev)
         ops.conv2d_wgrad(hats[1].view(b, 1, 1, d), hats[0].view(b, 1, 1, d), craw, craw, accumulate=False)   # craw[i][j] = sum_b zi_hat[b,i] zj_hat[b,j]
-        g = torch.empty((d, d), dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(d * d), dev)
-        _lib.call("ssv_barlow_cgrad", d, _lib.ptr(craw), 1.0 / b, float(lmbda), _lib.ptr(loss), _lib.ptr(g), _lib.ptr(ws), ws.numel(), _lib.stream())
+        loss, g = ops.barlow_cgrad(craw, 1.0 / b, lmbda)
         dhat_i = ops.conv2d_fwd(hats[1].view(b, 1, 1, d), g).view(b, d)                     # [b,i] = sum_j zj_hat[b,j] G[i,j]
         dhat_j = ops.conv2d_dgrad(hats[0].view(b, 1, 1, d), g, (b, 1, 1, d)).view(b, d)     # [b,j] = sum_i zi_hat[b,i] G[i,j]
         dgam, dbet = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)

@@ -1,5 +1,6 @@
 """World-size-2 gloo tests (CPU) of the data-parallel host logic: row placement / all-gather of the
-embeddings, the LSE exchange, loss all-reduce and the SUM gradient convention.  The HIP kernels are
+embeddings, the LSE exchange, loss all-reduce and the SUM gradient convention for all three losses (NT-Xent, BYOL pair MSE,
+Barlow Twins).  The HIP kernels are
 replaced, in these tests only, by oracle-backed CPU emulations of the same tensor-level entry points
 (ssv_amd.ops.*), so what is exercised is the product's orchestration code in utils/losses.py and distributed.py."""
 import os
@@ -63,11 +64,55 @@ def _emu_ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_temp, gscale):
     return gscale * (w @ zall - 2.0 * zall[(r + nglob) % (2 * nglob)])
 
 
+def _emu_mse_pair(o1, o2, t1, t2, scale):
+    loss = scale * (((o1 - t2) ** 2).sum() + ((o2 - t1) ** 2).sum())
+    return loss.reshape(()), 2 * scale * (o1 - t2), 2 * scale * (o2 - t1)
+
+
+def _emu_bn_train_fwd(x, gamma, beta, running_mean, running_var, nbt, relu=False, residual=None, eps=1e-5, **_):
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    return (x - mean) * invstd * gamma + beta, mean, invstd
+
+
+def _emu_bn_train_bwd(dy, y, x, gamma, mean, invstd, relu, dgamma, dbeta, want_dres=False, accumulate=True, relu_mask=None):
+    xh = (x - mean) * invstd
+    dgamma.copy_((dy * xh).sum(0))
+    dbeta.copy_(dy.sum(0))
+    m = x.shape[0]
+    return gamma * invstd * (dy - dbeta / m - xh * dgamma / m), None
+
+
+def _emu_conv1x1_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True):
+    k, c = dy.shape[-1], x.shape[-1]
+    dw.copy_(dy.reshape(-1, k).t() @ x.reshape(-1, c))              # dw[k][c] = sum_m dy[m,k] x[m,c]
+    return dw
+
+
+def _emu_conv1x1_fwd(x, w, stride=1, pad=0, bias=None, addend=None):
+    return (x.reshape(-1, x.shape[-1]) @ w.t()).reshape(*x.shape[:-1], w.shape[0])
+
+
+def _emu_conv1x1_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None):
+    return (dy.reshape(-1, dy.shape[-1]) @ w).reshape(tuple(x_shape))
+
+
+def _emu_barlow_cgrad(craw, inv_b, lmbda):
+    c = craw * inv_b
+    eye = torch.eye(c.shape[0])
+    wgt = eye + lmbda * (1 - eye)
+    return (wgt * (c - eye) ** 2).sum().reshape(()), 2 * wgt * (c - eye) * inv_b
+
+
 def _patch_ops():
     from ssv_amd import ops
     ops.l2norm_fwd, ops.l2norm_bwd = _emu_l2norm_fwd, _emu_l2norm_bwd
     ops.ntxent_fwd, ops.ntxent_loss, ops.ntxent_bwd = _emu_ntxent_fwd, _emu_ntxent_loss, _emu_ntxent_bwd
     ops.scale_ = lambda x, f: x.mul_(f)
+    ops.fill_ = lambda x, v: x.fill_(v)
+    ops.mse_pair, ops.barlow_cgrad = _emu_mse_pair, _emu_barlow_cgrad
+    ops.bn_train_fwd, ops.bn_train_bwd = _emu_bn_train_fwd, _emu_bn_train_bwd
+    ops.conv2d_wgrad, ops.conv2d_fwd, ops.conv2d_dgrad = _emu_conv1x1_wgrad, _emu_conv1x1_fwd, _emu_conv1x1_dgrad
 
 
 def _worker(rank, world, port, out):
@@ -119,6 +164,31 @@ def _worker(rank, world, port, out):
         flat = torch.cat([p.grad.flatten() for p in pl])
         hdist.all_reduce_sum(flat)                                # what FusedSGD.grad_sync does on the arena
         np.testing.assert_allclose(flat.numpy(), torch.cat([p.grad.flatten() for p in ps]).numpy(), rtol=5e-4, atol=1e-6)
+        # ---- 4. BYOL pair loss: global mean on every rank, SUM of per-rank gradients = gradient of the global mean
+        o = [seeded_randn(10 + k, n, d).requires_grad_() for k in range(2)]
+        t = [seeded_randn(12 + k, n, d) for k in range(2)]
+        ref = oracle.byol_mse_loss(o[0], o[1], t[0], t[1])
+        ref.backward()
+        sl = slice(rank * b, (rank + 1) * b)
+        ol = [x.detach()[sl].clone().requires_grad_() for x in o]
+        loss = losses.byol_pair_loss(ol[0], ol[1], t[0][sl].clone(), t[1][sl].clone())
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        for k in range(2):
+            np.testing.assert_allclose(ol[k].grad.numpy(), o[k].grad[sl].numpy(), rtol=1e-5, atol=1e-8)
+        # ---- 5. Barlow Twins: statistics and the cross-correlation are over the GLOBAL batch
+        dd = 16
+        zi, zj = seeded_randn(20, n, dd), seeded_randn(21, n, dd)
+        for normalize in (True, False):
+            a, c = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+            ref = oracle.barlow_loss(a, c, normalize, 0.005)
+            ref.backward()
+            li, lj = zi[sl].clone().requires_grad_(), zj[sl].clone().requires_grad_()
+            loss = losses.BarlowLoss(normalize, 0.005)(li, lj)
+            loss.backward()
+            np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+            np.testing.assert_allclose(li.grad.numpy(), a.grad[sl].numpy(), rtol=2e-3, atol=2e-6)
+            np.testing.assert_allclose(lj.grad.numpy(), c.grad[sl].numpy(), rtol=2e-3, atol=2e-6)
         out.put((rank, "ok"))
     except Exception as e:                                        # surface the failure to the parent
         import traceback

@@ -51,11 +51,41 @@ def _worker(rank, port, q):
         loss.backward()
         opt.step()
         torch.cuda.synchronize()
-        q.put((rank, "ok", loss.item(), opt.arena.data.cpu().numpy()))
+        extra = _sharded_loss_checks(rank, dev, losses)
+        q.put((rank, "ok" if extra is None else extra, loss.item(), opt.arena.data.cpu().numpy()))
         dist.destroy_process_group()
     except Exception:
         import traceback
         q.put((rank, traceback.format_exc(), None, None))
+
+
+def _sharded_loss_checks(rank, dev, losses):
+    """BYOL pair MSE and Barlow Twins over a batch split across the two ranks == the oracle on the whole batch."""
+    n, b = 2 * 24, 24
+    sl = slice(rank * b, (rank + 1) * b)
+    o = [seeded_randn(30 + k, n, 128).requires_grad_() for k in range(2)]
+    t = [seeded_randn(32 + k, n, 128) for k in range(2)]
+    ref = oracle.byol_mse_loss(o[0], o[1], t[0], t[1])
+    ref.backward()
+    ol = [x.detach()[sl].to(dev).requires_grad_() for x in o]
+    loss = losses.byol_pair_loss(ol[0], ol[1], t[0][sl].to(dev), t[1][sl].to(dev))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    for k in range(2):
+        np.testing.assert_allclose(ol[k].grad.cpu().numpy(), o[k].grad[sl].numpy(), rtol=1e-4, atol=1e-8)
+    zi, zj = seeded_randn(40, n, 64), seeded_randn(41, n, 64)
+    for normalize in (True, False):
+        a, c = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+        ref = oracle.barlow_loss(a, c, normalize, 0.005)
+        ref.backward()
+        li, lj = zi[sl].to(dev).requires_grad_(), zj[sl].to(dev).requires_grad_()
+        loss = losses.BarlowLoss(normalize, 0.005)(li, lj)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+        scale = float(a.grad.abs().max())
+        np.testing.assert_allclose(li.grad.cpu().numpy(), a.grad[sl].numpy(), rtol=2e-3, atol=2e-4 * scale)
+        np.testing.assert_allclose(lj.grad.cpu().numpy(), c.grad[sl].numpy(), rtol=2e-3, atol=2e-4 * scale)
+    return None
 
 
 def test_two_ranks_match_oracle_data_parallel_emulation():
