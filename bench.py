@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py - images/sec of the SimCLR ResNet-50 two-view training step on MI355X.
+"""bench.py - images/sec of the SimCLR (default; --algo byol|barlow for the siblings) ResNet-50 two-view training step on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -51,40 +51,58 @@ def conv_macs_resnet50(h, w, proj_dim=128):
             cin, ho, wo = planes * 4, h2, w2
     fwd = sum(macs)
     bwd = 2 * fwd - macs[0]
-    proj = 2048 * 2048 + 2048 * proj_dim
-    algo_bytes = 4 * (3 * sum(i + o for i, o in io) - sum(io[0]))   # fwd + dgrad + wgrad, each operand once; no stem dgrad
-    return fwd, bwd, proj, algo_bytes
+    bytes_fwd = 4 * sum(i + o for i, o in io)                        # every operand moved exactly once
+    bytes_bwd = 2 * bytes_fwd - 4 * sum(io[0])                       # dgrad + wgrad, no stem dgrad
+    return {"fwd": fwd, "bwd": bwd, "bytes_fwd": bytes_fwd, "bytes_bwd": bytes_bwd}
 
 
-def build(device, batch):
-    from ssv_amd.models import heads
-    from ssv_amd.networks import resnet
-    from ssv_amd.utils import losses, train_utils
+def step_work(algo, h, w, batch):
+    """Algorithmic work of ONE step on one GPU for everything that runs on the conv implicit-GEMM kernels (encoder convs,
+    the heads' Linear layers as 1x1 convs, Barlow's three B x D x D GEMMs): (FLOP, HBM bytes of the encoder convs)."""
+    c = conv_macs_resnet50(h, w)
+    train_views, fwd_only_views = 2, (2 if algo == "byol" else 0)
+    if algo == "simclr":
+        head_train, head_fwd, loss_macs = 2048 * 2048 + 2048 * 128, 0, 0
+    elif algo == "byol":                                             # projector d->d->D and predictor D->D->D online; projector only on the target
+        head_train, head_fwd, loss_macs = 2048 * 2048 + 2048 * 128 + 2 * 128 * 128, 2048 * 2048 + 2048 * 128, 0
+    else:                                                            # barlow: 2048->4096->4096->4096, C = zi^T zj and the two dz GEMMs once per step
+        head_train, head_fwd, loss_macs = 2048 * 4096 + 2 * 4096 * 4096, 0, 3 * 4096 * 4096
+    macs_per_sample = train_views * (c["fwd"] + c["bwd"] + 3 * head_train) + fwd_only_views * (c["fwd"] + head_fwd) + loss_macs
+    bytes_per_sample = train_views * (c["bytes_fwd"] + c["bytes_bwd"]) + fwd_only_views * c["bytes_fwd"]
+    return 2.0 * macs_per_sample * batch, bytes_per_sample * batch
+
+
+ALGOS = {"simclr": ("ssv_amd.models.simclr", "SimCLR"), "byol": ("ssv_amd.models.byol", "BYOL"), "barlow": ("ssv_amd.models.barlow", "BarlowTwins")}
+BENCH_CFG = {   # the reference configs' hyper-parameters (configs/{simclr,byol,barlow}.yaml) with the std-stem encoder for 224x224
+    "simclr": {"proj_dim": 128, "loss_fn": {"normalize": True, "temperature": 0.5}, "optimizer": {"name": "sgd", "lr": 2.0, "weight_decay": 1e-4}},
+    "byol": {"proj_dim": 128, "tau": 0.996, "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1e-4}},
+    "barlow": {"proj_dim": 4096, "loss_fn": {"normalize": True, "off_diagonal_weight": 0.005}, "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1.5e-6}},
+}
+
+
+def build(device, algo, steps_per_epoch=1000):
+    """The package's own trainer (ssv_amd.models.<algo>), constructed the way its __init__ does minus dataloaders, output
+    directory and wandb; bench steps call its train_step(batch) - the drop-in surface - not a copy of it."""
+    import importlib
     from ssv_amd import distributed as hdist
+    from ssv_amd.utils import train_utils
+    mod, name = ALGOS[algo]
+    cls = getattr(importlib.import_module(mod), name)
+    t = object.__new__(cls)
+    t.config = {"epochs": 1000, "encoder": {"reduce_bottom_conv": False}, "scheduler": {"name": "cosine", "warmup_epochs": 10}, **BENCH_CFG[algo]}
+    t.device, t.train_loader = device, [None] * steps_per_epoch
     torch.manual_seed(420)                                     # identical weights on every rank
-    encoder = resnet.resnet50().to(device)
-    head = heads.SimclrProjectionHead(2048, 128).to(device)
-    optim = train_utils.get_optimizer({"name": "sgd", "lr": 2.0, "weight_decay": 1e-4},
-                                      list(encoder.parameters()) + list(head.parameters()))
-    train_utils.get_scheduler({"name": "cosine", "warmup_epochs": 10, "epochs": 1000}, optim)      # lr seeded to 0.2
-    hdist.attach_grad_sync(optim)
-    loss_fn = losses.SimclrLoss(normalize=True, temperature=0.5)
-
-    from ssv_amd import nn as hnn
-    mode = {"dual": os.environ.get("SSV_SINGLE_STREAM", "0") != "1"}
+    t._build("resnet50")
+    t.scheduler, t.warmup_epochs = train_utils.get_scheduler({**t.config["scheduler"], "epochs": 1000}, optimizer=t.optim)   # lr seeded to lr/10
+    hdist.attach_grad_sync(t.optim)
+    state = {"i": 0}
 
     def step(v1, v2):
-        with hnn.parallel_views(device, enabled=mode["dual"]) as pv:      # same body as ssv_amd.models.simclr.SimCLR.train_step
-            with pv.view(0):
-                z1 = head(encoder(v1))
-            with pv.view(1):
-                z2 = head(encoder(v2))
-        loss = loss_fn(z1, z2)
-        optim.zero_grad()
-        loss.backward()
-        optim.step()
-        return loss.item()
-    return step, sum(p.numel() for p in optim.arena.params), mode
+        loss = t.train_step({"aug_1": v1, "aug_2": v2})["loss"]
+        t._after_step(state["i"])                                # BYOL: tau schedule + EMA of the target, as in the train loop
+        state["i"] += 1
+        return loss
+    return step, sum(p.numel() for p in t.optim.arena.params)
 
 
 AUG_CFG = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8},
@@ -92,7 +110,7 @@ AUG_CFG = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.
            "to_tensor": None, "normalize": {"mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225]}}
 
 
-def cpu_baseline(batch, size, steps):
+def cpu_baseline(batch, size, steps, algo="simclr"):
     """The oracle (CPU restatement of the reference step, pinned to reference fixtures) on this box's host cores."""
     import oracle
     from oracle.nets import ENCODER_DIM  # noqa: F401
@@ -100,7 +118,12 @@ def cpu_baseline(batch, size, steps):
     # dataloader-less single-socket run realistically uses.  `cores` below reports the threads actually used.
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    m = oracle.SimCLROracle("resnet50", False, 128, lr=0.2, weight_decay=1e-4)
+    if algo == "byol":
+        m = oracle.BYOLOracle("resnet50", False, 128, lr=0.02, weight_decay=1e-4)
+    elif algo == "barlow":
+        m = oracle.BarlowOracle("resnet50", False, 4096, lr=0.02, weight_decay=1.5e-6)
+    else:
+        m = oracle.SimCLROracle("resnet50", False, 128, lr=0.2, weight_decay=1e-4)
     g = torch.Generator().manual_seed(7)
     v1, v2 = torch.randn(batch, 3, size, size, generator=g), torch.randn(batch, 3, size, size, generator=g)
     m.train_step(v1, v2)                                       # warm-up
@@ -109,7 +132,7 @@ def cpu_baseline(batch, size, steps):
         m.train_step(v1, v2)
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (1 warm-up) of the same SimCLR ResNet-50 {size}x{size} step at batch {batch}, torch fp32 CPU"}
+            "sample": f"{steps} timed steps (1 warm-up) of the same {algo} ResNet-50 {size}x{size} step at batch {batch}, torch fp32 CPU"}
 
 
 def main():
@@ -119,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SSV_BENCH_BATCH", "512")), help="per-GPU batch (images)")
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--algo", choices=tuple(ALGOS), default="simclr", help="simclr = BASELINE.json's metric; byol = its config 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=2, help="extra instrumented steps for the per-kernel-class roofline")
     args = ap.parse_args()
@@ -134,7 +158,8 @@ def main():
     _lib.load()
 
     b, s = args.batch, args.size
-    train_step, nparams, mode = build(device, b)
+    from ssv_amd import nn as hnn
+    train_step, nparams = build(device, args.algo)
     # synthetic uint8 source images [B,S,S,3] ~ U{0..255}, resident in HBM before the timed region; every step draws
     # fresh augmentation parameters (Philox keyed by global sample index and step) and builds the two views on the GPU
     from ssv_amd.utils import augmentations
@@ -175,13 +200,12 @@ def main():
     images_per_s = b * world * args.steps / dt
 
     # ---- per-kernel-class timing (HIP events on the launch stream) over extra instrumented steps --------------
-    fwd, bwd, proj, algo_bytes = conv_macs_resnet50(s, s)
-    conv_flop_step = 2.0 * (fwd + bwd + 3 * proj) * 2 * b                     # per GPU: 2 FLOP/MAC, 2 views
+    conv_flop_step, algo_bytes_step = step_work(args.algo, s, s, b)           # per GPU and step; 2 FLOP/MAC
     roof, classes = None, {}
     if args.prof_steps > 0:
         # per-kernel durations are only meaningful when kernels do not overlap: the instrumented steps run the two
         # views back to back on ONE stream (the timed region above runs them on two streams)
-        was_dual, mode["dual"] = mode["dual"], False
+        was_dual = hnn.set_view_streams(False)
         step(); torch.cuda.synchronize()
         _lib.prof_enable(True)
         _lib.prof_reset()
@@ -190,13 +214,15 @@ def main():
         torch.cuda.synchronize()
         prof = _lib.prof_collect()
         _lib.prof_enable(False)
-        mode["dual"] = was_dual
+        hnn.set_view_streams(was_dual)
         classes = {k: {"ms_per_step": round(v[0] / args.prof_steps, 3), "launches_per_step": v[1] // args.prof_steps} for k, v in prof.items() if v[1]}
         conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
         conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
         ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; corrected as the guide prescribes)
+            if args.algo != "simclr":
+                raise KeyError(args.algo)                          # PMC passes exist for the headline workload only
             with open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic_b%d.json" % b)) as fh:
                 pmc = json.load(fh)["per_step_gb"]
             traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")), 1)
@@ -205,26 +231,29 @@ def main():
         roof = {"bound": "mfma", "kernel": "conv implicit-GEMM family (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/r01_c_pmc_hbm_traffic_b%d.json)" % b,
-                "algorithmic_gb_per_step": round(algo_bytes * 2 * b / 1e9, 1),
+                "algorithmic_gb_per_step": round(algo_bytes_step / 1e9, 1),
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
                 "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
-                "whole_step_mfma_frac": round(images_per_s / world * 2.0 * (fwd + bwd + 3 * proj) * 2 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "whole_step_mfma_frac": round(images_per_s / world * conv_flop_step / b / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "classes": classes}
 
+    label = {"simclr": "SimCLR", "byol": "BYOL", "barlow": "Barlow Twins"}[args.algo]
+    loss_desc = {"simclr": "NT-Xent(normalize, T=0.5) over the global batch", "byol": "EMA target encoder (4 encoder passes), pair MSE of unit vectors",
+                 "barlow": "cross-correlation loss D=4096 over the global batch"}[args.algo]
     out = {
-        "metric": "images/sec (whole node) SimCLR ResNet-50 two-view train step", "value": round(images_per_s, 2), "unit": "images/sec",
+        "metric": f"images/sec (whole node) {label} ResNet-50 two-view train step", "value": round(images_per_s, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SimCLR resnet50 (7x7/2 stem) synthetic 3x{s}x{s}, bs={b}/GPU, global batch {b * world}, "
-                               f"NT-Xent(normalize, T=0.5) over the global batch, SGD-Nesterov",
+        "config": {"workload": f"{label} resnet50 (7x7/2 stem) synthetic 3x{s}x{s}, bs={b}/GPU, global batch {b * world}, "
+                               f"{loss_desc}, SGD-Nesterov",
                    "input": f"uint8 [B,{s},{s},3] source resident in HBM -> fused GPU two-view augmentation each step",
                    "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
-                   "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if mode["dual"] else 1, "last_loss": loss},
+                   "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if hnn.view_streams() else 1, "last_loss": loss},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch=16, size=s, steps=2)
+        out["cpu_baseline"] = cpu_baseline(batch=16, size=s, steps=2, algo=args.algo)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

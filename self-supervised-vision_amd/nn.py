@@ -6,6 +6,8 @@ Parameters are ordinary ``nn.Parameter``s (state_dict keys/shapes identical to t
 parameter gradients are accumulated by the kernels straight into ``p.grad`` (which the optimizer
 keeps as views of one flat arena), never through torch ops.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,19 @@ from ._lib import SsvError
 #     order is view 1 then view 2, exactly like the reference's sequential forward passes.
 _SLOT = 0
 _STREAMS = {}
+_VIEW_STREAMS = os.environ.get("SSV_SINGLE_STREAM", "0") != "1"
+
+
+def view_streams():
+    return _VIEW_STREAMS
+
+
+def set_view_streams(on):
+    """Process-wide default of parallel_views: True = one HIP stream per view, False = both views on the ambient stream
+    (what a per-kernel profile needs).  Returns the previous setting."""
+    global _VIEW_STREAMS
+    prev, _VIEW_STREAMS = _VIEW_STREAMS, bool(on)
+    return prev
 
 
 def current_slot():
@@ -44,8 +59,8 @@ class parallel_views:
     On exit the ambient stream waits for both view streams.  Backward needs nothing special: torch.autograd runs
     each node on the stream of its forward and joins the streams at the end of backward()."""
 
-    def __init__(self, device, enabled=True):
-        self.device, self.enabled = device, enabled and device.type == "cuda"
+    def __init__(self, device, enabled=None):
+        self.device, self.enabled = device, (_VIEW_STREAMS if enabled is None else enabled) and device.type == "cuda"
 
     def __enter__(self):
         if self.enabled:
