@@ -173,6 +173,15 @@ int ssv_augment_views(int32_t B, int32_t nviews, int32_t Hs, int32_t Ws, int32_t
 int ssv_center_view(int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo, const uint8_t* src, const int64_t* sample_ids,
                     const float* mean3_host, const float* std3_host, float* out, void* stream);
 
+/* ---- kNN evaluation: compute_neighbor_accuracy utils/eval_utils.py:13-21 (faiss.IndexFlatIP search of every feature
+ * vector against the whole set, k+1 hits, the best one dropped, labels of the other k compared with the query's).
+ * z [n][d] fp32 (d % 4 == 0), labels [n] int32, 1 <= k <= min(63, n-1).  *count (device, 8 bytes) receives the number of
+ * (query, neighbour) pairs with equal labels; accuracy = count / (n*k).  Order: inner product descending, ties by index.
+ * S = Z Z^T is formed chunk by chunk in `ws` by the MFMA implicit-GEMM kernel; one wavefront per query keeps the top-(k+1). */
+size_t ssv_knn_workspace_bytes(int64_t n);
+int ssv_knn_label_agreement(int64_t n, int32_t d, const float* z, const int32_t* labels, int32_t k,
+                            unsigned long long* count, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
  * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
  * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */

@@ -68,6 +68,8 @@ SIGNATURES = {
     "ssv_augment_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "ssv_augment_views": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f3, _f3, _vp, _vp, _sz, _vp]),
     "ssv_center_view": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _f3, _f3, _vp, _vp]),
+    "ssv_knn_workspace_bytes": (_sz, [_i64]),
+    "ssv_knn_label_agreement": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
     "ssv_prof_enable": (C.c_int, [C.c_int]),
     "ssv_prof_reset": (C.c_int, []),
     "ssv_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

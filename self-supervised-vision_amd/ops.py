@@ -219,3 +219,18 @@ def barlow_cgrad(craw, inv_b, lmbda):
     ws = _lib.workspace.get(_lib.load().ssv_reduce_workspace_bytes(d * d), craw.device)
     call("ssv_barlow_cgrad", d, ptr(craw), float(inv_b), float(lmbda), ptr(loss), ptr(g), ptr(ws), ws.numel(), stream())
     return loss, g
+
+
+def knn_label_agreement(z, labels, k):
+    """Number of (query, neighbour) pairs with equal labels among each row's k nearest neighbours by inner product
+    (best hit dropped), as a python int.  z [n,d] fp32 device, labels [n] int32 device."""
+    _lib._dev(z, labels)
+    n, d = z.shape
+    if d % 4:
+        z = torch.nn.functional.pad(z, (0, 4 - d % 4))
+        d = z.shape[1]
+    z = z.contiguous()
+    count = torch.empty((1,), dtype=torch.int64, device=z.device)
+    ws = torch.empty(_lib.load().ssv_knn_workspace_bytes(n), dtype=torch.uint8, device=z.device)    # up to ~1 GB: not kept in the training scratch
+    call("ssv_knn_label_agreement", n, d, ptr(z), ptr(labels), int(k), ptr(count), ptr(ws), ws.numel(), stream())
+    return int(count.item())

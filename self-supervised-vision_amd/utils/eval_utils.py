@@ -1,26 +1,27 @@
-"""Evaluation helpers (outside the accelerated hot path; infrequent, host-side).
+"""Evaluation helpers.
 
-compute_neighbor_accuracy restates the reference's faiss IndexFlatIP 20-NN label agreement
-(utils/eval_utils.py:13-21) with a chunked numpy inner-product + argpartition, so --task train does
-not need faiss.  linear_evaluation is a small closed loop on frozen features.
+compute_neighbor_accuracy is the reference's 20-NN label agreement (utils/eval_utils.py:13-21, faiss.IndexFlatIP search) as
+one C-ABI call: S = Z Z^T on the fp32-MFMA GEMM kernel, streaming top-(k+1) per query on the GPU (csrc/evalknn.hip) - no faiss,
+and `eval_every` costs milliseconds.  linear_evaluation is a small closed loop on frozen features.
 """
 import numpy as np
+import torch
+
+from .. import ops
 
 
-def compute_neighbor_accuracy(fvecs, targets, k=20, chunk=2048):
-    fvecs = np.ascontiguousarray(fvecs, dtype=np.float32)
-    targets = np.asarray(targets)
-    n = fvecs.shape[0]
-    k = min(k, n - 1)
-    agree = 0.0
-    for s in range(0, n, chunk):
-        sims = fvecs[s:s + chunk] @ fvecs.T                       # inner product, like IndexFlatIP
-        idx = np.argpartition(-sims, k, axis=1)[:, :k + 1]        # k+1 best (includes the query itself)
-        part = np.take_along_axis(sims, idx, axis=1)
-        order = np.argsort(-part, axis=1, kind="stable")
-        nbrs = np.take_along_axis(idx, order, axis=1)[:, 1:]      # drop the top hit, as the reference does
-        agree += (targets[nbrs] == targets[s:s + chunk, None]).mean(axis=1).sum()
-    return float(agree / n)
+def compute_neighbor_accuracy(fvecs, targets, k=20, device=None):
+    """fvecs [n,d] and targets [n]: numpy arrays (what build_features returns) or tensors already on the GPU."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("compute_neighbor_accuracy runs on the GPU (libssv_hip); no HIP device is visible and there is no CPU fallback")
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    z = torch.as_tensor(fvecs, dtype=torch.float32).to(device)
+    labels = torch.as_tensor(targets).to(device=device, dtype=torch.int32).contiguous()
+    n = z.shape[0]
+    if z.dim() != 2 or labels.shape != (n,):
+        raise ValueError(f"expected fvecs [n,d] and targets [n], got {tuple(z.shape)} and {tuple(labels.shape)}")
+    k = min(int(k), n - 1)                                          # tiny evaluation sets (synthetic smoke runs)
+    return ops.knn_label_agreement(z, labels, k) / float(n * k)
 
 
 def hungarian_match(preds, targets, preds_k, targets_k):

@@ -141,3 +141,12 @@ def test_sgd_and_lr_schedule_match_reference(golden):
         _close(ps[0], g[f"sgd_p0_step{s}"], rtol=1e-6, atol=1e-7)
         _close(ps[1], g[f"sgd_p1_step{s}"], rtol=1e-6, atol=1e-7)
     assert abs(oracle.seeded_lr(2.0, 10) - g["lr_schedule"][0]) < 1e-15
+
+
+def test_knn_accuracy_oracle_matches_reference(golden):
+    """oracle/evalknn.py == the reference's compute_neighbor_accuracy (run over an exact-search stand-in for faiss)."""
+    from oracle import evalknn
+    g = golden["eval_level"]
+    for (seed, n, d, classes, spread, k), want in zip(g["knn_cases"], g["knn_accuracy"]):
+        fvecs, labels = evalknn.clustered_features(int(seed), int(n), int(d), int(classes), float(spread))
+        assert evalknn.compute_neighbor_accuracy(fvecs, labels, k=int(k)) == want
