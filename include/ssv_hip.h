@@ -182,11 +182,76 @@ size_t ssv_knn_workspace_bytes(int64_t n);
 int ssv_knn_label_agreement(int64_t n, int32_t d, const float* z, const int32_t* labels, int32_t k,
                             unsigned long long* count, void* ws, size_t ws_bytes, void* stream);
 
+/* ==== "next" row 1 of the scope table: DINO on the reference's ViT (networks/vit.py, models/dino.py) ====================
+ * Linear layers of the encoder and of the projection head are ssv_conv2d_fwd/dgrad/wgrad with H = W = R = S = 1 over
+ * N = B*T token rows; what follows are the pieces that are not GEMMs.  All matrices are dense row-major fp32. */
+
+/* EmbeddingLayer + nn.Unfold (networks/vit.py:71-82, :101-102): tokens[b][0] = [cls | pos[0]], tokens[b][1+p] =
+ * [patch p of image b in (channel, kh, kw) order | pos[1+p]];  T = (H/patch)(W/patch)+1, row length 3*patch^2 + E.
+ * img: [B][H][W][3] (channels-last).  bwd: dcls[f] = sum_b dtokens[b][0][f], dpos[t][e] = sum_b dtokens[b][t][3p^2+e]. */
+int ssv_vit_embed_fwd(int32_t B, int32_t H, int32_t W, int32_t patch, int32_t E, const float* img_nhwc,
+                      const float* cls, const float* pos, float* tokens, void* stream);
+int ssv_vit_embed_bwd(int32_t B, int32_t T, int32_t P3, int32_t E, const float* dtokens, float* dcls, float* dpos,
+                      int32_t accumulate, void* stream);
+
+/* nn.LayerNorm over the last axis of [M][C] (networks/vit.py:19,40; biased variance, eps inside the sqrt) with a fused
+ * addend: y = LN(x) * gamma + beta (+ addend) - the reference's "f(x) + LayerNorm(x)" residual form (:22-31, :43-46).
+ * bwd: dx = LN'(dy) (+ dx_addend), dgamma/dbeta (+)= column sums (per-block partials in `ws`, fixed-order final reduce). */
+int ssv_layernorm_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta, const float* addend,
+                      float eps, float* y, float* mean, float* invstd, void* stream);
+size_t ssv_layernorm_workspace_bytes(int64_t M, int32_t C);
+int ssv_layernorm_bwd(int64_t M, int32_t C, const float* dy, const float* x, const float* gamma, const float* mean,
+                      const float* invstd, const float* dx_addend, float* dx, float* dgamma, float* dbeta,
+                      int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.GELU() (erf form; networks/vit.py:38, models/dino.py:30-33) on n floats, n % 4 == 0 */
+int ssv_gelu_fwd(int64_t n, const float* x, float* y, void* stream);
+int ssv_gelu_bwd(int64_t n, const float* x, const float* dy, float* dx, void* stream);
+
+/* MultiheadSelfAttention core (networks/vit.py:24-30): o[b][t][h*dh..] = softmax(q k^T * scale) v per (image, head), without
+ * materialising the T x T probabilities (the reference returns them only for visualisation).  q/k/v rows have stride `ld`
+ * (so a fused [M][3*hidden] projection can be passed as three pointers), o/dout stride `ldo`, gradients stride `ldg`.
+ * dh must be 64.  lse and delta: [B][heads][T] (log-sum-exp of the scaled scores; rowsum(dout * o)). */
+int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
+                      int32_t ld, float scale, float* o, int32_t ldo, float* lse, void* stream);
+int ssv_attention_bwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
+                      int32_t ld, float scale, const float* o, const float* dout, int32_t ldo, const float* lse,
+                      float* delta, float* dq, float* dk, float* dv, int32_t ldg, void* stream);
+
+/* nn.utils.weight_norm(nn.Linear) (models/dino.py:35): w[r][:] = g[r] * v[r][:] / ||v[r]||; bwd -> dg, dv from dw */
+int ssv_weightnorm_fwd(int32_t rows, int32_t cols, const float* g, const float* v, float* w, float* inv_norm, void* stream);
+int ssv_weightnorm_bwd(int32_t rows, int32_t cols, const float* dw, const float* g, const float* v, const float* inv_norm,
+                       float* dg, float* dv, int32_t accumulate, void* stream);
+
+/* DinoLoss.forward (utils/losses.py:80-89): teacher [bs][2][K], student [bs][V][K], center [K];
+ * loss (+)= weight * sum_g mean_{b,v}( - softmax((teacher[b][g]-center)/temp_t) . log_softmax(student[b][v]/temp_s) ),
+ * dstudent = d(weight * that)/dstudent.  The caller passes weight 0.5 for each of the two pairs (models/dino.py:161-163). */
+size_t ssv_dino_loss_workspace_bytes(int32_t bs, int32_t V, int32_t K);
+int ssv_dino_loss(int32_t bs, int32_t V, int32_t K, const float* teacher, const float* student, const float* center,
+                  float temp_s, float temp_t, float weight, float* loss, int32_t accumulate_loss, float* dstudent,
+                  void* ws, size_t ws_bytes, void* stream);
+/* update_teacher_center (models/dino.py:136-141): center = m*center + (1-m)*mean over the rows of t1 and t2 */
+int ssv_dino_center_update(int32_t K, int32_t rows1, const float* t1, int32_t rows2, const float* t2, float momentum,
+                           float* center, void* stream);
+
+/* optim.AdamW (utils/train_utils.py:17-19) over a flat arena; g2 = optional second gradient slab; clip > 0 applies the
+ * reference's clamp hooks torch.clamp(grad, -clip, clip) (models/dino.py:76-79) to the summed gradient first.  step >= 1. */
+int ssv_adamw(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int64_t step, float clip, void* stream);
+
+/* MultiCrop (utils/augmentations.py:156-173): RandomResizedCrop(scale, ratio 3/4..4/3, BICUBIC) boxes drawn from the Philox
+ * stream (seed, step, sample, view_base + crop), view_base >= 16; then crop + bicubic resize (align_corners = False, A = -0.75,
+ * taps clamped to the box) of already normalised float views [B][Hs][Ws][3] into [B][ncrop][Ho][Wo][3]. */
+int ssv_multicrop_params(int32_t B, int32_t Hs, int32_t Ws, int32_t ncrop, int32_t view_base, double scale_min, double scale_max,
+                         uint64_t seed, uint64_t step, const int64_t* sample_ids, int64_t sample0, int32_t* boxes, void* stream);
+int ssv_multicrop(int32_t B, int32_t Hs, int32_t Ws, const float* views_nhwc, int32_t ncrop, const int32_t* boxes,
+                  int32_t Ho, int32_t Wo, float* out_nhwc, void* stream);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
  * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
  * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */
 enum { SSV_PROF_CONV_FWD = 0, SSV_PROF_CONV_DGRAD, SSV_PROF_CONV_WGRAD, SSV_PROF_BN_FWD, SSV_PROF_BN_BWD,
-       SSV_PROF_POOL, SSV_PROF_LOSS, SSV_PROF_OPTIM, SSV_PROF_AUG, SSV_PROF_MISC, SSV_PROF_NCLASS };
+       SSV_PROF_POOL, SSV_PROF_LOSS, SSV_PROF_OPTIM, SSV_PROF_AUG, SSV_PROF_MISC, SSV_PROF_ATTN, SSV_PROF_NORM, SSV_PROF_NCLASS };
 int ssv_prof_enable(int on);
 int ssv_prof_reset(void);
 int ssv_prof_collect(double* ms_per_class, int64_t* launches_per_class);   /* HOST arrays [SSV_PROF_NCLASS] */

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSV_HIP_LIB") or os.path.join(_HERE, "csrc", "libssv_hip.so")   # override: diagnostic builds only
 
-PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc")
+PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc", "attn", "norm")
 
 
 class SsvError(RuntimeError):
@@ -70,6 +70,23 @@ SIGNATURES = {
     "ssv_center_view": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _f3, _f3, _vp, _vp]),
     "ssv_knn_workspace_bytes": (_sz, [_i64]),
     "ssv_knn_label_agreement": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "ssv_vit_embed_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_vit_embed_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "ssv_layernorm_fwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "ssv_layernorm_workspace_bytes": (_sz, [_i64, _i32]),
+    "ssv_layernorm_bwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "ssv_gelu_fwd": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "ssv_gelu_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "ssv_attention_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),
+    "ssv_attention_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ssv_weightnorm_fwd": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_weightnorm_bwd": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ssv_dino_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "ssv_dino_loss": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "ssv_dino_center_update": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _f32, _vp, _vp]),
+    "ssv_adamw": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "ssv_multicrop_params": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, _vp, _i64, _vp, _vp]),
+    "ssv_multicrop": (C.c_int, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ssv_prof_enable": (C.c_int, [C.c_int]),
     "ssv_prof_reset": (C.c_int, []),
     "ssv_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

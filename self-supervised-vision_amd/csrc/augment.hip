@@ -52,6 +52,32 @@ struct Philox {
   }
 };
 
+// RandomResizedCrop.get_params: 10 attempts of (area ~ U[scale], log-ratio ~ U[log ratio]), then the centre-crop fallback
+__device__ void sample_rrc(Philox& st, int Hs, int Ws, double scale_min, double scale_max, double ratio_min, double ratio_max,
+                           int& top, int& left, int& h, int& w) {
+  const double area = (double)Hs * (double)Ws;
+  top = 0; left = 0; h = Hs; w = Ws;
+  bool done = false;
+  const double lr0 = log(ratio_min), lr1 = log(ratio_max);
+  for (int a = 0; a < 10 && !done; ++a) {
+    const double target = area * (scale_min + st.uniform() * (scale_max - scale_min));
+    const double ratio = exp(lr0 + st.uniform() * (lr1 - lr0));
+    const int ww = (int)floor(sqrt(target * ratio) + 0.5), hh = (int)floor(sqrt(target / ratio) + 0.5);
+    const double ui = st.uniform(), uj = st.uniform();
+    if (0 < ww && ww <= Ws && 0 < hh && hh <= Hs) {
+      w = ww; h = hh; top = (int)(ui * (double)(Hs - hh + 1)); left = (int)(uj * (double)(Ws - ww + 1));
+      done = true;
+    }
+  }
+  if (!done) {
+    const double in_ratio = (double)Ws / (double)Hs;
+    if (in_ratio < ratio_min) { w = Ws; h = (int)floor((double)Ws / ratio_min + 0.5); }
+    else if (in_ratio > ratio_max) { h = Hs; w = (int)floor((double)Hs * ratio_max + 0.5); }
+    else { w = Ws; h = Hs; }
+    top = (Hs - h) / 2; left = (Ws - w) / 2;
+  }
+}
+
 __global__ void aug_params_k(int B, int Hs, int Ws, AugCfg cfg, uint64_t seed, uint64_t step, const int64_t* __restrict__ ids,
                              int64_t sample0, int nviews, float* __restrict__ params) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,27 +99,8 @@ __global__ void aug_params_k(int B, int Hs, int Ws, AugCfg cfg, uint64_t seed, u
   p[7] = (float)(sl + st.uniform() * (1.0 + cfg.saturation - sl));
   p[8] = (float)(-cfg.hue + st.uniform() * 2.0 * cfg.hue);
   p[9] = st.uniform() < cfg.p_gray ? 1.f : 0.f;
-  const double area = (double)Hs * (double)Ws;
-  int top = 0, left = 0, h = Hs, w = Ws;
-  bool done = false;
-  const double lr0 = log(cfg.ratio_min), lr1 = log(cfg.ratio_max);
-  for (int a = 0; a < 10 && !done; ++a) {
-    const double target = area * (cfg.scale_min + st.uniform() * (cfg.scale_max - cfg.scale_min));
-    const double ratio = exp(lr0 + st.uniform() * (lr1 - lr0));
-    const int ww = (int)floor(sqrt(target * ratio) + 0.5), hh = (int)floor(sqrt(target / ratio) + 0.5);
-    const double ui = st.uniform(), uj = st.uniform();
-    if (0 < ww && ww <= Ws && 0 < hh && hh <= Hs) {
-      w = ww; h = hh; top = (int)(ui * (double)(Hs - hh + 1)); left = (int)(uj * (double)(Ws - ww + 1));
-      done = true;
-    }
-  }
-  if (!done) {
-    const double in_ratio = (double)Ws / (double)Hs;
-    if (in_ratio < cfg.ratio_min) { w = Ws; h = (int)floor((double)Ws / cfg.ratio_min + 0.5); }
-    else if (in_ratio > cfg.ratio_max) { h = Hs; w = (int)floor((double)Hs * cfg.ratio_max + 0.5); }
-    else { w = Ws; h = Hs; }
-    top = (Hs - h) / 2; left = (Ws - w) / 2;
-  }
+  int top, left, h, w;
+  sample_rrc(st, Hs, Ws, cfg.scale_min, cfg.scale_max, cfg.ratio_min, cfg.ratio_max, top, left, h, w);
   p[10] = (float)top; p[11] = (float)left; p[12] = (float)h; p[13] = (float)w;
   p[14] = st.uniform() < cfg.p_flip ? 1.f : 0.f;
   p[15] = 0.f;
@@ -292,6 +299,68 @@ center_view_k(int B, int Hs, int Ws, int Ho, int Wo, int top, int left, const ui
   }
 }
 
+
+// ---- MultiCrop (utils/augmentations.py:156-173): RandomResizedCrop(BICUBIC) of an ALREADY normalised float view ----------
+// boxes[b][crop] = (top, left, h, w); stream keyed (seed, step, sample, view_base + crop) so it never collides with the
+// two-view parameter streams (views 0..15)
+__global__ void multicrop_params_k(int B, int Hs, int Ws, int ncrop, int view_base, double scale_min, double scale_max,
+                                   double ratio_min, double ratio_max, uint64_t seed, uint64_t step, const int64_t* __restrict__ ids,
+                                   int64_t sample0, int32_t* __restrict__ boxes) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * ncrop) return;
+  const int b = t / ncrop, crop = t - b * ncrop;
+  Philox st(seed, step, (uint64_t)(ids ? ids[b] : sample0 + b), (uint32_t)(view_base + crop));
+  int top, left, h, w;
+  sample_rrc(st, Hs, Ws, scale_min, scale_max, ratio_min, ratio_max, top, left, h, w);
+  boxes[4 * t + 0] = top; boxes[4 * t + 1] = left; boxes[4 * t + 2] = h; boxes[4 * t + 3] = w;
+}
+
+// cubic convolution weights, A = -0.75 (upsample_bicubic2d)
+__device__ __forceinline__ void cubic_w(float t, float* w) {
+  const float A = -0.75f;
+  float x = t + 1.f;  w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t;              w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t;        w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t;        w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+
+// views [B][Hs][Ws][3] (NHWC) -> out [B][ncrop][Ho][Wo][3]; F.interpolate(mode="bicubic", align_corners=False) of the box,
+// source index = scale * (dst + 0.5) - 0.5 (not clamped), taps clamped to the box, no antialias, no value clamp
+__global__ void __launch_bounds__(256) multicrop_k(int64_t total, int Hs, int Ws, int ncrop, int Ho, int Wo, const float* __restrict__ views,
+                                                   const int32_t* __restrict__ boxes, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % Wo);
+  int64_t t = i / Wo;
+  const int yo = (int)(t % Ho);
+  const int64_t bc = t / Ho;                                  // b * ncrop + crop
+  const int64_t b = bc / ncrop;
+  const int32_t* bx = boxes + 4 * bc;
+  const int top = bx[0], left = bx[1], h = bx[2], w = bx[3];
+  const float sy = (float)h / (float)Ho, sx = (float)w / (float)Wo;
+  const float ry = sy * ((float)yo + 0.5f) - 0.5f, rx = sx * ((float)xo + 0.5f) - 0.5f;
+  const float fy = floorf(ry), fx = floorf(rx);
+  float wy[4], wx[4];
+  cubic_w(ry - fy, wy);
+  cubic_w(rx - fx, wx);
+  const int iy = (int)fy, ix = (int)fx;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = top + min(max(iy - 1 + a, 0), h - 1);
+    float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int xx = left + min(max(ix - 1 + c, 0), w - 1);
+      const float* px = views + ((b * Hs + yy) * (int64_t)Ws + xx) * 3;
+      row[0] += px[0] * wx[c]; row[1] += px[1] * wx[c]; row[2] += px[2] * wx[c];
+    }
+    acc[0] += row[0] * wy[a]; acc[1] += row[1] * wy[a]; acc[2] += row[2] * wy[a];
+  }
+  float* o = out + i * 3;
+  o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+}
+
 unsigned grid_for(int64_t n) {
   int64_t b = cdiv64(n, 256);
   if (b > 8192) b = 8192;
@@ -351,5 +420,28 @@ extern "C" int ssv_center_view(int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, in
   hipLaunchKernelGGL(center_view_k, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, s, B, Hs, Ws, Ho, Wo, top, left, src, sample_ids,
                      mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], out);
   SSV_CHECK_LAUNCH("ssv_center_view");
+  return SSV_OK;
+}
+
+extern "C" int ssv_multicrop_params(int32_t B, int32_t Hs, int32_t Ws, int32_t ncrop, int32_t view_base, double scale_min, double scale_max,
+                                    uint64_t seed, uint64_t step, const int64_t* sample_ids, int64_t sample0, int32_t* boxes, void* stream) {
+  SSV_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && ncrop > 0 && view_base >= 16 && view_base + ncrop <= 65536 && boxes, "ssv_multicrop_params: bad arguments (view_base >= 16)");
+  SSV_REQUIRE(scale_min > 0 && scale_max >= scale_min, "ssv_multicrop_params: bad scale range");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_AUG, s);
+  hipLaunchKernelGGL(multicrop_params_k, dim3(cdiv(B * ncrop, 64)), dim3(64), 0, s, B, Hs, Ws, ncrop, view_base, scale_min, scale_max,
+                     3.0 / 4.0, 4.0 / 3.0, seed, step, sample_ids, sample0, boxes);
+  SSV_CHECK_LAUNCH("ssv_multicrop_params");
+  return SSV_OK;
+}
+
+extern "C" int ssv_multicrop(int32_t B, int32_t Hs, int32_t Ws, const float* views_nhwc, int32_t ncrop, const int32_t* boxes,
+                             int32_t Ho, int32_t Wo, float* out_nhwc, void* stream) {
+  SSV_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && ncrop > 0 && Ho > 0 && Wo > 0 && views_nhwc && boxes && out_nhwc, "ssv_multicrop: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_AUG, s);
+  const int64_t total = (int64_t)B * ncrop * Ho * Wo;
+  hipLaunchKernelGGL(multicrop_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, total, Hs, Ws, ncrop, Ho, Wo, views_nhwc, boxes, out_nhwc);
+  SSV_CHECK_LAUNCH("ssv_multicrop");
   return SSV_OK;
 }

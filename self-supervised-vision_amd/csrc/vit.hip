@@ -1,0 +1,496 @@
+// ViT encoder pieces of the reference (networks/vit.py) that are not plain GEMMs, for gfx950:
+//   * token assembly  [cls | patches] ++ positional embedding (concatenated along the feature axis, :71-82, :101-102)
+//   * LayerNorm over the feature axis with a fused addend  (out = f(x) + LayerNorm(x), :22-31 and :43-46)
+//   * exact (erf) GELU
+//   * multi-head softmax(QK^T/sqrt(d))V on fp32 MFMA, forward + backward, without materialising the T x T matrix.
+// Linear layers run on the implicit-GEMM kernels of conv_mfma.hip (a Linear is a 1x1 convolution over M = B*T "pixels").
+//
+// Attention tiling (wave64, v_mfma_f32_32x32x2_f32, head size 64).  A 32x32 accumulator tile keeps its COLUMN on the lane
+// (col = lane & 31) and 16 rows in registers (row = (j&3) + 8*(j>>2) + 4*(lane>>5)).  Every product is therefore arranged
+// so that the index a softmax statistic belongs to is the column:
+//   forward / dQ pass : S^T = K Q^T          -> query on the lane: running max / sum / log-sum-exp / delta are lane-local;
+//                       O^T += V^T P^T       -> the P^T accumulator registers are fed back AS the B operand, step j uses the
+//                                               key rows {(j&3)+8(j>>2)+4*half}: no shuffles, no LDS round trip;
+//   dK/dV pass        : S  = Q K^T, dP = dO V^T (key on the lane), dV^T += dO^T P, dK^T += Q^T dS the same way.
+// The contraction over the head dimension is taken in the order d = 32*half + s, so each lane's operand fragment is 32
+// CONSECUTIVE floats of one row (8 x 16-byte loads).
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ int rowof(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
+
+// 32 consecutive floats of one row -> registers (optionally scaled)
+__device__ __forceinline__ void load_row32(const float* __restrict__ p, float* __restrict__ r, float scale) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 v = *(const f32x4*)(p + 4 * i);
+    r[4 * i + 0] = v[0] * scale; r[4 * i + 1] = v[1] * scale; r[4 * i + 2] = v[2] * scale; r[4 * i + 3] = v[3] * scale;
+  }
+}
+
+// acc^T[d][col] tile stored as rows of a [T][ld] matrix: lane (col, half) owns 4 consecutive d per register quad
+__device__ __forceinline__ void store_tile_T(float* __restrict__ base, int64_t row_stride, int row, bool valid, int half,
+                                             const f32x16& lo, const f32x16& hi, float mul) {
+  if (!valid) return;
+  float* p = base + (int64_t)row * row_stride;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = lo[4 * jj + e] * mul; b[e] = hi[4 * jj + e] * mul; }
+    *(f32x4*)(p + 8 * jj + 4 * half) = a;
+    *(f32x4*)(p + 32 + 8 * jj + 4 * half) = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention forward
+__global__ void __launch_bounds__(64) attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                 const float* __restrict__ V, int ld, float scale,
+                                                 float* __restrict__ O, int ldo, float* __restrict__ LSE) {
+  const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int64_t tok0 = (int64_t)b * T;
+  const int qrow = min(q0 + c, T - 1);
+  float qreg[32];
+  load_row32(Q + (tok0 + qrow) * ld + h * DH + half * 32, qreg, scale);
+  f32x16 o_lo = zero16(), o_hi = zero16();
+  float m = -INFINITY, l = 0.f;
+  const float* kbase = K + tok0 * ld + h * DH;
+  const float* vbase = V + tok0 * ld + h * DH;
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    float kreg[32], vlo[16], vhi[16];
+    load_row32(kbase + (int64_t)min(k0 + c, T - 1) * ld + half * 32, kreg, 1.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float* vr = vbase + (int64_t)min(k0 + rowof(j, half), T - 1) * ld;
+      vlo[j] = vr[c]; vhi[j] = vr[32 + c];
+    }
+    f32x16 s = zero16();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], qreg[i], s, 0, 0, 0);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (k0 + rowof(j, half) >= T) s[j] = -INFINITY;
+      mt = fmaxf(mt, s[j]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = expf(m - mn);                       // m = -inf on the first tile -> 0
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s[j] = expf(s[j] - mn); ls += s[j]; }
+    ls += __shfl_xor(ls, 32, 64);
+    l = l * alpha + ls;
+    m = mn;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { o_lo[j] *= alpha; o_hi[j] *= alpha; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vlo[j], s[j], o_lo, 0, 0, 0);
+      o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vhi[j], s[j], o_hi, 0, 0, 0);
+    }
+  }
+  const bool valid = q0 + c < T;
+  store_tile_T(O + tok0 * ldo + h * DH, ldo, q0 + c, valid, half, o_lo, o_hi, 1.f / l);
+  if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = m + logf(l);
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward: dQ (and delta)
+__global__ void __launch_bounds__(64) attn_bwd_dq_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, int ld, float scale,
+                                                    const float* __restrict__ O, const float* __restrict__ dO, int ldo,
+                                                    const float* __restrict__ LSE, float* __restrict__ DELTA,
+                                                    float* __restrict__ dQ, int ldg) {
+  const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int64_t tok0 = (int64_t)b * T;
+  const int qrow = min(q0 + c, T - 1);
+  float qreg[32], doreg[32];
+  load_row32(Q + (tok0 + qrow) * ld + h * DH + half * 32, qreg, scale);
+  load_row32(dO + (tok0 + qrow) * ldo + h * DH + half * 32, doreg, 1.f);
+  float delta = 0.f;
+  {
+    const float* op = O + (tok0 + qrow) * ldo + h * DH + half * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = *(const f32x4*)(op + 4 * i);
+      delta += v[0] * doreg[4 * i] + v[1] * doreg[4 * i + 1] + v[2] * doreg[4 * i + 2] + v[3] * doreg[4 * i + 3];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+  }
+  const int64_t stat = ((int64_t)b * heads + h) * T;
+  const float lse = LSE[stat + qrow];
+  const bool valid = q0 + c < T;
+  if (valid && half == 0) DELTA[stat + q0 + c] = delta;
+  f32x16 g_lo = zero16(), g_hi = zero16();
+  const float* kbase = K + tok0 * ld + h * DH;
+  const float* vbase = V + tok0 * ld + h * DH;
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    float kreg[32], vreg[32], klo[16], khi[16];
+    const int krow = min(k0 + c, T - 1);
+    load_row32(kbase + (int64_t)krow * ld + half * 32, kreg, 1.f);
+    load_row32(vbase + (int64_t)krow * ld + half * 32, vreg, 1.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float* kr = kbase + (int64_t)min(k0 + rowof(j, half), T - 1) * ld;
+      klo[j] = kr[c]; khi[j] = kr[32 + c];
+    }
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], qreg[i], s, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[i], doreg[i], dp, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float p = (k0 + rowof(j, half) < T) ? expf(s[j] - lse) : 0.f;
+      s[j] = p * (dp[j] - delta);                            // dS^T
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      g_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(klo[j], s[j], g_lo, 0, 0, 0);
+      g_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(khi[j], s[j], g_hi, 0, 0, 0);
+    }
+  }
+  store_tile_T(dQ + tok0 * ldg + h * DH, ldg, q0 + c, valid, half, g_lo, g_hi, scale);
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward: dK, dV
+__global__ void __launch_bounds__(64) attn_bwd_dkv_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                     const float* __restrict__ V, int ld, float scale,
+                                                     const float* __restrict__ dO, int ldo, const float* __restrict__ LSE,
+                                                     const float* __restrict__ DELTA, float* __restrict__ dK, float* __restrict__ dV, int ldg) {
+  const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
+  const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int64_t tok0 = (int64_t)b * T;
+  const int krow = min(k0 + c, T - 1);
+  const bool kvalid = k0 + c < T;
+  float kreg[32], vreg[32];
+  load_row32(K + (tok0 + krow) * ld + h * DH + half * 32, kreg, 1.f);
+  load_row32(V + (tok0 + krow) * ld + h * DH + half * 32, vreg, 1.f);
+  const int64_t stat = ((int64_t)b * heads + h) * T;
+  f32x16 dk_lo = zero16(), dk_hi = zero16(), dv_lo = zero16(), dv_hi = zero16();
+  const float* qbase = Q + tok0 * ld + h * DH;
+  const float* dobase = dO + tok0 * ldo + h * DH;
+  for (int q0 = 0; q0 < T; q0 += 32) {
+    float qreg[32], doreg[32];
+    const int qrow = min(q0 + c, T - 1);
+    load_row32(qbase + (int64_t)qrow * ld + half * 32, qreg, scale);
+    load_row32(dobase + (int64_t)qrow * ldo + half * 32, doreg, 1.f);
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i], kreg[i], s, 0, 0, 0);        // rows = query, col = key
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(doreg[i], vreg[i], dp, 0, 0, 0);
+    float qlo[16], qhi[16], dlo[16], dhi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int qi = q0 + rowof(j, half);
+      const int qr = min(qi, T - 1);
+      const float p = (qi < T && kvalid) ? expf(s[j] - LSE[stat + qr]) : 0.f;
+      s[j] = p;                                              // P
+      dp[j] = p * (dp[j] - DELTA[stat + qr]);                // dS
+      const float* qr_p = qbase + (int64_t)qr * ld;
+      const float* do_p = dobase + (int64_t)qr * ldo;
+      qlo[j] = qr_p[c]; qhi[j] = qr_p[32 + c];
+      dlo[j] = do_p[c]; dhi[j] = do_p[32 + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      dv_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(dlo[j], s[j], dv_lo, 0, 0, 0);
+      dv_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(dhi[j], s[j], dv_hi, 0, 0, 0);
+      dk_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(qlo[j], dp[j], dk_lo, 0, 0, 0);
+      dk_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(qhi[j], dp[j], dk_hi, 0, 0, 0);
+    }
+  }
+  store_tile_T(dK + tok0 * ldg + h * DH, ldg, k0 + c, kvalid, half, dk_lo, dk_hi, scale);
+  store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid, half, dv_lo, dv_hi, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wavefront per row; lane owns columns 4*lane + 256*it
+__global__ void __launch_bounds__(256) ln_fwd_k(int64_t M, int C, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, const float* __restrict__ addend, float eps,
+                                                float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const float* xr = x + r * C;
+  float s = 0.f;
+  for (int i = lane * 4; i < C; i += 256) { const f32x4 v = *(const f32x4*)(xr + i); s += (v[0] + v[1]) + (v[2] + v[3]); }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int i = lane * 4; i < C; i += 256) {
+    const f32x4 v = *(const f32x4*)(xr + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  }
+  const float invstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  float* yr = y + r * C;
+  const float* ar = addend ? addend + r * C : nullptr;
+  for (int i = lane * 4; i < C; i += 256) {
+    const f32x4 v = *(const f32x4*)(xr + i), g = *(const f32x4*)(gamma + i), bb = *(const f32x4*)(beta + i);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * invstd * g[e] + bb[e];
+    if (ar) { const f32x4 a = *(const f32x4*)(ar + i); o += a; }
+    *(f32x4*)(yr + i) = o;
+  }
+  if (lane == 0) { mean_out[r] = mean; invstd_out[r] = invstd; }
+}
+
+constexpr int LN_ROWS = 64;            // rows per block in the backward (4 waves x 16 rows)
+
+template <int NIT>
+__global__ void __launch_bounds__(256) ln_bwd_k(int64_t M, int C, const float* __restrict__ dy, const float* __restrict__ x,
+                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                const float* __restrict__ invstd, const float* __restrict__ dx_addend,
+                                                float* __restrict__ dx, float* __restrict__ partial /* [blocks][2][C] */) {
+  __shared__ float red[4][2][NIT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 ag[NIT], ab[NIT], gm[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane * 4 + 256 * it;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[it][e] = 0.f; ab[it][e] = 0.f; gm[it][e] = 0.f; }
+    if (i < C) gm[it] = *(const f32x4*)(gamma + i);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * LN_ROWS + wave * (LN_ROWS / 4);
+  for (int rr = 0; rr < LN_ROWS / 4; ++rr) {
+    const int64_t r = r0 + rr;
+    if (r >= M) break;
+    const float mu = mean[r], is = invstd[r];
+    f32x4 gv[NIT], xh[NIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = lane * 4 + 256 * it;
+      if (i < C) {
+        const f32x4 d = *(const f32x4*)(dy + r * C + i), v = *(const f32x4*)(x + r * C + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[it][e] = (v[e] - mu) * is;
+          gv[it][e] = d[e] * gm[it][e];
+          s1 += gv[it][e]; s2 += gv[it][e] * xh[it][e];
+          ag[it][e] += d[e] * xh[it][e]; ab[it][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = lane * 4 + 256 * it;
+      if (i < C) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = is * (gv[it][e] - s1 - xh[it][e] * s2);
+        if (dx_addend) { const f32x4 a = *(const f32x4*)(dx_addend + r * C + i); o += a; }
+        *(f32x4*)(dx + r * C + i) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][0][lane * 4 + 256 * it + e] = ag[it][e];
+      red[wave][1][lane * 4 + 256 * it + e] = ab[it][e];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    partial[((int64_t)blockIdx.x * 2 + 0) * C + i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+    partial[((int64_t)blockIdx.x * 2 + 1) * C + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+  }
+}
+
+__global__ void ln_bwd_finalize_k(int nblocks, int C, const float* __restrict__ partial, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  const int which = i / C, col = i - which * C;
+  double acc = 0.0;
+  for (int b = 0; b < nblocks; ++b) acc += (double)partial[((int64_t)b * 2 + which) * C + col];
+  float* out = which ? dbeta : dgamma;
+  out[col] = accumulate ? out[col] + (float)acc : (float)acc;
+}
+
+// ------------------------------------------------------------------------------------------------ GELU (erf form, nn.GELU default)
+__global__ void gelu_fwd_k(int64_t n4, const f32x4* __restrict__ x, f32x4* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = x[i];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+  y[i] = o;
+}
+__global__ void gelu_bwd_k(int64_t n4, const f32x4* __restrict__ x, const f32x4* __restrict__ dy, f32x4* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = x[i], g = dy[i];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float cdf = 0.5f * (1.f + erff(v[e] * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v[e] * v[e]);
+    o[e] = g[e] * (cdf + v[e] * pdf);
+  }
+  dx[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------------ token assembly
+__global__ void vit_embed_fwd_k(int64_t total, int T, int F, int P3, int patch, int H, int W, const float* __restrict__ img,
+                                const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ tok) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int f = (int)(i % F);
+  const int64_t bt = i / F;
+  const int t = (int)(bt % T);
+  const int64_t b = bt / T;
+  float v;
+  if (f >= P3) v = pos[(int64_t)t * (F - P3) + (f - P3)];
+  else if (t == 0) v = cls[f];
+  else {
+    const int pw = W / patch, pidx = t - 1, py = pidx / pw, px = pidx - py * pw;
+    const int pp = patch * patch, ch = f / pp, rem = f - ch * pp, kh = rem / patch, kw = rem - kh * patch;
+    v = img[((b * H + (py * patch + kh)) * (int64_t)W + (px * patch + kw)) * 3 + ch];      // NHWC image, (c, kh, kw) feature order
+  }
+  tok[i] = v;
+}
+
+// dcls[f] = sum_b dtok[b][0][f] (f < P3);  dpos[t][e] = sum_b dtok[b][t][P3+e]
+__global__ void vit_embed_bwd_k(int B, int T, int F, int P3, const float* __restrict__ dtok, float* __restrict__ dcls,
+                                float* __restrict__ dpos, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // over T*F
+  if (i >= T * F) return;
+  const int t = i / F, f = i - t * F;
+  if (f < P3 && t != 0) return;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) acc += (double)dtok[(int64_t)b * T * F + i];
+  float* out = f < P3 ? dcls + f : dpos + (int64_t)t * (F - P3) + (f - P3);
+  *out = accumulate ? *out + (float)acc : (float)acc;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
+                                 int32_t ld, float scale, float* o, int32_t ldo, float* lse, void* stream) {
+  SSV_REQUIRE(B > 0 && T > 0 && heads > 0 && q && k && v && o && lse, "ssv_attention_fwd: bad arguments");
+  SSV_REQUIRE(dh == DH, "ssv_attention_fwd: head size must be %d (got %d)", DH, dh);
+  SSV_REQUIRE(ld >= heads * dh && ldo >= heads * dh && ld % 4 == 0 && ldo % 4 == 0, "ssv_attention_fwd: row strides must cover heads*dh and be multiples of 4");
+  SSV_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "ssv_attention_fwd: pointers must be 16-byte aligned");
+  SSV_REQUIRE(B <= 65535 && heads <= 65535, "ssv_attention_fwd: grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_ATTN, s);
+  hipLaunchKernelGGL(attn_fwd_k, dim3(cdiv(T, 32), heads, B), dim3(64), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
+  SSV_CHECK_LAUNCH("attn_fwd_k");
+  return SSV_OK;
+}
+
+extern "C" int ssv_attention_bwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
+                                 int32_t ld, float scale, const float* o, const float* dout, int32_t ldo, const float* lse,
+                                 float* delta, float* dq, float* dk, float* dv, int32_t ldg, void* stream) {
+  SSV_REQUIRE(B > 0 && T > 0 && heads > 0 && q && k && v && o && dout && lse && delta && dq && dk && dv, "ssv_attention_bwd: bad arguments");
+  SSV_REQUIRE(dh == DH, "ssv_attention_bwd: head size must be %d (got %d)", DH, dh);
+  SSV_REQUIRE(ld >= heads * dh && ldo >= heads * dh && ldg >= heads * dh && ld % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0,
+              "ssv_attention_bwd: row strides must cover heads*dh and be multiples of 4");
+  SSV_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+              "ssv_attention_bwd: pointers must be 16-byte aligned");
+  SSV_REQUIRE(B <= 65535 && heads <= 65535, "ssv_attention_bwd: grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_ATTN, s);
+  const dim3 grid(cdiv(T, 32), heads, B);
+  hipLaunchKernelGGL(attn_bwd_dq_k, grid, dim3(64), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, ldg);
+  SSV_CHECK_LAUNCH("attn_bwd_dq_k");
+  hipLaunchKernelGGL(attn_bwd_dkv_k, grid, dim3(64), 0, s, T, heads, q, k, v, ld, scale, dout, ldo, lse, delta, dk, dv, ldg);
+  SSV_CHECK_LAUNCH("attn_bwd_dkv_k");
+  return SSV_OK;
+}
+
+extern "C" int ssv_layernorm_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta, const float* addend,
+                                 float eps, float* y, float* mean, float* invstd, void* stream) {
+  SSV_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && x && gamma && beta && y && mean && invstd, "ssv_layernorm_fwd: bad arguments (C %% 4 == 0)");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)addend | (uintptr_t)y) & 15) == 0, "ssv_layernorm_fwd: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_NORM, s);
+  hipLaunchKernelGGL(ln_fwd_k, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, s, M, C, x, gamma, beta, addend, eps, y, mean, invstd);
+  SSV_CHECK_LAUNCH("ln_fwd_k");
+  return SSV_OK;
+}
+
+extern "C" size_t ssv_layernorm_workspace_bytes(int64_t M, int32_t C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)cdiv64(M, LN_ROWS) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int ssv_layernorm_bwd(int64_t M, int32_t C, const float* dy, const float* x, const float* gamma, const float* mean,
+                                 const float* invstd, const float* dx_addend, float* dx, float* dgamma, float* dbeta,
+                                 int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 2048 && dy && x && gamma && mean && invstd && dx && dgamma && dbeta && ws,
+              "ssv_layernorm_bwd: bad arguments (C %% 4 == 0, C <= 2048)");
+  SSV_REQUIRE(ws_bytes >= ssv_layernorm_workspace_bytes(M, C), "ssv_layernorm_bwd: workspace too small");
+  SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx_addend | (uintptr_t)dx) & 15) == 0, "ssv_layernorm_bwd: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_NORM, s);
+  const int nblocks = (int)cdiv64(M, LN_ROWS);
+  float* partial = (float*)ws;
+  if (C <= 512) hipLaunchKernelGGL(ln_bwd_k<2>, dim3(nblocks), dim3(256), 0, s, M, C, dy, x, gamma, mean, invstd, dx_addend, dx, partial);
+  else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_k<4>, dim3(nblocks), dim3(256), 0, s, M, C, dy, x, gamma, mean, invstd, dx_addend, dx, partial);
+  else hipLaunchKernelGGL(ln_bwd_k<8>, dim3(nblocks), dim3(256), 0, s, M, C, dy, x, gamma, mean, invstd, dx_addend, dx, partial);
+  SSV_CHECK_LAUNCH("ln_bwd_k");
+  hipLaunchKernelGGL(ln_bwd_finalize_k, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, nblocks, C, partial, dgamma, dbeta, accumulate);
+  SSV_CHECK_LAUNCH("ln_bwd_finalize_k");
+  return SSV_OK;
+}
+
+extern "C" int ssv_gelu_fwd(int64_t n, const float* x, float* y, void* stream) {
+  SSV_REQUIRE(n > 0 && n % 4 == 0 && x && y && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "ssv_gelu_fwd: bad arguments (n %% 4 == 0, 16-byte aligned)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  hipLaunchKernelGGL(gelu_fwd_k, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, n / 4, (const f32x4*)x, (f32x4*)y);
+  SSV_CHECK_LAUNCH("gelu_fwd_k");
+  return SSV_OK;
+}
+
+extern "C" int ssv_gelu_bwd(int64_t n, const float* x, const float* dy, float* dx, void* stream) {
+  SSV_REQUIRE(n > 0 && n % 4 == 0 && x && dy && dx && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "ssv_gelu_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  hipLaunchKernelGGL(gelu_bwd_k, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, n / 4, (const f32x4*)x, (const f32x4*)dy, (f32x4*)dx);
+  SSV_CHECK_LAUNCH("gelu_bwd_k");
+  return SSV_OK;
+}
+
+extern "C" int ssv_vit_embed_fwd(int32_t B, int32_t H, int32_t W, int32_t patch, int32_t E, const float* img_nhwc,
+                                 const float* cls, const float* pos, float* tokens, void* stream) {
+  SSV_REQUIRE(B > 0 && H > 0 && W > 0 && patch > 0 && E >= 0 && H % patch == 0 && W % patch == 0 && img_nhwc && cls && pos && tokens,
+              "ssv_vit_embed_fwd: bad arguments (image size must be a multiple of the patch size)");
+  const int T = (H / patch) * (W / patch) + 1, P3 = 3 * patch * patch, F = P3 + E;
+  const int64_t total = (int64_t)B * T * F;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  hipLaunchKernelGGL(vit_embed_fwd_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, total, T, F, P3, patch, H, W, img_nhwc, cls, pos, tokens);
+  SSV_CHECK_LAUNCH("vit_embed_fwd_k");
+  return SSV_OK;
+}
+
+extern "C" int ssv_vit_embed_bwd(int32_t B, int32_t T, int32_t P3, int32_t E, const float* dtokens, float* dcls, float* dpos,
+                                 int32_t accumulate, void* stream) {
+  SSV_REQUIRE(B > 0 && T > 0 && P3 > 0 && E >= 0 && dtokens && dcls && dpos, "ssv_vit_embed_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  hipLaunchKernelGGL(vit_embed_bwd_k, dim3(cdiv(T * (P3 + E), 256)), dim3(256), 0, s, B, T, P3 + E, P3, dtokens, dcls, dpos, accumulate);
+  SSV_CHECK_LAUNCH("vit_embed_bwd_k");
+  return SSV_OK;
+}

@@ -234,3 +234,143 @@ def knn_label_agreement(z, labels, k):
     ws = torch.empty(_lib.load().ssv_knn_workspace_bytes(n), dtype=torch.uint8, device=z.device)    # up to ~1 GB: not kept in the training scratch
     call("ssv_knn_label_agreement", n, d, ptr(z), ptr(labels), int(k), ptr(count), ptr(ws), ws.numel(), stream())
     return int(count.item())
+
+
+# ------------------------------------------------------------------------------------------- ViT / DINO pieces
+LN_EPS = 1e-5
+
+
+def layernorm_fwd(x, gamma, beta, addend=None, eps=LN_EPS):
+    """y = LayerNorm(x) * gamma + beta (+ addend) over the last axis of a dense [M, C] matrix; returns (y, mean, invstd)."""
+    _lib._dev(x, gamma, beta, addend)
+    m, c = _rows(x)
+    y = torch.empty_like(x)
+    mean, invstd = _empty((m,), x), _empty((m,), x)
+    call("ssv_layernorm_fwd", m, c, ptr(x), ptr(gamma), ptr(beta), ptr(addend), float(eps), ptr(y), ptr(mean), ptr(invstd), stream())
+    return y, mean, invstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, invstd, dgamma, dbeta, dx_addend=None, accumulate=True):
+    _lib._dev(dy, x, dx_addend)
+    m, c = _rows(x)
+    dx = dx_addend if dx_addend is not None else torch.empty_like(x)      # in-place accumulate into the addend when given
+    ws = workspace.get(_lib.load().ssv_layernorm_workspace_bytes(m, c), x.device)
+    call("ssv_layernorm_bwd", m, c, ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx_addend), ptr(dx), ptr(dgamma), ptr(dbeta),
+         int(accumulate), ptr(ws), ws.numel(), stream())
+    return dx
+
+
+def gelu_fwd(x):
+    _lib._dev(x)
+    y = torch.empty_like(x)
+    call("ssv_gelu_fwd", x.numel(), ptr(x), ptr(y), stream())
+    return y
+
+
+def gelu_bwd(x, dy):
+    _lib._dev(x, dy)
+    dx = torch.empty_like(x)
+    call("ssv_gelu_bwd", x.numel(), ptr(x), ptr(dy), ptr(dx), stream())
+    return dx
+
+
+def _ld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.SsvError("attention operands must be [M, heads*dh] matrices with unit column stride")
+    return t.stride(0)
+
+
+def attention_fwd(q, k, v, batch, tokens, heads):
+    """softmax(q k^T / sqrt(dh)) v per (image, head); q/k/v: [batch*tokens, heads*dh] (may be column slices of one matrix)."""
+    _lib._dev(q, k, v)
+    hid = q.shape[1]
+    dh = hid // heads
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise _lib.SsvError("attention: q, k, v must share one row stride")
+    o = torch.empty((batch * tokens, hid), dtype=torch.float32, device=q.device)
+    lse = torch.empty((batch, heads, tokens), dtype=torch.float32, device=q.device)
+    call("ssv_attention_fwd", batch, tokens, heads, dh, ptr(q), ptr(k), ptr(v), _ld(q), dh ** -0.5, ptr(o), hid, ptr(lse), stream())
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, dout, lse, batch, tokens, heads, out=None):
+    """Returns (dq, dk, dv); with ``out`` = a [M, 3*hidden] matrix they are its three column blocks."""
+    _lib._dev(q, k, v, o, dout, lse)
+    hid = q.shape[1]
+    dh = hid // heads
+    if out is None:
+        dq, dk, dv = (torch.empty((batch * tokens, hid), dtype=torch.float32, device=q.device) for _ in range(3))
+    else:
+        dq, dk, dv = out[:, :hid], out[:, hid:2 * hid], out[:, 2 * hid:]
+    delta = torch.empty_like(lse)
+    call("ssv_attention_bwd", batch, tokens, heads, dh, ptr(q), ptr(k), ptr(v), _ld(q), dh ** -0.5, ptr(o), ptr(dout), _ld(o), ptr(lse),
+         ptr(delta), ptr(dq), ptr(dk), ptr(dv), _ld(dq), stream())
+    return dq, dk, dv
+
+
+def vit_embed_fwd(img_nhwc, cls, pos, patch):
+    """[B,H,W,3] image -> token matrix [B*T, 3*patch^2 + E] (cls row first, positional embedding concatenated)."""
+    _lib._dev(img_nhwc, cls, pos)
+    b, h, w, _ = img_nhwc.shape
+    e = pos.shape[1]
+    t = (h // patch) * (w // patch) + 1
+    if t > pos.shape[0]:
+        raise _lib.SsvError(f"vit_embed: {t} tokens but only {pos.shape[0]} positional embeddings")
+    tok = torch.empty((b * t, 3 * patch * patch + e), dtype=torch.float32, device=img_nhwc.device)
+    call("ssv_vit_embed_fwd", b, h, w, patch, e, ptr(img_nhwc), ptr(cls), ptr(pos), ptr(tok), stream())
+    return tok, t
+
+
+def vit_embed_bwd(dtok, batch, tokens, p3, e, dcls, dpos, accumulate=True):
+    _lib._dev(dtok, dcls, dpos)
+    call("ssv_vit_embed_bwd", batch, tokens, p3, e, ptr(dtok), ptr(dcls), ptr(dpos), int(accumulate), stream())
+
+
+def weightnorm_fwd(g, v):
+    _lib._dev(g, v)
+    w = torch.empty_like(v)
+    inv = _empty((v.shape[0],), v)
+    call("ssv_weightnorm_fwd", v.shape[0], v.shape[1], ptr(g), ptr(v), ptr(w), ptr(inv), stream())
+    return w, inv
+
+
+def weightnorm_bwd(dw, g, v, inv, dg, dv, accumulate=True):
+    _lib._dev(dw, g, v, inv, dg, dv)
+    call("ssv_weightnorm_bwd", v.shape[0], v.shape[1], ptr(dw), ptr(g), ptr(v), ptr(inv), ptr(dg), ptr(dv), int(accumulate), stream())
+
+
+def dino_loss(teacher, student, center, temp_s, temp_t, weight, loss, accumulate):
+    """teacher [bs,2,K], student [bs,V,K] (dense), center [K]; loss (0-d device tensor) (+)= weighted loss; returns dstudent."""
+    _lib._dev(teacher, student, center, loss)
+    bs, v, k = student.shape
+    if tuple(teacher.shape) != (bs, 2, k) or center.numel() != k:
+        raise _lib.SsvError(f"dino_loss: teacher {tuple(teacher.shape)} / center {tuple(center.shape)} do not match student {tuple(student.shape)}")
+    d = torch.empty_like(student)
+    ws = workspace.get(_lib.load().ssv_dino_loss_workspace_bytes(bs, v, k), student.device)
+    call("ssv_dino_loss", bs, v, k, ptr(teacher), ptr(student), ptr(center), float(temp_s), float(temp_t), float(weight), ptr(loss),
+         int(accumulate), ptr(d), ptr(ws), ws.numel(), stream())
+    return d
+
+
+def dino_center_update(center, t1, t2, momentum):
+    _lib._dev(center, t1, t2)
+    k = center.numel()
+    call("ssv_dino_center_update", k, t1.numel() // k, ptr(t1), 0 if t2 is None else t2.numel() // k, ptr(t2), float(momentum), ptr(center), stream())
+    return center
+
+
+def multicrop_params(batch, hs, ws_, ncrop, view_base, scale, seed, step, sample_ids=None, sample0=0, device=None):
+    boxes = torch.empty((batch, ncrop, 4), dtype=torch.int32, device=device if sample_ids is None else sample_ids.device)
+    call("ssv_multicrop_params", batch, hs, ws_, ncrop, view_base, float(scale[0]), float(scale[1]), int(seed), int(step), ptr(sample_ids),
+         int(sample0), ptr(boxes), stream())
+    return boxes
+
+
+def multicrop(views_nhwc, boxes, size):
+    """views [B,Hs,Ws,3] float, boxes [B,ncrop,4] int32 -> [B,ncrop,Ho,Wo,3] (crop + bicubic resize)."""
+    _lib._dev(views_nhwc, boxes)
+    b, hs, ws_, _ = views_nhwc.shape
+    ncrop = boxes.shape[1]
+    out = torch.empty((b, ncrop, size[0], size[1], 3), dtype=torch.float32, device=views_nhwc.device)
+    call("ssv_multicrop", b, hs, ws_, ptr(views_nhwc), ncrop, ptr(boxes), size[0], size[1], ptr(out), stream())
+    return out

@@ -1,0 +1,185 @@
+"""GPU: op-level parity of the ViT / DINO kernels against plain torch fp32/fp64 on the CPU (same seeded inputs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import seeded_randn
+from oracle import vit as ovit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _close(got, want, rtol, atol, msg=""):
+    np.testing.assert_allclose(got.detach().cpu().double().numpy(), want.detach().double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+@pytest.mark.parametrize("m,c", [(7, 384), (130, 384), (65, 512), (9, 1024), (5, 1536)])
+def test_layernorm_fwd_bwd(dev, m, c):
+    from ssv_amd import ops
+    x, g, b, add, dy = (seeded_randn(10 + i, *s) for i, s in enumerate(((m, c), (c,), (c,), (m, c), (m, c))))
+    xr, gr, br = x.double().requires_grad_(), g.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.layer_norm(xr, (c,), gr, br, 1e-5) + add.double()
+    ref.backward(dy.double())
+    y, mean, invstd = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), add.to(dev))
+    _close(y, ref, 1e-5, 1e-5)
+    dg, db = torch.full((c,), 1.0, device=dev), torch.full((c,), -2.0, device=dev)
+    dxa = seeded_randn(20, m, c)
+    dx = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, invstd, dg, db, dx_addend=dxa.to(dev).clone(), accumulate=True)
+    _close(dx, xr.grad + dxa.double(), 1e-4, 1e-5)
+    _close(dg, gr.grad + 1.0, 1e-4, 1e-4)
+    _close(db, br.grad - 2.0, 1e-4, 1e-4)
+
+
+def test_gelu_fwd_bwd(dev):
+    from ssv_amd import ops
+    x, dy = seeded_randn(1, 33, 768) * 3, seeded_randn(2, 33, 768)
+    xr = x.double().requires_grad_()
+    ref = F.gelu(xr)
+    ref.backward(dy.double())
+    _close(ops.gelu_fwd(x.to(dev)), ref, 1e-6, 1e-6)
+    _close(ops.gelu_bwd(x.to(dev), dy.to(dev)), xr.grad, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("b,t,heads", [(2, 65, 6), (3, 5, 6), (2, 197, 6), (1, 37, 2), (1, 32, 1), (2, 33, 3)])
+def test_attention_fwd_bwd(dev, b, t, heads):
+    from ssv_amd import ops
+    hid = heads * 64
+    qkv = seeded_randn(30 + t, b * t, 3 * hid)
+    dout = seeded_randn(31 + t, b * t, hid)
+    r = qkv.double().requires_grad_()
+    q, k, v = (r[:, i * hid:(i + 1) * hid].view(b, t, heads, 64).transpose(1, 2) for i in range(3))
+    probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(64), -1)
+    ref = (probs @ v).transpose(1, 2).reshape(b * t, hid)
+    ref.backward(dout.double())
+    dq = qkv.to(dev)
+    o, lse = ops.attention_fwd(dq[:, :hid], dq[:, hid:2 * hid], dq[:, 2 * hid:], b, t, heads)        # strided slices of one matrix
+    _close(o, ref, 1e-5, 2e-6)
+    grads = torch.empty_like(dq)
+    ops.attention_bwd(dq[:, :hid], dq[:, hid:2 * hid], dq[:, 2 * hid:], o, dout.to(dev), lse, b, t, heads, out=grads)
+    _close(grads, r.grad, 2e-4, 2e-6)
+    # dense operands too
+    qd, kd, vd = (dq[:, i * hid:(i + 1) * hid].contiguous() for i in range(3))
+    o2, _ = ops.attention_fwd(qd, kd, vd, b, t, heads)
+    assert torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("b,size,patch,e", [(3, 32, 4, 192), (2, 8, 4, 192), (2, 48, 16, 64)])
+def test_vit_embed_fwd_bwd(dev, b, size, patch, e):
+    from ssv_amd import ops
+    img = seeded_randn(40, b, 3, size, size)
+    n = (size // patch) ** 2
+    p3 = 3 * patch * patch
+    cls, pos = seeded_randn(41, 1, p3), seeded_randn(42, n + 3, e)
+    clsr, posr = cls.clone().requires_grad_(), pos.clone().requires_grad_()
+    x = ovit.unfold_patches(img, patch)
+    ref = torch.cat([torch.cat([clsr.expand(b, 1, -1), x], 1), posr[:n + 1].expand(b, -1, -1)], -1)
+    dtok = seeded_randn(43, b, n + 1, p3 + e)
+    ref.backward(dtok)
+    tok, t = ops.vit_embed_fwd(img.permute(0, 2, 3, 1).contiguous().to(dev), cls.to(dev), pos.to(dev), patch)
+    assert t == n + 1
+    assert torch.equal(tok.cpu().view(b, n + 1, -1), ref.detach())
+    dcls, dpos = torch.zeros(1, p3, device=dev), torch.zeros(n + 3, e, device=dev)
+    ops.vit_embed_bwd(dtok.to(dev), b, t, p3, e, dcls, dpos, accumulate=True)
+    _close(dcls, clsr.grad, 1e-5, 1e-6)
+    _close(dpos, posr.grad, 1e-5, 1e-6)
+
+
+def test_weightnorm_fwd_bwd(dev):
+    from ssv_amd import ops
+    g, v, dw = seeded_randn(50, 1024, 1).abs() + 0.5, seeded_randn(51, 1024, 512), seeded_randn(52, 1024, 512)
+    gr, vr = g.double().requires_grad_(), v.double().requires_grad_()
+    ref = ovit.weight_norm_weight(gr, vr)
+    ref.backward(dw.double())
+    w, inv = ops.weightnorm_fwd(g.to(dev), v.to(dev))
+    _close(w, ref, 1e-6, 1e-7)
+    dg, dv = torch.zeros(1024, 1, device=dev), torch.zeros(1024, 512, device=dev)
+    ops.weightnorm_bwd(dw.to(dev), g.to(dev), v.to(dev), inv, dg, dv, accumulate=True)
+    _close(dg, gr.grad, 1e-4, 1e-6)
+    _close(dv, vr.grad, 1e-4, 1e-6)
+
+
+def test_dino_loss_matches_reference_golden(dev, golden):
+    from ssv_amd import ops
+    g = golden["dino_level"]
+    t, st, c = seeded_randn(903, 4, 2, 64), seeded_randn(904, 4, 5, 64), seeded_randn(905, 1, 64)
+    loss = torch.zeros((), device=dev)
+    d = ops.dino_loss(t.to(dev), st.to(dev), c.to(dev).view(-1), 0.1, 0.04, 1.0, loss, accumulate=False)
+    np.testing.assert_allclose(loss.item(), g["dinoloss_value"], rtol=2e-6)
+    np.testing.assert_allclose(d.cpu().numpy(), g["dinoloss_dstudent"], rtol=1e-4, atol=1e-7)
+    # weight and accumulation
+    ops.dino_loss(t.to(dev), st.to(dev), c.to(dev).view(-1), 0.1, 0.04, 0.5, loss, accumulate=True)
+    np.testing.assert_allclose(loss.item(), 1.5 * g["dinoloss_value"], rtol=2e-6)
+
+
+def test_dino_loss_large_k_and_center_update(dev):
+    from ssv_amd import ops
+    bs, v, k = 6, 10, 1024
+    t, st, c = seeded_randn(60, bs, 2, k) * 3, seeded_randn(61, bs, v, k) * 2, seeded_randn(62, 1, k)
+    sr = st.double().requires_grad_()
+    ref = ovit.dino_loss(t.double(), sr, 0.1, 0.07, c.double())
+    ref.backward()
+    loss = torch.zeros((), device=dev)
+    d = ops.dino_loss(t.to(dev), st.to(dev), c.to(dev).view(-1), 0.1, 0.07, 1.0, loss, accumulate=False)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    _close(d, sr.grad, 1e-3, 1e-8)
+    cen = c.to(dev).view(-1).clone()
+    t2 = seeded_randn(63, bs, 2, k)
+    ops.dino_center_update(cen, t.to(dev), t2.to(dev), 0.9)
+    want = 0.9 * c + 0.1 * torch.cat((t.view(-1, k), t2.view(-1, k)), 0).mean(0)
+    _close(cen, want.view(-1), 1e-5, 1e-6)
+
+
+def test_adamw_matches_torch(dev):
+    from ssv_amd import _lib
+    n = 5000
+    p0, m0 = seeded_randn(70, n), None
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.04, eps=1e-6)
+    p = p0.to(dev).clone()
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        g = seeded_randn(70 + step, n) * 5
+        ref.grad = g.clamp(-3.0, 3.0)
+        opt.step()
+        _lib.call("ssv_adamw", n, _lib.ptr(p), _lib.ptr(g.to(dev)), 0, _lib.ptr(m), _lib.ptr(v), 1e-3, 0.9, 0.999, 1e-6, 0.04, step, 3.0, _lib.stream())
+        _close(p, ref, 1e-5, 1e-6, f"step {step}")
+
+
+def test_multicrop_bicubic_matches_torch_interpolate(dev):
+    from ssv_amd import ops
+    b = 3
+    views = seeded_randn(80, b, 3, 32, 32)
+    boxes = torch.tensor([[[0, 0, 32, 32], [4, 6, 8, 8], [3, 1, 20, 13], [10, 10, 5, 22]]] * b, dtype=torch.int32)
+    boxes[1, 2] = torch.tensor([0, 19, 32, 13])
+    for size in ((32, 32), (8, 8), (13, 7)):
+        got = ops.multicrop(views.permute(0, 2, 3, 1).contiguous().to(dev), boxes.to(dev), size).cpu()        # [b, ncrop, Ho, Wo, 3]
+        for i in range(b):
+            for c in range(boxes.shape[1]):
+                want = ovit.multicrop_resize(views[i], tuple(int(x) for x in boxes[i, c]), size)
+                np.testing.assert_allclose(got[i, c].permute(2, 0, 1).numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_multicrop_params_ranges_and_determinism(dev):
+    from ssv_amd import ops
+    ids = torch.arange(100, 612, device=dev, dtype=torch.int64)
+    a = ops.multicrop_params(512, 224, 224, 8, 16, (0.08, 0.3), 420, 3, sample_ids=ids)
+    b2 = ops.multicrop_params(512, 224, 224, 8, 16, (0.08, 0.3), 420, 3, sample_ids=ids)
+    assert torch.equal(a, b2)
+    c = ops.multicrop_params(512, 224, 224, 8, 16, (0.08, 0.3), 420, 4, sample_ids=ids)
+    assert not torch.equal(a, c)
+    bx = a.cpu().numpy().reshape(-1, 4).astype(np.float64)
+    area = bx[:, 2] * bx[:, 3] / (224.0 * 224.0)
+    ratio = bx[:, 3] / bx[:, 2]
+    assert area.min() > 0.07 and area.max() < 0.31 and 0.7 < ratio.min() and ratio.max() < 1.4
+    assert (bx[:, 0] >= 0).all() and (bx[:, 0] + bx[:, 2] <= 224).all() and (bx[:, 1] >= 0).all() and (bx[:, 1] + bx[:, 3] <= 224).all()
+    # the per-sample stream depends on the global sample id only
+    sub = ops.multicrop_params(8, 224, 224, 8, 16, (0.08, 0.3), 420, 3, sample_ids=ids[40:48].contiguous())
+    assert torch.equal(sub, a[40:48])
