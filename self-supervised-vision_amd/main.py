@@ -2,7 +2,7 @@
 
 The flag surface is the reference's (main.py:11-12,38-43), verbatim: -c/--config, -m/--arch, -a/--algo, -t/--task,
 -o/--output, -l/--load with the same choices, so scripts written for the reference keep working.  Algorithms outside the
-accelerated two-view path (moco, dino, pirl, simsiam, relic, deep_cluster, swav, sela) and the ViT encoder stay on the
+accelerated two-view path (moco, pirl, simsiam, relic, deep_cluster, swav, sela) stay on the
 surface and raise NotImplementedError.  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N main.py ...`.
 """
 import argparse
@@ -15,7 +15,7 @@ import numpy as np
 TASKS = ("train", "linear_eval", "get_features")
 NETWORKS = ("resnet18", "resnet50", "resnext50", "resnext101", "wide_resnet50", "wide_resnet101", "vit")
 # algo -> (module, class) for what is built; None marks flag values that exist but are not accelerated
-ALGORITHMS = {"simclr": ("simclr", "SimCLR"), "moco": None, "byol": ("byol", "BYOL"), "dino": None, "pirl": None,
+ALGORITHMS = {"simclr": ("simclr", "SimCLR"), "moco": None, "byol": ("byol", "BYOL"), "dino": ("dino", "DINO"), "pirl": None,
               "barlow": ("barlow", "BarlowTwins"), "simsiam": None, "relic": None, "deep_cluster": None, "swav": None, "sela": None}
 
 _FLAGS = (
@@ -49,8 +49,8 @@ def trainer_class(algo):
 
 def main(argv=None):
     args = parse(argv)
-    if args["arch"] == "vit":
-        raise NotImplementedError("--arch vit belongs to DINO, which is not on the accelerated path yet")
+    if (args["arch"] == "vit") != (args["algo"] == "dino"):
+        raise NotImplementedError("--arch vit and --algo dino go together: DINO is built on the ViT encoder, the two-view algorithms on ResNets")
     if args["task"] != "train" and args["load"] is None:
         raise NotImplementedError("For inference tasks, model checkpoint must be specified using --load")
     model = trainer_class(args["algo"])(args=args)

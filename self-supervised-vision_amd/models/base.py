@@ -51,15 +51,16 @@ class _Tracker:
 
 
 class TwoViewTrainer:
-    algo = None          # "simclr" | "byol" | "barlow": names the outputs/<algo>/ directory
+    algo = None          # "simclr" | "byol" | "barlow" | "dino": names the outputs/<algo>/ directory
+    archs = tuple(NETWORKS)
 
     def __init__(self, args):
         arch = args["arch"]
-        if arch not in NETWORKS:
-            raise AssertionError(f"Expected 'arch' to be one of {list(NETWORKS)}")
+        if arch not in self.archs:
+            raise AssertionError(f"Expected 'arch' to be one of {list(self.archs)}")
         run_root = os.path.join("outputs", self.algo, arch)
         self.config, self.output_dir, self.logger, self.device = common.initialize_experiment(args, run_root)
-        self.train_loader, self.test_loader = data_utils.get_double_augment_dataloaders(**self.config["data"], device=self.device)
+        self.train_loader, self.test_loader = self._make_loaders()
         self._tracker = _Tracker(self.config.get("wandb"), self.logger)
         self._build(arch)                                               # encoder, heads, self.optim, self.loss_fn
         sched_cfg = dict(self.config["scheduler"], epochs=self.config["epochs"])
@@ -83,6 +84,12 @@ class TwoViewTrainer:
 
     def _load_state(self, state):
         raise NotImplementedError
+
+    def _make_loaders(self):
+        return data_utils.get_double_augment_dataloaders(**self.config["data"], device=self.device)
+
+    def _after_epoch(self, epoch):
+        """Per-epoch schedules other than the learning rate (DINO: teacher EMA, weight decay, teacher temperature)."""
 
     def _after_step(self, step):
         """Called after every optimiser step with the within-epoch step index (BYOL: tau schedule + EMA)."""
@@ -174,6 +181,7 @@ class TwoViewTrainer:
             tag = "Epoch {:4d}/{:4d}".format(epoch, last)
             meter = self._run_epoch(tag)
             self.logger.write(f"{tag} " + meter.return_msg(), mode="train")
+            self._after_epoch(epoch)
             self.adjust_learning_rate(epoch)
             if epoch % self.config["eval_every"] == 0:
                 self._validate(epoch, tag)

@@ -220,11 +220,12 @@ def global_avgpool(tape, x):
     return y
 
 
-def linear(tape, x, weight, bias):
-    """x [B,Din] -> [B,Dout]: a 1x1 'convolution' over a 1x1 image on the same MFMA kernels."""
+def linear(tape, x, weight, bias, addend=None):
+    """x [M,Din] -> [M,Dout] (+ addend [M,Dout]): a 1x1 'convolution' over a 1x1 image on the same MFMA kernels."""
     b, din = x.shape
     x4 = x.view(b, 1, 1, din)
-    y4 = ops.conv2d_fwd(x4, weight, 1, 0, bias=bias)
+    a4 = None if addend is None else addend.view(b, 1, 1, -1)
+    y4 = ops.conv2d_fwd(x4, weight, 1, 0, bias=bias, addend=a4)
     y = y4.view(b, weight.shape[0])
     if tape is not None:
         need_dx = tape.needs_grad(x)
@@ -236,12 +237,101 @@ def linear(tape, x, weight, bias):
             ops.conv2d_wgrad(x4, dy4, weight, grad_of(weight, slot), 1, 0, accumulate=True)
             if bias is not None:
                 ops.colsum(dy, grad_of(bias, slot), accumulate=True)
+            dadd = None if addend is None else _accum(existing[1], dy)      # pass-through (dy is not needed again by its producer)
+            if not need_dx:
+                return (None, dadd)
+            ex = existing[0]
+            ex4 = None if ex is None else ex.view(b, 1, 1, din)
+            dx = ops.conv2d_dgrad(dy4, weight, x4.shape, 1, 0, addend=ex4, out=ex4)
+            return (dx.view(b, din), dadd)
+        tape.record((x, addend), y, bwd)
+    return y
+
+
+def layernorm(tape, x, ln, addend=None):
+    """LayerNorm(x) * weight + bias (+ addend) over the last axis of [M, C]."""
+    y, mean, invstd = ops.layernorm_fwd(x, ln.weight, ln.bias, addend, ln.eps)
+    if tape is not None:
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dx = ops.layernorm_bwd(dy, x, ln.weight, mean, invstd, grad_of(ln.weight, slot), grad_of(ln.bias, slot),
+                                   dx_addend=existing[0], accumulate=True)
+            return (dx, None if addend is None else _accum(existing[1], dy))
+        tape.record((x, addend), y, bwd)
+    return y
+
+
+def gelu(tape, x):
+    y = ops.gelu_fwd(x)
+    if tape is not None:
+        tape.record((x,), y, lambda dy, ex: (_accum(ex[0], ops.gelu_bwd(x, dy)),))
+    return y
+
+
+def attention(tape, q, k, v, batch, tokens, heads):
+    """softmax(q k^T / sqrt(dh)) v per (image, head) on [batch*tokens, heads*dh] matrices; probabilities are never stored."""
+    o, lse = ops.attention_fwd(q, k, v, batch, tokens, heads)
+    if tape is not None:
+        def bwd(dy, existing):
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, dy, lse, batch, tokens, heads)
+            return (_accum(existing[0], dq), _accum(existing[1], dk), _accum(existing[2], dv))
+        tape.record((q, k, v), o, bwd)
+    return o
+
+
+def vit_embed(tape, img_nhwc, cls_weight, pos_weight, patch):
+    """[B,H,W,3] -> ([B*T, 3 patch^2 + E] token rows, T); gradients go to the cls and positional embeddings only."""
+    tok, t = ops.vit_embed_fwd(img_nhwc, cls_weight, pos_weight, patch)
+    if tape is not None:
+        slot = tape.slot
+        b, p3, e = img_nhwc.shape[0], 3 * patch * patch, pos_weight.shape[1]
+
+        def bwd(dy, existing):
+            ops.vit_embed_bwd(dy, b, t, p3, e, grad_of(cls_weight, slot), grad_of(pos_weight, slot), accumulate=True)
+            return (None,)
+        tape.record((img_nhwc,), tok, bwd)
+    return tok, t
+
+
+def take_cls(tape, x, batch, tokens):
+    """Rows 0, T, 2T, ... of the token matrix: the [CLS] embeddings (networks/vit.py:116)."""
+    hid = x.shape[1]
+    y = x.view(batch, tokens, hid)[:, 0, :].contiguous()
+    if tape is not None:
+        def bwd(dy, existing):
+            dx = existing[0]
+            if dx is None:
+                dx = ops.fill_(torch.empty_like(x), 0.0)
+                dx.view(batch, tokens, hid)[:, 0, :].copy_(dy)
+            else:
+                dx.view(batch, tokens, hid)[:, 0, :].add_(dy)
+            return (dx,)
+        tape.record((x,), y, bwd)
+    return y
+
+
+def weightnorm_linear(tape, x, weight_g, weight_v, bias):
+    """nn.utils.weight_norm(nn.Linear): w = g * v / ||v||_row, y = x w^T + bias."""
+    w, inv = ops.weightnorm_fwd(weight_g, weight_v)
+    b, din = x.shape
+    x4 = x.view(b, 1, 1, din)
+    y = ops.conv2d_fwd(x4, w, 1, 0, bias=bias).view(b, w.shape[0])
+    if tape is not None:
+        need_dx = tape.needs_grad(x)
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dy4 = dy.view(b, 1, 1, -1)
+            dw = torch.empty_like(w)
+            ops.conv2d_wgrad(x4, dy4, w, dw, 1, 0, accumulate=False)
+            ops.weightnorm_bwd(dw, weight_g, weight_v, inv, grad_of(weight_g, slot), grad_of(weight_v, slot), accumulate=True)
+            ops.colsum(dy, grad_of(bias, slot), accumulate=True)
             if not need_dx:
                 return (None,)
             ex = existing[0]
             ex4 = None if ex is None else ex.view(b, 1, 1, din)
-            dx = ops.conv2d_dgrad(dy4, weight, x4.shape, 1, 0, addend=ex4, out=ex4)
-            return (dx.view(b, din),)
+            return (ops.conv2d_dgrad(dy4, w, x4.shape, 1, 0, addend=ex4, out=ex4).view(b, din),)
         tape.record((x,), y, bwd)
     return y
 
@@ -344,10 +434,24 @@ class HipBatchNorm(HipModule):
 
 
 class HipLinear(HipModule):
+    """``bias=False`` builds a bias-free layer (the ViT's query / key / value projections)."""
+
     def __init__(self, din, dout, weight=None, bias=None):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(dout, din) if weight is None else weight)
-        self.bias = nn.Parameter(torch.empty(dout) if bias is None else bias)
+        if bias is False:
+            self.register_parameter("bias", None)
+        else:
+            self.bias = nn.Parameter(torch.empty(dout) if bias is None else bias)
 
-    def _run(self, tape, x):
-        return linear(tape, x, self.weight, self.bias)
+    def _run(self, tape, x, addend=None):
+        return linear(tape, x, self.weight, self.bias, addend)
+
+
+class HipLayerNorm(HipModule):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.weight, self.bias, self.eps = nn.Parameter(torch.ones(dim)), nn.Parameter(torch.zeros(dim)), eps
+
+    def _run(self, tape, x, addend=None):
+        return layernorm(tape, x, self, addend)

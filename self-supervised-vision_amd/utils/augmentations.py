@@ -103,3 +103,31 @@ class GpuTransform:
 def get_transform(config):
     """YAML transform block -> GpuTransform (same entry point name as the reference)."""
     return GpuTransform(config)
+
+
+class MultiCrop:
+    """GPU form of the reference's MultiCrop (utils/augmentations.py:156-173): the two-view chain produces two augmented,
+    already normalised copies of every image; each copy then yields `num_global_views` crops (area scale (threshold, 1)) and
+    `num_local_views` crops (scale (0.08, threshold)), all resized bicubically on the float tensors.  Returns the batch dict
+    entries global_1, global_2 [B, Vg, 3, Hg, Wg] and local_1, local_2 [B, Vl, 3, Hl, Wl]."""
+
+    def __init__(self, config, seed=420):
+        self.num_local = int(config.get("num_local_views", 6))
+        self.num_global = int(config.get("num_global_views", 2))
+        self.scale = float(config.get("scale_threshold", 0.3))
+        self.global_size, self.local_size = tuple(config["global_size"]), tuple(config["local_size"])
+        self.transforms = get_transform(config["train_transforms"])
+        self.seed = seed
+
+    def __call__(self, images, idx, step):
+        from .. import ops
+        views = self.transforms.apply(images, idx, self.transforms.draw(images, idx, step, 2))     # [2, B, 3, H, W], NHWC memory
+        hs, ws = self.transforms.size
+        out = {}
+        for copy in range(2):
+            nhwc = views[copy].permute(0, 2, 3, 1)
+            for name, ncrop, scale, size, base in (("global", self.num_global, (self.scale, 1.0), self.global_size, 16),
+                                                   ("local", self.num_local, (0.08, self.scale), self.local_size, 144)):
+                boxes = ops.multicrop_params(idx.numel(), hs, ws, ncrop, base + 256 * copy, scale, self.seed, step, sample_ids=idx)
+                out[f"{name}_{copy + 1}"] = ops.multicrop(nhwc, boxes, size).permute(0, 1, 4, 2, 3)
+        return out

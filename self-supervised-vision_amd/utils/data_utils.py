@@ -88,3 +88,38 @@ def get_double_augment_dataloaders(dataset_name, root, transforms, batch_size, d
     train_loader = GpuTwoViewLoader(xtr, ytr, transforms, batch_size, True, device)
     test_loader = GpuTwoViewLoader(xte, yte, transforms, batch_size, False, device)
     return train_loader, test_loader
+
+
+class GpuMultiCropLoader(GpuTwoViewLoader):
+    """Iterates {img, global_1, global_2, local_1, local_2, label} batches (reference MultiCropDataset, utils/data_utils.py:76-92)."""
+
+    def __init__(self, images_u8, labels, multicrop_config, batch_size, shuffle, device, seed=420):
+        self.device = device
+        self.images = torch.from_numpy(images_u8).to(device)
+        self.labels = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(device)
+        self.batch_size, self.shuffle = int(batch_size), shuffle
+        self.multi_crop = augmentations.MultiCrop(multicrop_config)
+        self.test_tf = augmentations.get_transform(multicrop_config["test_transforms"])
+        self.gen = torch.Generator().manual_seed(seed)
+        self.step = 0
+
+    def __iter__(self):
+        n = self.images.shape[0]
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        for s in range(0, n, self.batch_size):
+            idx = order[s:s + self.batch_size].to(self.device)
+            batch = self.multi_crop(self.images, idx, self.step)
+            batch.update(img=self.test_tf.one_view(self.images, idx), label=self.labels[idx])
+            self.step += 1
+            yield batch
+
+
+def get_multicrop_dataloaders(dataset_name, root, multicrop_config, batch_size, device=None, synthetic=None):
+    assert synthetic is not None or dataset_name in DATASETS, \
+        f"Unrecognized dataset {dataset_name}, expected one of {list(DATASETS)}"
+    if synthetic is not None:
+        (xtr, ytr), (xte, yte) = _synthetic(synthetic, True), _synthetic(synthetic, False)
+    else:
+        (xtr, ytr), (xte, yte) = _load_cifar(root, dataset_name, True), _load_cifar(root, dataset_name, False)
+    return (GpuMultiCropLoader(xtr, ytr, multicrop_config, batch_size, True, device),
+            GpuMultiCropLoader(xte, yte, multicrop_config, batch_size, False, device))

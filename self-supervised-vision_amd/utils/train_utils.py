@@ -88,12 +88,50 @@ class FusedSGD(torch.optim.Optimizer):
         self._steps += 1
 
 
+class FusedAdamW(torch.optim.Optimizer):
+    """optim.AdamW(lr, weight_decay, eps, betas=(0.9, 0.999)) as ONE ssv_adamw launch over the arena.  ``clip`` > 0 clamps the
+    (summed) gradient element-wise first - the reference's DINO trainer does that with tensor hooks (models/dino.py:76-79)."""
+
+    def __init__(self, params, lr, weight_decay, eps=1e-6, betas=(0.9, 0.999), clip=0.0):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, weight_decay=weight_decay, eps=eps, betas=betas))
+        self.arena = ParamArena(params)
+        self.exp_avg = ops.fill_(torch.empty_like(self.arena.data), 0.0)
+        self.exp_avg_sq = ops.fill_(torch.empty_like(self.arena.data), 0.0)
+        self.clip = float(clip)
+        self._steps = 0
+        self.grad_sync = None
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        a = self.arena
+        from .. import nn as hnn
+        hnn.join_view_streams(a.data.device)
+        g2 = a.grad_alt
+        if self.grad_sync is not None:
+            ops.add_(a.grad, a.grad_alt)
+            self.grad_sync(a.grad)
+            g2 = None
+        self._steps += 1
+        _lib.call("ssv_adamw", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._steps,
+                  self.clip, _lib.stream())
+
+
 def get_optimizer(config, params):
     name = config.get("name", "sgd")
     if name == "sgd":
         return FusedSGD(params, lr=config["lr"], weight_decay=config["weight_decay"], momentum=0.9)
-    if name in ("adam", "adamw"):
-        raise NotImplementedError(f"optimizer {name} is used only by algorithms outside the accelerated path (DINO); not built yet")
+    if name == "adamw":
+        if config.get("amsgrad", False):
+            raise NotImplementedError("AdamW with amsgrad=True is not built (configs/dino.yaml uses amsgrad: False)")
+        return FusedAdamW(params, lr=config["lr"], weight_decay=config["weight_decay"], eps=config.get("epsilon", 1e-06))
+    if name == "adam":
+        raise NotImplementedError("optimizer adam (coupled weight decay) is not used by any accelerated algorithm; not built")
     raise NotImplementedError(f"Invalid optimizer {name}")
 
 

@@ -23,7 +23,7 @@ def test_vit_init_and_forward_match_reference(golden):
     p = ovit.init_vit(ENC)
     assert list(p) == [str(k) for k in g["vit_init_keys"]]                      # same keys, same order
     for k, ref in zip(g["vit_init_keys"], g["vit_init_sums"]):
-        np.testing.assert_array_equal(np.array(oracle.tensor_checksum(p[str(k)])), ref)      # same RNG stream: bit-equal
+        np.testing.assert_allclose(np.array(oracle.tensor_checksum(p[str(k)])), ref, rtol=1e-12, atol=0)      # same RNG stream
     with torch.no_grad():
         fg = ovit.vit_forward(p, ENC, seeded_randn(901, 3, 3, 32, 32))
         fl = ovit.vit_forward(p, ENC, seeded_randn(902, 5, 3, 8, 8))
@@ -46,8 +46,8 @@ def test_dino_two_steps_match_reference(golden):
     assert [k for k in m.student if not k.endswith("num_batches_tracked")] == [str(k) for k in g["dino_param_order"]]
     for params, tag in ((m.student, "student"), (m.teacher, "teacher")):
         for k, ref in zip(g[f"dino_{tag}_init_keys"], g[f"dino_{tag}_init_sums"]):
-            np.testing.assert_array_equal(np.array(oracle.tensor_checksum(params[str(k)])), ref)
-    np.testing.assert_array_equal(np.array(oracle.tensor_checksum(m.center)), g["dino_center_init"])
+            np.testing.assert_allclose(np.array(oracle.tensor_checksum(params[str(k)])), ref, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(np.array(oracle.tensor_checksum(m.center)), g["dino_center_init"], rtol=1e-12, atol=0)
     assert abs(m.lr - float(g["dino_lr"])) < 1e-18
     bs, vl = 4, 3
     losses = []
