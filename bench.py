@@ -72,11 +72,17 @@ def step_work(algo, h, w, batch):
     return 2.0 * macs_per_sample * batch, bytes_per_sample * batch
 
 
-ALGOS = {"simclr": ("ssv_amd.models.simclr", "SimCLR"), "byol": ("ssv_amd.models.byol", "BYOL"), "barlow": ("ssv_amd.models.barlow", "BarlowTwins")}
+ALGOS = {"simclr": ("ssv_amd.models.simclr", "SimCLR"), "byol": ("ssv_amd.models.byol", "BYOL"), "barlow": ("ssv_amd.models.barlow", "BarlowTwins"),
+         "dino": ("ssv_amd.models.dino", "DINO")}
+VITS16 = {"hidden_dim": 384, "embedding_dim": 192, "intermediate_dim": 1536, "num_attention_heads": 6, "patch_size": 16,
+          "num_local_patches": 36, "num_global_patches": 196, "num_encoder_layers": 12}          # ViT-S/16 in the reference's encoder vocabulary
+DINO_CROPS = {"num_global_views": 2, "num_local_views": 8, "global_size": [224, 224], "local_size": [96, 96], "scale_threshold": 0.3}
 BENCH_CFG = {   # the reference configs' hyper-parameters (configs/{simclr,byol,barlow}.yaml) with the std-stem encoder for 224x224
     "simclr": {"proj_dim": 128, "loss_fn": {"normalize": True, "temperature": 0.5}, "optimizer": {"name": "sgd", "lr": 2.0, "weight_decay": 1e-4}},
     "byol": {"proj_dim": 128, "tau": 0.996, "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1e-4}},
     "barlow": {"proj_dim": 4096, "loss_fn": {"normalize": True, "off_diagonal_weight": 0.005}, "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1.5e-6}},
+    "dino": {"encoder": VITS16, "proj_head": {"hidden_dim": 512, "proj_dim": 1024}, "gradient_clip": 3.0,
+             "optimizer": {"name": "adamw", "lr": 5e-4, "amsgrad": False, "epsilon": 1e-6, "weight_decay": 0.04}},
 }
 
 
@@ -92,17 +98,34 @@ def build(device, algo, steps_per_epoch=1000):
     t.config = {"epochs": 1000, "encoder": {"reduce_bottom_conv": False}, "scheduler": {"name": "cosine", "warmup_epochs": 10}, **BENCH_CFG[algo]}
     t.device, t.train_loader = device, [None] * steps_per_epoch
     torch.manual_seed(420)                                     # identical weights on every rank
-    t._build("resnet50")
+    t._build("vit" if algo == "dino" else "resnet50")
     t.scheduler, t.warmup_epochs = train_utils.get_scheduler({**t.config["scheduler"], "epochs": 1000}, optimizer=t.optim)   # lr seeded to lr/10
     hdist.attach_grad_sync(t.optim)
     state = {"i": 0}
 
-    def step(v1, v2):
-        loss = t.train_step({"aug_1": v1, "aug_2": v2})["loss"]
+    def step(batch):
+        loss = t.train_step(batch)["loss"]
         t._after_step(state["i"])                                # BYOL: tau schedule + EMA of the target, as in the train loop
         state["i"] += 1
         return loss
     return step, sum(p.numel() for p in t.optim.arena.params)
+
+
+def dino_work(batch):
+    """Algorithmic work of one DINO ViT-S/16 multi-crop step on one GPU: (GEMM FLOP of the Linear layers, attention FLOP).
+    Per sample the student sees 2 copies x (2 global 197-token + 8 local 37-token) crops forward+backward, the teacher the
+    4 global crops forward only.  Attention counts QK^T and PV forward and the four products of the backward (no recompute)."""
+    e, head = VITS16, BENCH_CFG["dino"]["proj_head"]
+    hid, inter, layers = e["hidden_dim"], e["intermediate_dim"], e["num_encoder_layers"]
+    per_token = layers * (3 * hid * hid + 2 * hid * inter) + (3 * e["patch_size"] ** 2 + e["embedding_dim"]) * hid
+    per_image_head = hid * head["hidden_dim"] + 2 * head["hidden_dim"] ** 2 + head["hidden_dim"] * head["proj_dim"]
+    tg, tl = e["num_global_patches"] + 1, e["num_local_patches"] + 1
+    ng, nl = 2 * DINO_CROPS["num_global_views"], 2 * DINO_CROPS["num_local_views"]
+    student_tokens, teacher_tokens = ng * tg + nl * tl, ng * tg
+    gemm_macs = 3 * (student_tokens * per_token + (ng + nl) * per_image_head) + teacher_tokens * per_token + ng * per_image_head
+    attn = lambda t: layers * t * t * hid                       # MACs of ONE T x T x hidden product over all heads
+    attn_macs = 6 * (ng * attn(tg) + nl * attn(tl)) + 2 * ng * attn(tg)
+    return 2.0 * gemm_macs * batch, 2.0 * attn_macs * batch
 
 
 AUG_CFG = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8},
@@ -118,6 +141,8 @@ def cpu_baseline(batch, size, steps, algo="simclr"):
     # dataloader-less single-socket run realistically uses.  `cores` below reports the threads actually used.
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    if algo == "dino":
+        return cpu_baseline_dino(cores)
     if algo == "byol":
         m = oracle.BYOLOracle("resnet50", False, 128, lr=0.02, weight_decay=1e-4)
     elif algo == "barlow":
@@ -135,12 +160,27 @@ def cpu_baseline(batch, size, steps, algo="simclr"):
             "sample": f"{steps} timed steps (1 warm-up) of the same {algo} ResNet-50 {size}x{size} step at batch {batch}, torch fp32 CPU"}
 
 
+def cpu_baseline_dino(cores, batch=2, steps=1):
+    from oracle import vit as ovit
+    m = ovit.DinoOracle(VITS16, BENCH_CFG["dino"]["proj_head"], lr=5e-4)
+    g = torch.Generator().manual_seed(7)
+    mk = lambda v, sz: torch.randn(batch, v, 3, sz, sz, generator=g)
+    args = (mk(2, 224), mk(2, 224), mk(8, 96), mk(8, 96))
+    m.train_step(*args)                                        # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step(*args)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed step (1 warm-up) of the same DINO ViT-S/16 multi-crop step at batch {batch}, torch fp32 CPU"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSV_BENCH_BATCH", "512")), help="per-GPU batch (images)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (images); default 512, 128 for --algo dino (BASELINE configs)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--algo", choices=tuple(ALGOS), default="simclr", help="simclr = BASELINE.json's metric; byol = its config 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,6 +197,8 @@ def main():
     device = torch.device("cuda", torch.cuda.current_device())
     _lib.load()
 
+    if args.batch is None:
+        args.batch = int(os.environ.get("SSV_BENCH_BATCH", "128" if args.algo == "dino" else "512"))
     b, s = args.batch, args.size
     from ssv_amd import nn as hnn
     train_step, nparams = build(device, args.algo)
@@ -170,13 +212,18 @@ def main():
     cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in AUG_CFG.items()}
     cfg["random_resized_crop"] = {"size": [s, s], "scale": [0.2, 1.0]}
     tf = augmentations.get_transform(cfg)
+    multi_crop = augmentations.MultiCrop({**DINO_CROPS, "train_transforms": cfg}) if args.algo == "dino" else None
     counter = [0]
 
     def step():
-        params = tf.draw(source, sample_ids, counter[0])          # RNG keyed by the GLOBAL sample id
-        views = tf.apply(source, rows, params)
+        if multi_crop is not None:                                # two augmented copies -> 2 x (2 global + 8 local) bicubic crops
+            batch = multi_crop(source, rows, counter[0], sample_ids=sample_ids)
+        else:
+            params = tf.draw(source, sample_ids, counter[0])      # RNG keyed by the GLOBAL sample id
+            views = tf.apply(source, rows, params)
+            batch = {"aug_1": views[0], "aug_2": views[1]}
         counter[0] += 1
-        return train_step(views[0], views[1])
+        return train_step(batch)
 
     def barrier():
         if world > 1:
@@ -200,7 +247,12 @@ def main():
     images_per_s = b * world * args.steps / dt
 
     # ---- per-kernel-class timing (HIP events on the launch stream) over extra instrumented steps --------------
-    conv_flop_step, algo_bytes_step = step_work(args.algo, s, s, b)           # per GPU and step; 2 FLOP/MAC
+    if args.algo == "dino":
+        conv_flop_step, attn_flop_step = dino_work(b)
+        algo_bytes_step = None
+    else:
+        conv_flop_step, algo_bytes_step = step_work(args.algo, s, s, b)       # per GPU and step; 2 FLOP/MAC
+        attn_flop_step = 0.0
     roof, classes = None, {}
     if args.prof_steps > 0:
         # per-kernel durations are only meaningful when kernels do not overlap: the instrumented steps run the two
@@ -228,25 +280,31 @@ def main():
             traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")), 1)
         except (OSError, KeyError, ValueError):
             pass
-        roof = {"bound": "mfma", "kernel": "conv implicit-GEMM family (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
+        attn_ms = prof.get("attn", (0.0, 0))[0] / args.prof_steps
+        roof = {"bound": "mfma", "kernel": ("implicit-GEMM family running the Linear layers" if args.algo == "dino" else "conv implicit-GEMM family") +
+                                           " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/r01_c_pmc_hbm_traffic_b%d.json)" % b,
-                "algorithmic_gb_per_step": round(algo_bytes_step / 1e9, 1),
+                "algorithmic_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
                 "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
-                "whole_step_mfma_frac": round(images_per_s / world * conv_flop_step / b / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "whole_step_mfma_frac": round(images_per_s / world * (conv_flop_step + attn_flop_step) / b / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "attention": None if not attn_flop_step else {"algorithmic_gflop_per_step": round(attn_flop_step / 1e9, 1), "kernel_ms_per_step": round(attn_ms, 3),
+                                                              "achieved_tflops": round(attn_flop_step / max(attn_ms, 1e-9) / 1e9, 2)},
                 "classes": classes}
 
-    label = {"simclr": "SimCLR", "byol": "BYOL", "barlow": "Barlow Twins"}[args.algo]
+    label = {"simclr": "SimCLR", "byol": "BYOL", "barlow": "Barlow Twins", "dino": "DINO"}[args.algo]
     loss_desc = {"simclr": "NT-Xent(normalize, T=0.5) over the global batch", "byol": "EMA target encoder (4 encoder passes), pair MSE of unit vectors",
-                 "barlow": "cross-correlation loss D=4096 over the global batch"}[args.algo]
+                 "barlow": "cross-correlation loss D=4096 over the global batch",
+                 "dino": "multi-crop 2 copies x (2 global 224 + 8 local 96), softmax-centering loss K=1024, AdamW + clamp"}[args.algo]
+    net_desc = "ViT-S/16 (reference encoder form)" if args.algo == "dino" else "resnet50 (7x7/2 stem)"
     out = {
-        "metric": f"images/sec (whole node) {label} ResNet-50 two-view train step", "value": round(images_per_s, 2), "unit": "images/sec",
+        "metric": f"images/sec (whole node) {label} {'ViT-S/16 multi-crop' if args.algo == 'dino' else 'ResNet-50 two-view'} train step", "value": round(images_per_s, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{label} resnet50 (7x7/2 stem) synthetic 3x{s}x{s}, bs={b}/GPU, global batch {b * world}, "
-                               f"{loss_desc}, SGD-Nesterov",
+        "config": {"workload": f"{label} {net_desc} synthetic 3x{s}x{s}, bs={b}/GPU, global batch {b * world}, "
+                               f"{loss_desc}" + ("" if args.algo == "dino" else ", SGD-Nesterov"),
                    "input": f"uint8 [B,{s},{s},3] source resident in HBM -> fused GPU two-view augmentation each step",
                    "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
                    "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if hnn.view_streams() else 1, "last_loss": loss},

@@ -119,15 +119,17 @@ class MultiCrop:
         self.transforms = get_transform(config["train_transforms"])
         self.seed = seed
 
-    def __call__(self, images, idx, step):
+    def __call__(self, images, idx, step, sample_ids=None):
+        """idx: rows of `images`; sample_ids (default idx): the GLOBAL sample ids that key the random streams."""
         from .. import ops
-        views = self.transforms.apply(images, idx, self.transforms.draw(images, idx, step, 2))     # [2, B, 3, H, W], NHWC memory
+        ids = idx if sample_ids is None else sample_ids
+        views = self.transforms.apply(images, idx, self.transforms.draw(images, ids, step, 2))     # [2, B, 3, H, W], NHWC memory
         hs, ws = self.transforms.size
         out = {}
         for copy in range(2):
             nhwc = views[copy].permute(0, 2, 3, 1)
             for name, ncrop, scale, size, base in (("global", self.num_global, (self.scale, 1.0), self.global_size, 16),
                                                    ("local", self.num_local, (0.08, self.scale), self.local_size, 144)):
-                boxes = ops.multicrop_params(idx.numel(), hs, ws, ncrop, base + 256 * copy, scale, self.seed, step, sample_ids=idx)
+                boxes = ops.multicrop_params(idx.numel(), hs, ws, ncrop, base + 256 * copy, scale, self.seed, step, sample_ids=ids)
                 out[f"{name}_{copy + 1}"] = ops.multicrop(nhwc, boxes, size).permute(0, 1, 4, 2, 3)
         return out

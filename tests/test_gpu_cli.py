@@ -46,3 +46,34 @@ def test_main_train_then_get_features(tmp_path, monkeypatch, algo, cfgname):
     assert f.shape == (48, cfg["proj_dim"]) and gt.shape == (48,)
     np.testing.assert_allclose(np.linalg.norm(f, axis=1), 1.0, rtol=1e-4)
     assert m2 is not None
+
+
+def test_main_dino_vit_train_then_get_features(tmp_path, monkeypatch):
+    """`-a dino -m vit`: multi-crop loader -> ViT student/teacher -> DINO loss -> AdamW, per-epoch schedules, kNN validation."""
+    from ssv_amd import main as cli
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "self-supervised-vision_amd", "configs", "dino.yaml")))
+    cfg["epochs"], cfg["eval_every"] = 2, 1
+    cfg["data"]["batch_size"] = 16
+    cfg["data"]["synthetic"] = {"num_train": 40, "num_test": 48, "image_size": [32, 32], "num_classes": 10}
+    cfg["encoder"]["num_encoder_layers"] = 2
+    cfg["linear_eval"]["epochs"] = 3
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.dump(cfg, sort_keys=False))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("WANDB_MODE", "disabled")
+    model = cli.main(["-c", str(path), "-a", "dino", "-m", "vit", "-t", "train", "-o", "run"])
+    out = tmp_path / "outputs" / "dino" / "vit" / "run"
+    log = (out / "trainlogs.txt").read_text()
+    assert "[TRAIN] Epoch    2/   2 [loss]" in log and "[VALID] Epoch    2/   2 [accuracy]" in log and (out / "best_model.pt").exists()
+    state = torch.load(out / "best_model.pt", map_location="cpu")["encoder"]
+    assert list(state)[0] == "encoder.projection_fc.weight" and list(state)[-1] == "fc_out.weight_v"
+    # after two epochs: the schedules of models/dino.py:226-229
+    assert abs(model.temp_teacher - (0.04 + 0.03 * 2 / 30)) < 1e-12
+    assert abs(model.optim.param_groups[0]["lr"] - (1e-12 + 2 * (1e-4 - 1e-12) / 10)) < 1e-12
+    assert abs(model.optim.param_groups[0]["weight_decay"] - 0.4) < 1e-12          # cosine ramp 0.04 -> 0.4 reaches its top at the last epoch
+    assert np.isfinite(model.optim.arena.data.cpu().numpy()).all() and np.isfinite(model.teacher_center.cpu().numpy()).all()
+    with pytest.raises(NotImplementedError):
+        cli.main(["-c", str(path), "-a", "dino", "-m", "resnet18", "-t", "train", "-o", "x"])
+    cli.main(["-c", str(path), "-a", "dino", "-m", "vit", "-t", "get_features", "-o", "feat", "-l", str(out)])
+    f = np.load(tmp_path / "outputs" / "dino" / "vit" / "feat" / "test_fvecs.npy")
+    assert f.shape == (48, 1024) and np.isfinite(f).all()
