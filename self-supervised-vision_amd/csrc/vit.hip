@@ -52,12 +52,54 @@ __device__ __forceinline__ void store_tile_T(float* __restrict__ base, int64_t r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ attention, shared pieces
+// A workgroup = NW wavefronts = NW consecutive 32-row tiles of ONE (image, head).  The tiles it streams over (keys/values in the
+// forward and dQ passes, queries/dO in the dK/dV pass) are staged once per workgroup into LDS with coalesced 16-byte loads
+// (row stride 68 floats: conflict-free ds_read_b128 of a 32-float row fragment) and double-buffered: the global loads of tile
+// t+1 are in flight while the MFMAs of tile t run.
+constexpr int TS = 68;                                        // LDS row stride (floats) of a staged 32 x 64 tile
+
+template <int NW>
+struct Stage {                                                // registers holding one thread's share of two 32x64 tiles
+  static constexpr int N4 = 512 / (NW * 64);                  // float4 per thread per tile
+  f32x4 a[N4], b[N4];
+  __device__ __forceinline__ void load(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int row0, int T) {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
+      const int64_t row = min(row0 + r, T - 1);
+      a[i] = *(const f32x4*)(A + row * lda + c4);
+      b[i] = *(const f32x4*)(B + row * ldb + c4);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ sa, float* __restrict__ sb) const {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
+      *(f32x4*)(sa + r * TS + c4) = a[i];
+      *(f32x4*)(sb + r * TS + c4) = b[i];
+    }
+  }
+};
+
+__device__ __forceinline__ void lds_row32(const float* __restrict__ tile, int row, int half, float* __restrict__ r) {
+  const float* p = tile + row * TS + half * 32;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 v = *(const f32x4*)(p + 4 * i);
+    r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ attention forward
-__global__ void __launch_bounds__(64) attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
-                                                 const float* __restrict__ V, int ld, float scale,
-                                                 float* __restrict__ O, int ldo, float* __restrict__ LSE) {
-  const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
-  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                      const float* __restrict__ V, int ld, float scale,
+                                                      float* __restrict__ O, int ldo, float* __restrict__ LSE) {
+  __shared__ float sk[2][32 * TS], sv[2][32 * TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
+  const int q0 = (blockIdx.x * NW + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const bool active = q0 < T;                                 // a trailing wave only helps staging
   const int64_t tok0 = (int64_t)b * T;
   const int qrow = min(q0 + c, T - 1);
   float qreg[32];
@@ -66,39 +108,46 @@ __global__ void __launch_bounds__(64) attn_fwd_k(int T, int heads, const float* 
   float m = -INFINITY, l = 0.f;
   const float* kbase = K + tok0 * ld + h * DH;
   const float* vbase = V + tok0 * ld + h * DH;
-  for (int k0 = 0; k0 < T; k0 += 32) {
-    float kreg[32], vlo[16], vhi[16];
-    load_row32(kbase + (int64_t)min(k0 + c, T - 1) * ld + half * 32, kreg, 1.f);
+  Stage<NW> st;
+  st.load(kbase, ld, vbase, ld, 0, T);
+  st.store(sk[0], sv[0]);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < T; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < T;
+    if (more) st.load(kbase, ld, vbase, ld, k0 + 32, T);
+    if (active) {
+      float kreg[32];
+      lds_row32(sk[buf], c, half, kreg);
+      f32x16 s = zero16();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float* vr = vbase + (int64_t)min(k0 + rowof(j, half), T - 1) * ld;
-      vlo[j] = vr[c]; vhi[j] = vr[32 + c];
+      for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], qreg[i], s, 0, 0, 0);
+      float mt = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (k0 + rowof(j, half) >= T) s[j] = -INFINITY;
+        mt = fmaxf(mt, s[j]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m, mt);
+      const float alpha = expf(m - mn);                       // m = -inf on the first tile -> 0
+      float ls = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { s[j] = expf(s[j] - mn); ls += s[j]; }
+      ls += __shfl_xor(ls, 32, 64);
+      l = l * alpha + ls;
+      m = mn;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { o_lo[j] *= alpha; o_hi[j] *= alpha; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float* vr = sv[buf] + rowof(j, half) * TS;
+        o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[c], s[j], o_lo, 0, 0, 0);
+        o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 + c], s[j], o_hi, 0, 0, 0);
+      }
     }
-    f32x16 s = zero16();
-#pragma unroll
-    for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], qreg[i], s, 0, 0, 0);
-    float mt = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (k0 + rowof(j, half) >= T) s[j] = -INFINITY;
-      mt = fmaxf(mt, s[j]);
-    }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
-    const float alpha = expf(m - mn);                       // m = -inf on the first tile -> 0
-    float ls = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { s[j] = expf(s[j] - mn); ls += s[j]; }
-    ls += __shfl_xor(ls, 32, 64);
-    l = l * alpha + ls;
-    m = mn;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { o_lo[j] *= alpha; o_hi[j] *= alpha; }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vlo[j], s[j], o_lo, 0, 0, 0);
-      o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vhi[j], s[j], o_hi, 0, 0, 0);
-    }
+    if (more) st.store(sk[buf ^ 1], sv[buf ^ 1]);
+    __syncthreads();
   }
   const bool valid = q0 + c < T;
   store_tile_T(O + tok0 * ldo + h * DH, ldo, q0 + c, valid, half, o_lo, o_hi, 1.f / l);
@@ -106,13 +155,16 @@ __global__ void __launch_bounds__(64) attn_fwd_k(int T, int heads, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward: dQ (and delta)
-__global__ void __launch_bounds__(64) attn_bwd_dq_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
-                                                    const float* __restrict__ V, int ld, float scale,
-                                                    const float* __restrict__ O, const float* __restrict__ dO, int ldo,
-                                                    const float* __restrict__ LSE, float* __restrict__ DELTA,
-                                                    float* __restrict__ dQ, int ldg) {
-  const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
-  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ V, int ld, float scale,
+                                                         const float* __restrict__ O, const float* __restrict__ dO, int ldo,
+                                                         const float* __restrict__ LSE, float* __restrict__ DELTA,
+                                                         float* __restrict__ dQ, int ldg) {
+  __shared__ float sk[2][32 * TS], sv[2][32 * TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
+  const int q0 = (blockIdx.x * NW + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const bool active = q0 < T;
   const int64_t tok0 = (int64_t)b * T;
   const int qrow = min(q0 + c, T - 1);
   float qreg[32], doreg[32];
@@ -135,42 +187,51 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_k(int T, int heads, const floa
   f32x16 g_lo = zero16(), g_hi = zero16();
   const float* kbase = K + tok0 * ld + h * DH;
   const float* vbase = V + tok0 * ld + h * DH;
-  for (int k0 = 0; k0 < T; k0 += 32) {
-    float kreg[32], vreg[32], klo[16], khi[16];
-    const int krow = min(k0 + c, T - 1);
-    load_row32(kbase + (int64_t)krow * ld + half * 32, kreg, 1.f);
-    load_row32(vbase + (int64_t)krow * ld + half * 32, vreg, 1.f);
+  Stage<NW> st;
+  st.load(kbase, ld, vbase, ld, 0, T);
+  st.store(sk[0], sv[0]);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < T; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < T;
+    if (more) st.load(kbase, ld, vbase, ld, k0 + 32, T);
+    if (active) {
+      float kreg[32];
+      f32x16 s = zero16(), dp = zero16();
+      lds_row32(sk[buf], c, half, kreg);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float* kr = kbase + (int64_t)min(k0 + rowof(j, half), T - 1) * ld;
-      klo[j] = kr[c]; khi[j] = kr[32 + c];
+      for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], qreg[i], s, 0, 0, 0);
+      lds_row32(sv[buf], c, half, kreg);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], doreg[i], dp, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float p = (k0 + rowof(j, half) < T) ? expf(s[j] - lse) : 0.f;
+        s[j] = p * (dp[j] - delta);                            // dS^T
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float* kr = sk[buf] + rowof(j, half) * TS;
+        g_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[c], s[j], g_lo, 0, 0, 0);
+        g_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[32 + c], s[j], g_hi, 0, 0, 0);
+      }
     }
-    f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-    for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], qreg[i], s, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[i], doreg[i], dp, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float p = (k0 + rowof(j, half) < T) ? expf(s[j] - lse) : 0.f;
-      s[j] = p * (dp[j] - delta);                            // dS^T
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      g_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(klo[j], s[j], g_lo, 0, 0, 0);
-      g_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(khi[j], s[j], g_hi, 0, 0, 0);
-    }
+    if (more) st.store(sk[buf ^ 1], sv[buf ^ 1]);
+    __syncthreads();
   }
   store_tile_T(dQ + tok0 * ldg + h * DH, ldg, q0 + c, valid, half, g_lo, g_hi, scale);
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward: dK, dV
-__global__ void __launch_bounds__(64) attn_bwd_dkv_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
-                                                     const float* __restrict__ V, int ld, float scale,
-                                                     const float* __restrict__ dO, int ldo, const float* __restrict__ LSE,
-                                                     const float* __restrict__ DELTA, float* __restrict__ dK, float* __restrict__ dV, int ldg) {
-  const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
-  const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                          const float* __restrict__ V, int ld, float scale,
+                                                          const float* __restrict__ dO, int ldo, const float* __restrict__ LSE,
+                                                          const float* __restrict__ DELTA, float* __restrict__ dK, float* __restrict__ dV, int ldg) {
+  __shared__ float sq[2][32 * TS], sd[2][32 * TS], sstat[2][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
+  const int k0 = (blockIdx.x * NW + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const bool active = k0 < T;
   const int64_t tok0 = (int64_t)b * T;
   const int krow = min(k0 + c, T - 1);
   const bool kvalid = k0 + c < T;
@@ -181,39 +242,54 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_k(int T, int heads, const flo
   f32x16 dk_lo = zero16(), dk_hi = zero16(), dv_lo = zero16(), dv_hi = zero16();
   const float* qbase = Q + tok0 * ld + h * DH;
   const float* dobase = dO + tok0 * ldo + h * DH;
-  for (int q0 = 0; q0 < T; q0 += 32) {
-    float qreg[32], doreg[32];
-    const int qrow = min(q0 + c, T - 1);
-    load_row32(qbase + (int64_t)qrow * ld + half * 32, qreg, scale);
-    load_row32(dobase + (int64_t)qrow * ldo + half * 32, doreg, 1.f);
-    f32x16 s = zero16(), dp = zero16();
+  Stage<NW> st;
+  float st_stat = 0.f;                                        // threads 0..31: lse, 32..63: delta of the staged query rows
+  auto load_stat = [&](int q0) {
+    if (threadIdx.x < 64) st_stat = (threadIdx.x < 32 ? LSE : DELTA)[stat + min(q0 + (int)(threadIdx.x & 31), T - 1)];
+  };
+  st.load(qbase, ld, dobase, ldo, 0, T);
+  load_stat(0);
+  st.store(sq[0], sd[0]);
+  if (threadIdx.x < 64) sstat[0][threadIdx.x >> 5][threadIdx.x & 31] = st_stat;
+  __syncthreads();
+  int buf = 0;
+  for (int q0 = 0; q0 < T; q0 += 32, buf ^= 1) {
+    const bool more = q0 + 32 < T;
+    if (more) { st.load(qbase, ld, dobase, ldo, q0 + 32, T); load_stat(q0 + 32); }
+    if (active) {
+      float qreg[32];
+      f32x16 s = zero16(), dp = zero16();
+      lds_row32(sq[buf], c, half, qreg);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i], kreg[i], s, 0, 0, 0);        // rows = query, col = key
+      for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i] * scale, kreg[i], s, 0, 0, 0);   // rows = query, col = key
+      lds_row32(sd[buf], c, half, qreg);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(doreg[i], vreg[i], dp, 0, 0, 0);
-    float qlo[16], qhi[16], dlo[16], dhi[16];
+      for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i], vreg[i], dp, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int qi = q0 + rowof(j, half);
-      const int qr = min(qi, T - 1);
-      const float p = (qi < T && kvalid) ? expf(s[j] - LSE[stat + qr]) : 0.f;
-      s[j] = p;                                              // P
-      dp[j] = p * (dp[j] - DELTA[stat + qr]);                // dS
-      const float* qr_p = qbase + (int64_t)qr * ld;
-      const float* do_p = dobase + (int64_t)qr * ldo;
-      qlo[j] = qr_p[c]; qhi[j] = qr_p[32 + c];
-      dlo[j] = do_p[c]; dhi[j] = do_p[32 + c];
+      for (int j = 0; j < 16; ++j) {
+        const int r = rowof(j, half);
+        const float p = (q0 + r < T && kvalid) ? expf(s[j] - sstat[buf][0][r]) : 0.f;
+        s[j] = p;                                              // P
+        dp[j] = p * (dp[j] - sstat[buf][1][r]);                // dS
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float* qr = sq[buf] + rowof(j, half) * TS;
+        const float* dr = sd[buf] + rowof(j, half) * TS;
+        dv_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[c], s[j], dv_lo, 0, 0, 0);
+        dv_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[32 + c], s[j], dv_hi, 0, 0, 0);
+        dk_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[c], dp[j], dk_lo, 0, 0, 0);
+        dk_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 + c], dp[j], dk_hi, 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      dv_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(dlo[j], s[j], dv_lo, 0, 0, 0);
-      dv_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(dhi[j], s[j], dv_hi, 0, 0, 0);
-      dk_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(qlo[j], dp[j], dk_lo, 0, 0, 0);
-      dk_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(qhi[j], dp[j], dk_hi, 0, 0, 0);
+    if (more) {
+      st.store(sq[buf ^ 1], sd[buf ^ 1]);
+      if (threadIdx.x < 64) sstat[buf ^ 1][threadIdx.x >> 5][threadIdx.x & 31] = st_stat;
     }
+    __syncthreads();
   }
-  store_tile_T(dK + tok0 * ldg + h * DH, ldg, k0 + c, kvalid, half, dk_lo, dk_hi, scale);
-  store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid, half, dv_lo, dv_hi, 1.f);
+  store_tile_T(dK + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dk_lo, dk_hi, scale);
+  store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dv_lo, dv_hi, 1.f);
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -248,7 +324,7 @@ __global__ void __launch_bounds__(256) ln_fwd_k(int64_t M, int C, const float* _
   if (lane == 0) { mean_out[r] = mean; invstd_out[r] = invstd; }
 }
 
-constexpr int LN_ROWS = 64;            // rows per block in the backward (4 waves x 16 rows)
+constexpr int LN_ROWS = 256;           // rows per block in the backward (4 waves x 64 rows)
 
 template <int NIT>
 __global__ void __launch_bounds__(256) ln_bwd_k(int64_t M, int C, const float* __restrict__ dy, const float* __restrict__ x,
@@ -313,15 +389,27 @@ __global__ void __launch_bounds__(256) ln_bwd_k(int64_t M, int C, const float* _
   }
 }
 
-__global__ void ln_bwd_finalize_k(int nblocks, int C, const float* __restrict__ partial, float* __restrict__ dgamma,
-                                  float* __restrict__ dbeta, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  const int which = i / C, col = i - which * C;
+// 32 columns x 8 partial sums per block; the 8 partials are combined in fixed order: deterministic
+__global__ void __launch_bounds__(256) ln_bwd_finalize_k(int nblocks, int C, const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int accumulate) {
+  __shared__ double sh[8][32];
+  const int col_in = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + col_in;                     // over 2*C
   double acc = 0.0;
-  for (int b = 0; b < nblocks; ++b) acc += (double)partial[((int64_t)b * 2 + which) * C + col];
-  float* out = which ? dbeta : dgamma;
-  out[col] = accumulate ? out[col] + (float)acc : (float)acc;
+  int which = 0, col = 0;
+  if (i < 2 * C) {
+    which = i / C; col = i - which * C;
+    for (int b = grp; b < nblocks; b += 8) acc += (double)partial[((int64_t)b * 2 + which) * C + col];
+  }
+  sh[grp][col_in] = acc;
+  __syncthreads();
+  if (grp == 0 && i < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += sh[g][col_in];
+    float* out = which ? dbeta : dgamma;
+    out[col] = accumulate ? out[col] + (float)t : (float)t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ GELU (erf form, nn.GELU default)
@@ -393,7 +481,8 @@ extern "C" int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh
   SSV_REQUIRE(B <= 65535 && heads <= 65535, "ssv_attention_fwd: grid too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_ATTN, s);
-  hipLaunchKernelGGL(attn_fwd_k, dim3(cdiv(T, 32), heads, B), dim3(64), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
+  if (T <= 64) hipLaunchKernelGGL(attn_fwd_k<2>, dim3(cdiv(T, 64), heads, B), dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
+  else hipLaunchKernelGGL(attn_fwd_k<4>, dim3(cdiv(T, 128), heads, B), dim3(256), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
   SSV_CHECK_LAUNCH("attn_fwd_k");
   return SSV_OK;
 }
@@ -410,10 +499,17 @@ extern "C" int ssv_attention_bwd(int32_t B, int32_t T, int32_t heads, int32_t dh
   SSV_REQUIRE(B <= 65535 && heads <= 65535, "ssv_attention_bwd: grid too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_ATTN, s);
-  const dim3 grid(cdiv(T, 32), heads, B);
-  hipLaunchKernelGGL(attn_bwd_dq_k, grid, dim3(64), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, ldg);
-  SSV_CHECK_LAUNCH("attn_bwd_dq_k");
-  hipLaunchKernelGGL(attn_bwd_dkv_k, grid, dim3(64), 0, s, T, heads, q, k, v, ld, scale, dout, ldo, lse, delta, dk, dv, ldg);
+  if (T <= 64) {
+    const dim3 grid(cdiv(T, 64), heads, B);
+    hipLaunchKernelGGL(attn_bwd_dq_k<2>, grid, dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, ldg);
+    SSV_CHECK_LAUNCH("attn_bwd_dq_k");
+    hipLaunchKernelGGL(attn_bwd_dkv_k<2>, grid, dim3(128), 0, s, T, heads, q, k, v, ld, scale, dout, ldo, lse, delta, dk, dv, ldg);
+  } else {
+    const dim3 grid(cdiv(T, 128), heads, B);
+    hipLaunchKernelGGL(attn_bwd_dq_k<4>, grid, dim3(256), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, ldg);
+    SSV_CHECK_LAUNCH("attn_bwd_dq_k");
+    hipLaunchKernelGGL(attn_bwd_dkv_k<4>, grid, dim3(256), 0, s, T, heads, q, k, v, ld, scale, dout, ldo, lse, delta, dk, dv, ldg);
+  }
   SSV_CHECK_LAUNCH("attn_bwd_dkv_k");
   return SSV_OK;
 }
@@ -449,7 +545,7 @@ extern "C" int ssv_layernorm_bwd(int64_t M, int32_t C, const float* dy, const fl
   else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_k<4>, dim3(nblocks), dim3(256), 0, s, M, C, dy, x, gamma, mean, invstd, dx_addend, dx, partial);
   else hipLaunchKernelGGL(ln_bwd_k<8>, dim3(nblocks), dim3(256), 0, s, M, C, dy, x, gamma, mean, invstd, dx_addend, dx, partial);
   SSV_CHECK_LAUNCH("ln_bwd_k");
-  hipLaunchKernelGGL(ln_bwd_finalize_k, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, nblocks, C, partial, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_bwd_finalize_k, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, nblocks, C, partial, dgamma, dbeta, accumulate);
   SSV_CHECK_LAUNCH("ln_bwd_finalize_k");
   return SSV_OK;
 }

@@ -151,9 +151,13 @@ class DINO(TwoViewTrainer):
         vl = l1.shape[1]
         glob = torch.cat((g1.flatten(0, 1), g2.flatten(0, 1)), 0)          # [2*bs*vg, 3, hg, wg]: both copies' crops in one pass
         loc = torch.cat((l1.flatten(0, 1), l2.flatten(0, 1)), 0)
-        student_g, student_l = self.student_model(glob), self.student_model(loc)
-        with torch.no_grad():
-            teacher_g = self.teacher_model(glob)
+        with hnn.parallel_views(self.device) as pv:      # independent passes on two HIP streams: MFMA-bound GEMMs of one overlap
+            with pv.view(0):                             # the HBM-bound LayerNorm / GELU kernels of the other
+                student_g = self.student_model(glob)
+            with pv.view(1):
+                student_l = self.student_model(loc)
+                with torch.no_grad():
+                    teacher_g = self.teacher_model(glob)
         loss = self.loss_fn(student_g, student_l, teacher_g, self.teacher_center.view(-1), bs, vg, vl, self.temp_student, self.temp_teacher)
         ng = bs * vg
         self.update_teacher_center(teacher_g[:ng], teacher_g[ng:])
