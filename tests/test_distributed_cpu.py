@@ -104,6 +104,16 @@ def _emu_barlow_cgrad(craw, inv_b, lmbda):
     return (wgt * (c - eye) ** 2).sum().reshape(()), 2 * wgt * (c - eye) * inv_b
 
 
+def _emu_dino_loss(teacher, student, center, temp_s, temp_t, weight, loss, accumulate):
+    from oracle import vit as ovit
+    with torch.enable_grad():                                    # called from inside autograd.Function.forward
+        st = student.clone().requires_grad_()
+        val = weight * ovit.dino_loss(teacher, st, temp_s, temp_t, center.view(1, -1))
+        val.backward()
+    loss.copy_(loss + val.detach() if accumulate else val.detach())
+    return st.grad
+
+
 def _patch_ops():
     from ssv_amd import ops
     ops.l2norm_fwd, ops.l2norm_bwd = _emu_l2norm_fwd, _emu_l2norm_bwd
@@ -111,6 +121,7 @@ def _patch_ops():
     ops.scale_ = lambda x, f: x.mul_(f)
     ops.fill_ = lambda x, v: x.fill_(v)
     ops.mse_pair, ops.barlow_cgrad = _emu_mse_pair, _emu_barlow_cgrad
+    ops.dino_loss = _emu_dino_loss
     ops.bn_train_fwd, ops.bn_train_bwd = _emu_bn_train_fwd, _emu_bn_train_bwd
     ops.conv2d_wgrad, ops.conv2d_fwd, ops.conv2d_dgrad = _emu_conv1x1_wgrad, _emu_conv1x1_fwd, _emu_conv1x1_dgrad
 
@@ -189,6 +200,33 @@ def _worker(rank, world, port, out):
             np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
             np.testing.assert_allclose(li.grad.numpy(), a.grad[sl].numpy(), rtol=2e-3, atol=2e-6)
             np.testing.assert_allclose(lj.grad.numpy(), c.grad[sl].numpy(), rtol=2e-3, atol=2e-6)
+        # ---- 6. DINO: every rank scores its own shard (the reference's cat-then-view grouping is per batch, so the data-parallel
+        #         loss is DEFINED as the mean of the per-shard reference losses); SUM of gradients = gradient of that mean
+        from oracle import vit as ovit
+        from ssv_amd.models import dino as hdino
+        bs, vg, vl, k = 3, 2, 4, 24
+        center = seeded_randn(30, k)
+        shards = [[seeded_randn(31 + 10 * r + i, n_, k) for i, n_ in enumerate((2 * bs * vg, 2 * bs * vl, 2 * bs * vg))] for r in range(world)]
+
+        def shard_loss(sg, sl, tg):
+            ng, nl = bs * vg, bs * vl
+            s1 = torch.cat((sg[:ng], sl[:nl]), 0).view(bs, vg + vl, k)
+            s2 = torch.cat((sg[ng:], sl[nl:]), 0).view(bs, vg + vl, k)
+            t1, t2 = tg[:ng].view(bs, vg, k), tg[ng:].view(bs, vg, k)
+            return 0.5 * ovit.dino_loss(t1, s2, 0.1, 0.04, center.view(1, -1)) + 0.5 * ovit.dino_loss(t2, s1, 0.1, 0.04, center.view(1, -1))
+
+        refs = []
+        for r in range(world):
+            sg, sl = shards[r][0].clone().requires_grad_(), shards[r][1].clone().requires_grad_()
+            (shard_loss(sg, sl, shards[r][2]) / world).backward()
+            refs.append((sg.grad, sl.grad))
+        want = sum(float(shard_loss(*shards[r])) for r in range(world)) / world
+        sg, sl = shards[rank][0].clone().requires_grad_(), shards[rank][1].clone().requires_grad_()
+        loss = hdino._DinoLossFn.apply(sg, sl, shards[rank][2], center, bs, vg, vl, 0.1, 0.04)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), want, rtol=2e-6)
+        np.testing.assert_allclose(sg.grad.numpy(), refs[rank][0].numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(sl.grad.numpy(), refs[rank][1].numpy(), rtol=1e-5, atol=1e-9)
         out.put((rank, "ok"))
     except Exception as e:                                        # surface the failure to the parent
         import traceback
