@@ -65,8 +65,7 @@ class MultiheadSelfAttention(hnn.HipModule):
         self.layer_norm = hnn.HipLayerNorm(hidden_dim)
 
     def _run(self, tape, x, batch, tokens):
-        q, k, v = self.query._run(tape, x), self.key._run(tape, x), self.value._run(tape, x)
-        o = hnn.attention(tape, q, k, v, batch, tokens, self.heads)
+        o = hnn.qkv_attention(tape, x, self.query.weight, self.key.weight, self.value.weight, batch, tokens, self.heads)
         return self.layer_norm._run(tape, x, addend=o)                       # attention(x) + LayerNorm(x)
 
 

@@ -280,6 +280,56 @@ def attention(tape, q, k, v, batch, tokens, heads):
     return o
 
 
+def _stacked(a, b, c):
+    """[3*rows, cols] view over three equally shaped matrices when they sit back to back in memory (parameters and their
+    gradients do once the optimizer's arena owns them), else None."""
+    if a is None or b is None or c is None:
+        return None
+    nbytes = a.numel() * a.element_size()
+    if not (a.is_contiguous() and b.is_contiguous() and c.is_contiguous()):
+        return None
+    if a.data_ptr() + nbytes != b.data_ptr() or b.data_ptr() + nbytes != c.data_ptr():
+        return None
+    return a.as_strided((3 * a.shape[0], a.shape[1]), (a.shape[1], 1))
+
+
+def qkv_attention(tape, x, wq, wk, wv, batch, tokens, heads):
+    """attention(x Wq^T, x Wk^T, x Wv^T).  With the three weights adjacent in the parameter arena the projections are ONE
+    GEMM into an [M, 3*hidden] matrix whose column blocks feed the attention kernel directly (and one wgrad + one dgrad
+    in the backward); otherwise three GEMMs - same numbers per element either way."""
+    wcat = _stacked(wq.data, wk.data, wv.data)
+    if wcat is None:
+        q, k, v = linear(tape, x, wq, None), linear(tape, x, wk, None), linear(tape, x, wv, None)
+        return attention(tape, q, k, v, batch, tokens, heads)
+    m, din = x.shape
+    hid = wq.shape[0]
+    x4 = x.view(m, 1, 1, din)
+    y = ops.conv2d_fwd(x4, wcat, 1, 0).view(m, 3 * hid)
+    q, k, v = y[:, :hid], y[:, hid:2 * hid], y[:, 2 * hid:]
+    o, lse = ops.attention_fwd(q, k, v, batch, tokens, heads)
+    if tape is not None:
+        need_dx = tape.needs_grad(x)
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dqkv = torch.empty_like(y)
+            ops.attention_bwd(q, k, v, o, dy, lse, batch, tokens, heads, out=dqkv)
+            d4 = dqkv.view(m, 1, 1, 3 * hid)
+            gcat = _stacked(grad_of(wq, slot), grad_of(wk, slot), grad_of(wv, slot))
+            if gcat is not None:
+                ops.conv2d_wgrad(x4, d4, wcat, gcat, 1, 0, accumulate=True)
+            else:
+                for i, w in enumerate((wq, wk, wv)):
+                    ops.conv2d_wgrad(x4, dqkv[:, i * hid:(i + 1) * hid].contiguous().view(m, 1, 1, hid), w, grad_of(w, slot), 1, 0, accumulate=True)
+            if not need_dx:
+                return (None,)
+            ex = existing[0]
+            ex4 = None if ex is None else ex.view(m, 1, 1, din)
+            return (ops.conv2d_dgrad(d4, wcat, x4.shape, 1, 0, addend=ex4, out=ex4).view(m, din),)
+        tape.record((x,), o, bwd)
+    return o
+
+
 def vit_embed(tape, img_nhwc, cls_weight, pos_weight, patch):
     """[B,H,W,3] -> ([B*T, 3 patch^2 + E] token rows, T); gradients go to the cls and positional embeddings only."""
     tok, t = ops.vit_embed_fwd(img_nhwc, cls_weight, pos_weight, patch)
