@@ -21,6 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_FILES = {"simclr": "r01_c_pmc_hbm_traffic_b%d.json", "dino": "r01_h_pmc_hbm_traffic_dino_b%d.json"}   # rocprofv3 --pmc passes, tools/pmc_traffic.py
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -125,7 +126,11 @@ def dino_work(batch):
     gemm_macs = 3 * (student_tokens * per_token + (ng + nl) * per_image_head) + teacher_tokens * per_token + ng * per_image_head
     attn = lambda t: layers * t * t * hid                       # MACs of ONE T x T x hidden product over all heads
     attn_macs = 6 * (ng * attn(tg) + nl * attn(tl)) + 2 * ng * attn(tg)
-    return 2.0 * gemm_macs * batch, 2.0 * attn_macs * batch
+    # HBM bytes of the encoder GEMMs when every operand moves once: per token and layer, forward = q/k/v (in 384, out 1152),
+    # fc1 (in 384, out 1536), fc2 (in 1536, residual 384, out 384); dgrad and wgrad each move about as much again
+    per_token_fwd = 4 * (layers * (2 * hid + 3 * hid + 2 * inter + 2 * hid) + (3 * e["patch_size"] ** 2 + e["embedding_dim"]) + hid)
+    gemm_bytes = (3 * student_tokens + teacher_tokens) * per_token_fwd
+    return 2.0 * gemm_macs * batch, 2.0 * attn_macs * batch, gemm_bytes * batch
 
 
 AUG_CFG = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8},
@@ -248,8 +253,7 @@ def main():
 
     # ---- per-kernel-class timing (HIP events on the launch stream) over extra instrumented steps --------------
     if args.algo == "dino":
-        conv_flop_step, attn_flop_step = dino_work(b)
-        algo_bytes_step = None
+        conv_flop_step, attn_flop_step, algo_bytes_step = dino_work(b)
     else:
         conv_flop_step, algo_bytes_step = step_work(args.algo, s, s, b)       # per GPU and step; 2 FLOP/MAC
         attn_flop_step = 0.0
@@ -273,9 +277,9 @@ def main():
         ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; corrected as the guide prescribes)
-            if args.algo != "simclr":
-                raise KeyError(args.algo)                          # PMC passes exist for the headline workload only
-            with open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic_b%d.json" % b)) as fh:
+            if args.algo not in PMC_FILES:
+                raise KeyError(args.algo)                          # PMC passes exist for the headline workload and for DINO
+            with open(os.path.join(ROOT, "profiles", PMC_FILES[args.algo] % b)) as fh:
                 pmc = json.load(fh)["per_step_gb"]
             traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")), 1)
         except (OSError, KeyError, ValueError):
@@ -284,7 +288,7 @@ def main():
         roof = {"bound": "mfma", "kernel": ("implicit-GEMM family running the Linear layers" if args.algo == "dino" else "conv implicit-GEMM family") +
                                            " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/r01_c_pmc_hbm_traffic_b%d.json)" % b,
+                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/%s)" % (PMC_FILES.get(args.algo, "-") % b if args.algo in PMC_FILES else "-"),
                 "algorithmic_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),

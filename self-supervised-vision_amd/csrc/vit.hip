@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const
 
 // ------------------------------------------------------------------------------------------------ attention backward: dK, dV
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_bwd_dkv_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V, int ld, float scale,
                                                           const float* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                           const float* __restrict__ DELTA, float* __restrict__ dK, float* __restrict__ dV, int ldg) {
