@@ -247,6 +247,26 @@ int ssv_multicrop_params(int32_t B, int32_t Hs, int32_t Ws, int32_t ncrop, int32
 int ssv_multicrop(int32_t B, int32_t Hs, int32_t Ws, const float* views_nhwc, int32_t ncrop, const int32_t* boxes,
                   int32_t Ho, int32_t Wo, float* out_nhwc, void* stream);
 
+/* ==== "next" row 4: sibling two-view algorithms (they reuse every encoder / head kernel above) ========================= */
+/* SimSiamLoss (utils/losses.py:145-152) for both pairs: loss = -scale * (sum o1.t2 + sum o2.t1), do1 = -scale*t2, do2 = -scale*t1
+ * (scale = 0.5 / batch for models/simsiam.py:126-127).  Workspace: ssv_reduce_workspace_bytes(n). */
+int ssv_negdot_pair_fwd_bwd(int64_t n, const float* o1, const float* o2, const float* t1, const float* t2, float scale,
+                            float* loss, float* do1, float* do2, void* ws, size_t ws_bytes, void* stream);
+/* RelicLoss invariance term (utils/losses.py:195-201): a = diag(zi zo^T)/T, b = diag(zj zo^T)/T over dense [N][D] matrices,
+ * loss (+)= alpha * sum_n exp(lq_n) (lq_n - p_n) with p = softmax(a), lq = log_softmax(b) ACROSS the batch; writes the gradients
+ * w.r.t. zi, zj, zo.  (The contrastive half of RelicLoss is ssv_ntxent_*.) */
+size_t ssv_relic_kl_workspace_bytes(int32_t N);
+int ssv_relic_kl_fwd_bwd(int32_t N, int32_t D, const float* zi, const float* zj, const float* zo, float inv_temp, float alpha,
+                         float* loss, int32_t accumulate_loss, float* dzi, float* dzj, float* dzo,
+                         void* ws, size_t ws_bytes, void* stream);
+/* MocoLoss (utils/losses.py:49-71) given neg[n][j] = q[n].bank[j] (N x K products, row stride ldk, from ssv_conv2d_fwd):
+ * loss = mean_n(logsumexp([q.k/T | neg/T]) - q.k/T); neg is overwritten by d loss / d neg (columns K..ldk zeroed) and
+ * dq_init[n] = d loss / d(q.k) * k[n]; the caller finishes dq = dq_init + neg . bank with ssv_conv2d_dgrad's addend. */
+int ssv_moco_loss_fwd_bwd(int32_t N, int32_t D, int32_t K, int32_t ldk, const float* q, const float* k, float* neg, float inv_temp,
+                          float* loss, float* dq_init, void* ws, size_t ws_bytes, void* stream);
+/* MemoryBank.add_batch (models/moco.py:32-37): bank[(ptr+i) % K] = keys[i] / max(||keys[i]||, eps) for i < n */
+int ssv_queue_push(int32_t K, int32_t D, float* bank, int32_t ptr, int32_t n, const float* keys, float eps, void* stream);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
  * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
  * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */

@@ -2,7 +2,7 @@
 
 The flag surface is the reference's (main.py:11-12,38-43), verbatim: -c/--config, -m/--arch, -a/--algo, -t/--task,
 -o/--output, -l/--load with the same choices, so scripts written for the reference keep working.  Algorithms outside the
-accelerated two-view path (moco, pirl, simsiam, relic, deep_cluster, swav, sela) stay on the
+accelerated two-view path (pirl, deep_cluster, swav, sela) stay on the
 surface and raise NotImplementedError.  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N main.py ...`.
 """
 import argparse
@@ -15,8 +15,8 @@ import numpy as np
 TASKS = ("train", "linear_eval", "get_features")
 NETWORKS = ("resnet18", "resnet50", "resnext50", "resnext101", "wide_resnet50", "wide_resnet101", "vit")
 # algo -> (module, class) for what is built; None marks flag values that exist but are not accelerated
-ALGORITHMS = {"simclr": ("simclr", "SimCLR"), "moco": None, "byol": ("byol", "BYOL"), "dino": ("dino", "DINO"), "pirl": None,
-              "barlow": ("barlow", "BarlowTwins"), "simsiam": None, "relic": None, "deep_cluster": None, "swav": None, "sela": None}
+ALGORITHMS = {"simclr": ("simclr", "SimCLR"), "moco": ("moco", "MoCo"), "byol": ("byol", "BYOL"), "dino": ("dino", "DINO"), "pirl": None,
+              "barlow": ("barlow", "BarlowTwins"), "simsiam": ("simsiam", "SimSiam"), "relic": ("relic", "ReLIC"), "deep_cluster": None, "swav": None, "sela": None}
 
 _FLAGS = (
     ("-c", "--config", dict(required=True, help="YAML configuration file")),

@@ -1,0 +1,85 @@
+"""MoCo on the HIP path - drop-in for the reference trainer (models/moco.py:23-126).
+
+Kept from the reference: the key encoder starts as a copy of the query encoder and follows it by EMA (m = 0.999) after every
+optimiser step; the queue starts as zeros and receives the L2-normalised keys AFTER that update; the head is one Linear layer
+behind nn.ReLU (which is the identity on ResNet's pooled features - an average of post-ReLU activations - in value and in
+gradient, so no kernel is spent on it).  The queue lives in HBM ([K rounded up to 16, D], extra rows zero and masked) and is
+pushed by one kernel instead of a per-row Python loop (models/moco.py:32-37)."""
+import torch
+
+from .. import _lib, nn as hnn, ops
+from ..utils import losses, train_utils
+from .base import NETWORKS, TwoViewTrainer
+from .heads import _fresh_linear
+
+
+class MemoryBank:
+    def __init__(self, queue_size, feature_size, device):
+        self.size, self.ptr = int(queue_size), 0
+        self.bank = ops.fill_(torch.empty(((self.size + 15) // 16 * 16, feature_size), dtype=torch.float32, device=device), 0.0)
+
+    def add_batch(self, batch):
+        self.ptr = ops.queue_push(self.bank, self.size, self.ptr, batch.detach().contiguous())
+
+    def get_vectors(self):
+        return self.bank
+
+
+class EncoderModel(hnn.HipModule):
+    def __init__(self, encoder, encoder_dim, projection_dim):
+        super().__init__()
+        self.encoder = encoder
+        self.proj_head = _fresh_linear(encoder_dim, projection_dim)
+
+    def _prepare_input(self, x):
+        return self.encoder._prepare_input(x)
+
+    def _run(self, tape, x):
+        return self.proj_head._run(tape, self.encoder._run(tape, x))     # ReLU(pooled features) == pooled features
+
+
+class MoCo(TwoViewTrainer):
+    algo = "moco"
+
+    def _build(self, arch):
+        encoder, encoder_dim = NETWORKS[arch].values()
+        cfg = self.config
+        self.query_encoder = EncoderModel(encoder(**cfg["encoder"]), encoder_dim, cfg["proj_dim"]).to(self.device)
+        self.key_encoder = EncoderModel(encoder(**cfg["encoder"]), encoder_dim, cfg["proj_dim"]).to(self.device)   # its init draws are consumed, then overwritten
+        self.memory_bank = MemoryBank(cfg["queue_size"], cfg["proj_dim"], self.device)
+        self.m = cfg.get("momentum", 0.999)
+        self.key_encoder.load_state_dict(self.query_encoder.state_dict())
+        for p in self.key_encoder.parameters():
+            p.requires_grad = False
+        self.optim = train_utils.get_optimizer(cfg["optimizer"], params=self.query_encoder.parameters())
+        self._key_arena = train_utils.ParamArena(list(self.key_encoder.parameters()), with_grads=False)
+        self.loss_fn = losses.MocoLoss(**cfg["loss_fn"])
+
+    @torch.no_grad()
+    def momentum_update(self):
+        _lib.call("ssv_ema", self._key_arena.numel, _lib.ptr(self._key_arena.data), _lib.ptr(self.optim.arena.data), float(self.m), _lib.stream())
+
+    def _embed(self, img):
+        return self.query_encoder(img)
+
+    def train_step(self, batch):
+        img_1, img_2 = batch["aug_1"].to(self.device), batch["aug_2"].to(self.device)
+        with hnn.parallel_views(self.device) as pv:
+            with pv.view(0):
+                query = self.query_encoder(img_1)
+            with pv.view(1):
+                with torch.no_grad():
+                    keys = self.key_encoder(img_2)
+        loss = self.loss_fn(query, keys, self.memory_bank.get_vectors(), self.memory_bank.size)
+        self.optim.zero_grad()
+        loss.backward()
+        self.optim.step()
+        self.momentum_update()
+        self.memory_bank.add_batch(keys)
+        return {"loss": loss.item()}
+
+    def _checkpoint_state(self):
+        return {"encoder": self.query_encoder.state_dict()}
+
+    def _load_state(self, state):
+        self.query_encoder.load_state_dict(state["encoder"])

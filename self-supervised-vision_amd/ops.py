@@ -374,3 +374,46 @@ def multicrop(views_nhwc, boxes, size):
     out = torch.empty((b, ncrop, size[0], size[1], 3), dtype=torch.float32, device=views_nhwc.device)
     call("ssv_multicrop", b, hs, ws_, ptr(views_nhwc), ncrop, ptr(boxes), size[0], size[1], ptr(out), stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------- sibling algorithms' losses
+def negdot_pair(o1, o2, t1, t2, scale):
+    """loss = -scale * (sum o1*t2 + sum o2*t1); returns (loss 0-d, dloss/do1, dloss/do2)."""
+    _lib._dev(o1, o2, t1, t2)
+    n = o1.numel()
+    do1, do2 = torch.empty_like(o1), torch.empty_like(o2)
+    loss = torch.empty((), dtype=torch.float32, device=o1.device)
+    ws = workspace.get(_lib.load().ssv_reduce_workspace_bytes(n), o1.device)
+    call("ssv_negdot_pair_fwd_bwd", n, ptr(o1), ptr(o2), ptr(t1), ptr(t2), float(scale), ptr(loss), ptr(do1), ptr(do2), ptr(ws), ws.numel(), stream())
+    return loss, do1, do2
+
+
+def relic_kl(zi, zj, zo, inv_temp, alpha):
+    """ReLIC invariance term on dense [N,D] matrices; returns (alpha * kl as a 0-d tensor, dzi, dzj, dzo)."""
+    _lib._dev(zi, zj, zo)
+    n, d = zi.shape
+    loss = torch.empty((), dtype=torch.float32, device=zi.device)
+    dzi, dzj, dzo = torch.empty_like(zi), torch.empty_like(zj), torch.empty_like(zo)
+    ws = workspace.get(_lib.load().ssv_relic_kl_workspace_bytes(n), zi.device)
+    call("ssv_relic_kl_fwd_bwd", n, d, ptr(zi), ptr(zj), ptr(zo), float(inv_temp), float(alpha), ptr(loss), 0, ptr(dzi), ptr(dzj), ptr(dzo),
+         ptr(ws), ws.numel(), stream())
+    return loss, dzi, dzj, dzo
+
+
+def moco_loss(q, k, neg, queue_size, inv_temp):
+    """q, k [N,D] (already normalised if the loss normalises), neg [N, ldk] = q bank^T; neg is overwritten by dloss/dneg.
+    Returns (loss 0-d, dq_init [N,D])."""
+    _lib._dev(q, k, neg)
+    n, d = q.shape
+    loss = torch.empty((), dtype=torch.float32, device=q.device)
+    dq = torch.empty_like(q)
+    ws = workspace.get(n * 8, q.device)
+    call("ssv_moco_loss_fwd_bwd", n, d, int(queue_size), neg.shape[1], ptr(q), ptr(k), ptr(neg), float(inv_temp), ptr(loss), ptr(dq), ptr(ws), ws.numel(), stream())
+    return loss, dq
+
+
+def queue_push(bank, queue_size, pointer, keys, eps=1e-12):
+    """bank[(pointer + i) % queue_size] = normalize(keys[i]); returns the new pointer."""
+    _lib._dev(bank, keys)
+    call("ssv_queue_push", int(queue_size), bank.shape[1], ptr(bank), int(pointer), keys.shape[0], ptr(keys), float(eps), stream())
+    return (pointer + keys.shape[0]) % queue_size

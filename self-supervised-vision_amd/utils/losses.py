@@ -167,3 +167,95 @@ class BarlowLoss(nn.Module):
         if z_i.shape != z_j.shape or z_i.dim() != 2:
             raise ValueError(f"BarlowLoss expects two [B,D] matrices, got {tuple(z_i.shape)} and {tuple(z_j.shape)}")
         return _BarlowFn.apply(z_i, z_j, self.normalize, self.lmbda)
+
+
+# ------------------------------------------------------------------------------------------- sibling algorithms
+class _NegDotPairFn(torch.autograd.Function):
+    """0.5 * (SimSiamLoss(o1, t2) + SimSiamLoss(o2, t1)) (utils/losses.py:145-152, models/simsiam.py:126-127); the mean runs over
+    the GLOBAL batch under data parallelism (weight 1/world, scalar all-reduced)."""
+
+    @staticmethod
+    def forward(ctx, o1, o2, t1, t2):
+        o1c, o2c, t1c, t2c = (t.detach().contiguous() for t in (o1, o2, t1, t2))
+        loss, do1, do2 = ops.negdot_pair(o1c, o2c, t1c, t2c, 0.5 / (o1c.shape[0] * hdist.world_size()))
+        hdist.all_reduce_sum(loss)
+        ctx.saved = (do1, do2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        do1, do2 = ctx.saved
+        g = dloss.contiguous()
+        return ops.scale_(do1, g), ops.scale_(do2, g), None, None
+
+
+def simsiam_pair_loss(online_1, online_2, target_1, target_2):
+    return _NegDotPairFn.apply(online_1, online_2, target_1, target_2)
+
+
+class _RelicKLFn(torch.autograd.Function):
+    """alpha * KL term of RelicLoss (utils/losses.py:195-201) with its gradient w.r.t. all three embedding matrices."""
+
+    @staticmethod
+    def forward(ctx, zi, zj, zo, normalize, temperature, alpha):
+        if hdist.world_size() > 1:
+            raise NotImplementedError("ReLIC's invariance term soft-maxes across the batch; its data-parallel form is not built")
+        d = zi.shape[1]
+        mats, invs = [], []
+        for z in (zi, zj, zo):
+            zh, inv = ops.l2norm_fwd(z.detach().contiguous(), normalize)
+            mats.append(zh)
+            invs.append(inv)
+        loss, *grads = ops.relic_kl(mats[0], mats[1], mats[2], 1.0 / float(temperature), alpha)
+        ctx.saved = tuple(ops.l2norm_bwd(mats[k], invs[k], grads[k], d, normalize) for k in range(3))
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g = dloss.contiguous()
+        dzi, dzj, dzo = (ops.scale_(t, g) for t in ctx.saved)
+        return dzi, dzj, dzo, None, None, None
+
+
+class RelicLoss(nn.Module):
+    """utils/losses.py:155-201: the NT-Xent of (zi, zj) plus alpha * the invariance term against the un-augmented image's embedding."""
+
+    def __init__(self, normalize=True, temperature=1.0, alpha=0.5):
+        super().__init__()
+        self.normalize, self.temperature, self.alpha = normalize, temperature, alpha
+        self.contrastive = SimclrLoss(normalize, temperature)
+
+    def forward(self, zi, zj, z_orig):
+        return self.contrastive(zi, zj) + _RelicKLFn.apply(zi, zj, z_orig, self.normalize, self.temperature, self.alpha)
+
+
+class _MocoFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, query, keys, bank, queue_size, normalize, temperature):
+        if hdist.world_size() > 1:
+            raise NotImplementedError("MoCo's queue under data parallelism (all-gather of the keys) is not built")
+        n, d = query.shape
+        qn, inv_q = ops.l2norm_fwd(query.detach().contiguous(), normalize)
+        kn, _ = ops.l2norm_fwd(keys.detach().contiguous(), normalize)
+        neg = ops.conv2d_fwd(qn.view(n, 1, 1, d), bank).view(n, bank.shape[0])                    # [N, K_pad] products with the queue (MFMA GEMM)
+        loss, dq = ops.moco_loss(qn, kn, neg, queue_size, 1.0 / float(temperature))
+        ops.conv2d_dgrad(neg.view(n, 1, 1, -1), bank, (n, 1, 1, d), addend=dq.view(n, 1, 1, d), out=dq.view(n, 1, 1, d))   # dq += P . bank
+        ctx.saved = ops.l2norm_bwd(qn, inv_q, dq, d, normalize)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return ops.scale_(ctx.saved, dloss.contiguous()), None, None, None, None, None
+
+
+class MocoLoss(nn.Module):
+    """utils/losses.py:49-71.  ``memory_vectors`` is the device queue [K_pad, D] (K_pad = queue size rounded up to 16, extra rows zero
+    and masked out) as held by models.moco.MemoryBank."""
+
+    def __init__(self, normalize=True, temperature=1.0):
+        super().__init__()
+        self.normalize, self.temperature = normalize, temperature
+
+    def forward(self, query, keys, memory_vectors, queue_size=None):
+        k = memory_vectors.shape[0] if queue_size is None else queue_size
+        return _MocoFn.apply(query, keys, memory_vectors, k, self.normalize, self.temperature)

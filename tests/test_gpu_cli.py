@@ -77,3 +77,33 @@ def test_main_dino_vit_train_then_get_features(tmp_path, monkeypatch):
     cli.main(["-c", str(path), "-a", "dino", "-m", "vit", "-t", "get_features", "-o", "feat", "-l", str(out)])
     f = np.load(tmp_path / "outputs" / "dino" / "vit" / "feat" / "test_fvecs.npy")
     assert f.shape == (48, 1024) and np.isfinite(f).all()
+
+
+@pytest.mark.parametrize("algo,first_key", [("simsiam", "encoder.conv1.weight"), ("relic", "encoder.conv1.weight"), ("moco", "encoder.conv1.weight")])
+def test_main_sibling_algorithms_train(tmp_path, monkeypatch, algo, first_key):
+    """`-a simsiam|relic|moco`: the reference's CLI surface for the sibling two-view algorithms, end to end on synthetic data."""
+    from ssv_amd import main as cli
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "self-supervised-vision_amd", "configs", f"{algo}.yaml")))
+    cfg["epochs"], cfg["eval_every"] = 2, 1
+    cfg["data"]["batch_size"] = 32
+    cfg["data"]["synthetic"] = {"num_train": 80, "num_test": 48, "image_size": [32, 32], "num_classes": 10}
+    cfg["linear_eval"]["epochs"] = 2
+    if algo == "simsiam":
+        cfg["proj_dim"], cfg["bottleneck_dim"] = 256, 64
+    if algo == "moco":
+        cfg["queue_size"] = 100                                                   # 80 keys per epoch: wraps in the second epoch
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.dump(cfg, sort_keys=False))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("WANDB_MODE", "disabled")
+    model = cli.main(["-c", str(path), "-a", algo, "-m", "resnet18", "-t", "train", "-o", "run"])
+    out = tmp_path / "outputs" / algo / "resnet18" / "run"
+    log = (out / "trainlogs.txt").read_text()
+    assert "[TRAIN] Epoch    2/   2 [loss]" in log and "[VALID] Epoch    2/   2 [accuracy]" in log and (out / "best_model.pt").exists()
+    state = torch.load(out / "best_model.pt", map_location="cpu")["encoder"]
+    assert list(state)[0] == first_key
+    assert np.isfinite(model.optim.arena.data.cpu().numpy()).all()
+    if algo == "moco":
+        assert model.memory_bank.ptr == (2 * 80) % 100
+        norms = model.memory_bank.bank[:100].norm(dim=1).cpu().numpy()
+        np.testing.assert_allclose(norms, 1.0, rtol=1e-4)                         # the queue is full of unit keys after 160 pushes
