@@ -267,6 +267,16 @@ int ssv_moco_loss_fwd_bwd(int32_t N, int32_t D, int32_t K, int32_t ldk, const fl
 /* MemoryBank.add_batch (models/moco.py:32-37): bank[(ptr+i) % K] = keys[i] / max(||keys[i]||, eps) for i < n */
 int ssv_queue_push(int32_t K, int32_t D, float* bank, int32_t ptr, int32_t n, const float* keys, float eps, void* stream);
 
+/* linear probe (utils/eval_utils.py:37-76): NLLLoss(log_softmax(logits)) and accuracy of a [N][ld] logit matrix (first C columns
+ * valid) against int32 labels; stats[0] = mean loss, stats[1] = fraction of rows whose arg-max is the label; dlogits (may be NULL)
+ * = d(mean loss)/dlogits, padding columns zeroed.  Workspace: ssv_softmax_ce_workspace_bytes(N). */
+size_t ssv_softmax_ce_workspace_bytes(int32_t N);
+int ssv_softmax_ce_fwd_bwd(int32_t N, int32_t C, int32_t ld, const float* logits, const int32_t* labels, float* stats,
+                           float* dlogits, void* ws, size_t ws_bytes, void* stream);
+/* optim.SGD(lr, momentum, weight_decay, nesterov) over n floats (the probe's optimiser, utils/eval_utils.py:42) */
+int ssv_sgd(int64_t n, float* p, const float* g, float* buf, float lr, float weight_decay, float momentum, int nesterov,
+            int first_step, void* stream);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
  * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
  * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */

@@ -75,6 +75,45 @@ __global__ void __launch_bounds__(256) knn_agree_k(const float* __restrict__ S, 
 
 __global__ void zero_count_k(unsigned long long* c) { *c = 0ull; }
 
+// ---- linear probe: NLLLoss(log_softmax(logits)) + accuracy (utils/eval_utils.py:52-54), one wavefront per row ----------------
+// stats[0] += sum of per-row losses, stats[1] += number of rows whose arg-max is the label; dlogits = (softmax - onehot) * gscale
+__global__ void __launch_bounds__(256) softmax_ce_k(int N, int C, int ld, const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                    float gscale, float* __restrict__ dlogits, float* __restrict__ row_loss, int32_t* __restrict__ row_hit) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= N) return;
+  const float* row = logits + (int64_t)r * ld;
+  float mx = -INFINITY;
+  int arg = 0;
+  for (int c = lane; c < C; c += 64) { const float v = row[c]; if (v > mx) { mx = v; arg = c; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ov > mx || (ov == mx && oa < arg)) { mx = ov; arg = oa; }          // first maximum, like argmax
+  }
+  float sm = 0.f;
+  for (int c = lane; c < C; c += 64) sm += expf(row[c] - mx);
+  sm = wave_sum(sm);
+  const float lse = mx + logf(sm);
+  const int y = labels[r];
+  if (dlogits) {
+    for (int c = lane; c < ld; c += 64)
+      dlogits[(int64_t)r * ld + c] = c < C ? (expf(row[c] - lse) - (c == y ? 1.f : 0.f)) * gscale : 0.f;
+  }
+  if (lane == 0) { row_loss[r] = lse - row[y]; row_hit[r] = arg == y ? 1 : 0; }
+}
+__global__ void ce_reduce_k(int N, const float* __restrict__ row_loss, const int32_t* __restrict__ row_hit, float* __restrict__ stats) {
+  __shared__ double sl[256];
+  __shared__ int sh[256];
+  double a = 0.0;
+  int h = 0;
+  for (int i = threadIdx.x; i < N; i += 256) { a += (double)row_loss[i]; h += row_hit[i]; }
+  sl[threadIdx.x] = a; sh[threadIdx.x] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sh[threadIdx.x] += sh[threadIdx.x + o]; } __syncthreads(); }
+  if (threadIdx.x == 0) { stats[0] = (float)(sl[0] / (double)N); stats[1] = (float)sh[0] / (float)N; }
+}
+
 int64_t chunk_rows(int64_t n) {
   // one chunk of S must satisfy the convolution's element limit (< 2^29 - 2^22 outputs) and stay cache/HBM friendly
   int64_t r = ((1ll << 29) - (1ll << 23)) / n;
@@ -117,5 +156,21 @@ extern "C" int ssv_knn_label_agreement(int64_t n, int32_t d, const float* z, con
       hipLaunchKernelGGL(knn_agree_k<64>, grid, dim3(256), 0, s, S, n, (int)n, rows, (int)r0, labels, k, count);
     SSV_CHECK_LAUNCH("knn_agree_k");
   }
+  return SSV_OK;
+}
+
+extern "C" size_t ssv_softmax_ce_workspace_bytes(int32_t N) { return N > 0 ? (size_t)N * 8 : 0; }
+
+extern "C" int ssv_softmax_ce_fwd_bwd(int32_t N, int32_t C, int32_t ld, const float* logits, const int32_t* labels, float* stats,
+                                      float* dlogits, void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(N > 0 && C > 0 && ld >= C && logits && labels && stats && ws, "ssv_softmax_ce_fwd_bwd: bad arguments");
+  SSV_REQUIRE(ws_bytes >= ssv_softmax_ce_workspace_bytes(N), "ssv_softmax_ce_fwd_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  float* row_loss = (float*)ws;
+  int32_t* row_hit = (int32_t*)(row_loss + N);
+  hipLaunchKernelGGL(softmax_ce_k, dim3(cdiv(N, 4)), dim3(256), 0, s, N, C, ld, logits, labels, 1.f / (float)N, dlogits, row_loss, row_hit);
+  hipLaunchKernelGGL(ce_reduce_k, dim3(1), dim3(256), 0, s, N, (const float*)row_loss, (const int32_t*)row_hit, stats);
+  SSV_CHECK_LAUNCH("ssv_softmax_ce_fwd_bwd");
   return SSV_OK;
 }

@@ -29,6 +29,19 @@ sgd_nesterov_k(int64_t n, float* __restrict__ p, const float* __restrict__ g, co
   }
 }
 
+// optim.SGD(momentum, weight_decay, nesterov flag) - the plain form used by the linear probe (utils/eval_utils.py:42)
+__global__ void __launch_bounds__(256)
+sgd_k(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float lr, float wd, float mom, int nesterov, int first) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float pv = p[i];
+    const float gv = g[i] + wd * pv;
+    const float bv = first ? gv : mom * buf[i] + gv;
+    buf[i] = bv;
+    p[i] = pv - lr * (nesterov ? gv + mom * bv : bv);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 ema_k(int64_t n, float* __restrict__ t, const float* __restrict__ o, float tau) {
   const int64_t n4 = n >> 2;
@@ -86,5 +99,15 @@ extern "C" int ssv_add(int64_t n, float* dst, const float* src, void* stream) {
   ProfScope ps(SSV_PROF_MISC, s);
   hipLaunchKernelGGL(add_k, dim3(grid_for(n)), dim3(256), 0, s, n, dst, src);
   SSV_CHECK_LAUNCH("ssv_add");
+  return SSV_OK;
+}
+
+extern "C" int ssv_sgd(int64_t n, float* p, const float* g, float* buf, float lr, float weight_decay, float momentum, int nesterov,
+                       int first_step, void* stream) {
+  SSV_REQUIRE(n > 0 && p && g && buf, "ssv_sgd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_OPTIM, s);
+  hipLaunchKernelGGL(sgd_k, dim3(grid_for(n)), dim3(256), 0, s, n, p, g, buf, lr, weight_decay, momentum, nesterov, first_step);
+  SSV_CHECK_LAUNCH("ssv_sgd");
   return SSV_OK;
 }

@@ -54,3 +54,36 @@ def test_knn_rejects_bad_arguments(dev):
         ops.knn_label_agreement(z, labels, 10)          # k must be < n
     with pytest.raises(_lib.SsvError):
         ops.knn_label_agreement(z.cpu(), labels.cpu(), 3)
+
+
+def test_linear_probe_matches_oracle(dev):
+    """The GPU probe (MFMA logits / weight gradient, softmax-CE kernel, plain-momentum SGD kernel) against the torch CPU restatement
+    with the same init draw and the same batch order."""
+    from ssv_amd.utils import eval_utils
+    xtr, ytr = evalknn.clustered_features(81, 700, 126, 10, 2.0)             # 126: not a multiple of 4 -> padded; 700: ragged last batch
+    xte, yte = evalknn.clustered_features(81, 300, 126, 10, 2.0)
+    cfg = {"epochs": 6, "batch_size": 128, "lr": 0.1, "input_dim": 128}
+    torch.manual_seed(5)
+    want, head = evalknn.linear_evaluation(cfg, {"fvecs": xtr, "labels": ytr}, {"fvecs": xte, "labels": yte}, 10, eval_utils.probe_batches)
+    torch.manual_seed(5)
+    got = eval_utils.linear_evaluation(cfg, {"fvecs": xtr, "labels": ytr}, {"fvecs": xte, "labels": yte}, 10, dev)
+    assert abs(got - want) <= 1.0 / 300 + 1e-9, (got, want)
+    assert want > 0.5                                                         # the probe actually learns the planted classes
+
+
+def test_softmax_ce_kernel(dev):
+    from ssv_amd import _lib
+    n, c, ld = 37, 10, 12
+    logits = torch.randn(n, ld, generator=torch.Generator().manual_seed(3)) * 3
+    labels = torch.randint(0, c, (n,), generator=torch.Generator().manual_seed(4), dtype=torch.int32)
+    ref_in = logits[:, :c].double().requires_grad_()
+    ref = torch.nn.functional.nll_loss(torch.log_softmax(ref_in, -1), labels.long())
+    ref.backward()
+    lg, lb = logits.to(dev), labels.to(dev)
+    stats, dl = torch.zeros(2, device=dev), torch.full((n, ld), 7.0, device=dev)
+    ws = torch.empty(_lib.load().ssv_softmax_ce_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    _lib.call("ssv_softmax_ce_fwd_bwd", n, c, ld, _lib.ptr(lg), _lib.ptr(lb), _lib.ptr(stats), _lib.ptr(dl), _lib.ptr(ws), ws.numel(), _lib.stream())
+    np.testing.assert_allclose(stats[0].item(), ref.item(), rtol=1e-6)
+    np.testing.assert_allclose(stats[1].item(), float((ref_in.argmax(-1) == labels.long()).float().mean()), rtol=1e-6)
+    np.testing.assert_allclose(dl[:, :c].cpu().numpy(), ref_in.grad.numpy(), rtol=1e-5, atol=1e-8)
+    assert float(dl[:, c:].abs().max()) == 0.0
