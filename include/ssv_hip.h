@@ -204,6 +204,12 @@ int ssv_layernorm_bwd(int64_t M, int32_t C, const float* dy, const float* x, con
                       const float* invstd, const float* dx_addend, float* dx, float* dgamma, float* dbeta,
                       int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Feedforward.fc1 + nn.GELU in one pass (networks/vit.py:42,45): h = x w^T + bias and act = gelu(h), both written by the GEMM
+ * epilogue (h is kept for the backward); and the matching backward of fc2: dx = (dy w) * gelu'(h) (+ addend).  Linear layers only
+ * (H = W = R = S = 1); forward: C % 32 == 0, K >= 128; dgrad: K % 32 == 0, C >= 128. */
+int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* h, float* act, void* stream);
+int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, const float* w, const float* h, const float* addend,
+                          float* dx, void* stream);
 /* nn.GELU() (erf form; networks/vit.py:38, models/dino.py:30-33) on n floats, n % 4 == 0 */
 int ssv_gelu_fwd(int64_t n, const float* x, float* y, void* stream);
 int ssv_gelu_bwd(int64_t n, const float* x, const float* dy, float* dx, void* stream);

@@ -41,7 +41,15 @@ struct ConvKP {
   int M;              // fwd/wgrad: N*Ho*Wo
   int RSC;            // R*S*C
   FastDiv dHoWo, dWo, dC, dS;
+  float* aux_out;     // fused-activation variants only: forward also writes gelu(y) here
+  const float* aux_in;  //                                   dgrad multiplies by gelu'(aux_in) before the addend
 };
+
+// exact (erf) GELU and its derivative, as csrc/vit.hip
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  return 0.5f * (1.f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
 
 // Buffer loads: a 128-bit resource descriptor (base, byte size) in SGPRs + a 32-bit per-lane byte offset + a uniform
 // SGPR byte offset.  Anything out of [0, size) reads as ZERO in hardware, so padding taps, ragged tile edges and rows
@@ -274,9 +282,10 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // bias / residual addend are read 16 bytes per lane too).  LDS traffic of one wave is in order, so no barrier is needed
 // inside; the caller has passed the barrier that ends the K loop.  row_off(r) gives the element offset of output row r of
 // the wave tile, or -1.
-template <int TM, int TN, class RowOff>
+template <int TM, int TN, bool EPI = false, class RowOff>
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
-                                             const float* __restrict__ bias, const float* addend, float* out, RowOff&& row_off) {
+                                             const float* __restrict__ bias, const float* addend, float* out, RowOff&& row_off,
+                                             float* out_act = nullptr, const float* gate = nullptr) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
@@ -297,8 +306,23 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
       const long long off = row_off(tm * 32 + r);
       if (off >= 0 && cok) {
         v += b4;
+        if constexpr (EPI) {
+          if (gate) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gate + off + gcol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(g[e]);
+          }
+        }
         if (addend) v += *reinterpret_cast<const f32x4*>(addend + off + gcol);
         *reinterpret_cast<f32x4*>(out + off + gcol) = v;
+        if constexpr (EPI) {
+          if (out_act) {
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = gelu_f(v[e]);
+            *reinterpret_cast<f32x4*>(out_act + off + gcol) = a;
+          }
+        }
       }
     }
   }
@@ -307,7 +331,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC, bool EPI = false>
 __global__ void __launch_bounds__(256)
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
@@ -449,11 +473,13 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 
   // ---- epilogue: acc reg j of lane l is (row (j&3)+8*(j>>2)+4*(l>>5), col l&31) of its 32x32 tile ----
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
+  static_assert(!EPI || (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE), "the fused-activation forward needs the vectorised epilogue");
   if constexpr (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE) {
     if ((p.K & 3) == 0) {             // 16-byte stores need K % 4 == 0 (uniform): whole rows segments through LDS
       const int rbase = m0 + wr0;
-      epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
-                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; });
+      epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+                                [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
+                                EPI ? p.aux_out : nullptr, nullptr);
       return;
     }
   }
@@ -483,7 +509,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // dgrad: rows are the input pixels of ONE stride-parity class (blockIdx.y); only taps with
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool EPI = false>
 __global__ void __launch_bounds__(256)
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -598,9 +624,11 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   k_loop<TM, TN, true, false, LDT, BN, BK, STAGE, DB, AP + BP>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
+  static_assert(!EPI || EP_FLOATS <= (DB ? 2 : 1) * STAGE, "the fused-activation dgrad needs the vectorised epilogue");
   if constexpr (EP_FLOATS <= (DB ? 2 : 1) * STAGE) {       // C % 4 == 0 is a precondition of this kernel
-    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
-                         [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; });
+    epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
+                              [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
+                              nullptr, EPI ? p.aux_in : nullptr);
     return;
   }
   const int l31 = lane & 31, h = lane >> 5;
@@ -816,6 +844,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dWo = make_fastdiv((uint32_t)d->Wo);
   p.dC = make_fastdiv((uint32_t)d->C);
   p.dS = make_fastdiv((uint32_t)d->S);
+  p.aux_out = nullptr; p.aux_in = nullptr;
   return p;
 }
 
@@ -891,6 +920,42 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
     hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, GBK, false, false>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd");
+  return SSV_OK;
+}
+
+// Linear + GELU with both tensors kept (the pre-activation h for the backward, gelu(h) for the next layer): one GEMM, one
+// epilogue; and its counterpart, dgrad with the GELU derivative applied to the product before the addend.
+extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* h, float* act, void* stream) {
+  if (int rc = check_desc(d, "ssv_linear_gelu_fwd")) return rc;
+  SSV_REQUIRE(x && w && h && act, "ssv_linear_gelu_fwd: null pointer");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)h | (uintptr_t)act) & 15) == 0, "ssv_linear_gelu_fwd: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K >= 128 && d->K % 4 == 0, "ssv_linear_gelu_fwd: needs C %% 32 == 0, K >= 128, K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.aux_out = act;
+  const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+  // K-step 32 only: its LDS stage is what the vectorised epilogue (the one that writes the second tensor) needs
+  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, false, true, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
+  SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, const float* w, const float* h, const float* addend,
+                                     float* dx, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_dgrad_gelu")) return rc;
+  SSV_REQUIRE(dy && w && h && dx, "ssv_conv2d_dgrad_gelu: null pointer");
+  SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)h | (uintptr_t)dx) & 15) == 0, "ssv_conv2d_dgrad_gelu: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->K % 32 == 0 && d->C % 4 == 0 && d->C >= 128 && d->stride == 1 && d->R == 1 && d->S == 1,
+              "ssv_conv2d_dgrad_gelu: a Linear layer with K %% 32 == 0, C %% 4 == 0, C >= 128 (got K=%d C=%d)", d->K, d->C);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_DGRAD, s);
+  ConvKP p = make_kp(d);
+  p.aux_in = h;
+  const int64_t Mc = (int64_t)d->N * d->H * d->W;
+  const unsigned gx = (unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128));
+  hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32, false, true>), dim3(gx, 1), dim3(256), 0, s, p, dy, w, addend, dx);
+  SSV_CHECK_LAUNCH("ssv_conv2d_dgrad_gelu");
   return SSV_OK;
 }
 

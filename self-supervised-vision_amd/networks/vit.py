@@ -78,7 +78,7 @@ class Feedforward(hnn.HipModule):
 
     def _run(self, tape, x):
         identity = self.layer_norm._run(tape, x)
-        return self.fc2._run(tape, hnn.gelu(tape, self.fc1._run(tape, x)), addend=identity)     # residual added in the GEMM epilogue
+        return hnn.ffn_gelu(tape, x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, addend=identity)   # GELU and residual in GEMM epilogues
 
 
 class TransformerLayer(hnn.HipModule):

@@ -269,6 +269,42 @@ def gelu(tape, x):
     return y
 
 
+def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
+    """fc2(gelu(fc1(x))) (+ addend) with the GELU folded into the GEMM epilogues: fc1 writes the pre-activation and its GELU in
+    one pass, and in the backward fc2's dgrad applies gelu' before it stores - no stand-alone element-wise pass in either direction."""
+    m, din = x.shape
+    inter = w1.shape[0]
+    if din % 32 or inter < 128 or inter % 32 or w2.shape[0] % 32 or bias_missing(b1, b2):
+        return linear(tape, gelu(tape, linear(tape, x, w1, b1)), w2, b2, addend)
+    h, act = ops.linear_gelu_fwd(x, w1, b1)
+    a4 = None if addend is None else addend.view(m, 1, 1, -1)
+    y = ops.conv2d_fwd(act.view(m, 1, 1, inter), w2, 1, 0, bias=b2, addend=a4).view(m, w2.shape[0])
+    if tape is not None:
+        need_dx = tape.needs_grad(x)
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dy4 = dy.view(m, 1, 1, -1)
+            ops.conv2d_wgrad(act.view(m, 1, 1, inter), dy4, w2, grad_of(w2, slot), 1, 0, accumulate=True)
+            ops.colsum(dy, grad_of(b2, slot), accumulate=True)
+            dh = ops.linear_dgrad_gelu(dy, w2, h)
+            x4, dh4 = x.view(m, 1, 1, din), dh.view(m, 1, 1, inter)
+            ops.conv2d_wgrad(x4, dh4, w1, grad_of(w1, slot), 1, 0, accumulate=True)
+            ops.colsum(dh, grad_of(b1, slot), accumulate=True)
+            dadd = None if addend is None else _accum(existing[1], dy)
+            if not need_dx:
+                return (None, dadd)
+            ex = existing[0]
+            ex4 = None if ex is None else ex.view(m, 1, 1, din)
+            return (ops.conv2d_dgrad(dh4, w1, x4.shape, 1, 0, addend=ex4, out=ex4).view(m, din), dadd)
+        tape.record((x, addend), y, bwd)
+    return y
+
+
+def bias_missing(*biases):
+    return any(b is None for b in biases)
+
+
 def attention(tape, q, k, v, batch, tokens, heads):
     """softmax(q k^T / sqrt(dh)) v per (image, head) on [batch*tokens, heads*dh] matrices; probabilities are never stored."""
     o, lse = ops.attention_fwd(q, k, v, batch, tokens, heads)

@@ -417,3 +417,26 @@ def queue_push(bank, queue_size, pointer, keys, eps=1e-12):
     _lib._dev(bank, keys)
     call("ssv_queue_push", int(queue_size), bank.shape[1], ptr(bank), int(pointer), keys.shape[0], ptr(keys), float(eps), stream())
     return (pointer + keys.shape[0]) % queue_size
+
+
+def linear_gelu_fwd(x, w, bias):
+    """(h, gelu(h)) with h = x w^T + bias, both written by one GEMM epilogue.  x [M, C] dense, w [K, C]."""
+    _lib._dev(x, w, bias)
+    m, c = x.shape
+    w, wshape = _ohwi(w)
+    d = conv_desc((m, 1, 1, c), wshape, 1, 0)
+    h = _empty((m, wshape[0]), x)
+    act = torch.empty_like(h)
+    call("ssv_linear_gelu_fwd", C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(h), ptr(act), stream())
+    return h, act
+
+
+def linear_dgrad_gelu(dy, w, h, addend=None, out=None):
+    """dh = (dy w) * gelu'(h) (+ addend): the backward of `gelu(h) -> Linear(w)` down to the pre-activation, in the dgrad epilogue."""
+    _lib._dev(dy, w, h, addend)
+    m = dy.shape[0]
+    w, wshape = _ohwi(w)
+    d = conv_desc((m, 1, 1, wshape[1]), wshape, 1, 0)
+    dh = out if out is not None else torch.empty_like(h)
+    call("ssv_conv2d_dgrad_gelu", C.byref(d), ptr(dy), ptr(w), ptr(h), ptr(addend), ptr(dh), stream())
+    return dh

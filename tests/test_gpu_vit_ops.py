@@ -183,3 +183,22 @@ def test_multicrop_params_ranges_and_determinism(dev):
     # the per-sample stream depends on the global sample id only
     sub = ops.multicrop_params(8, 224, 224, 8, 16, (0.08, 0.3), 420, 3, sample_ids=ids[40:48].contiguous())
     assert torch.equal(sub, a[40:48])
+
+
+@pytest.mark.parametrize("m,c,k", [(300, 384, 768), (130, 64, 128)])
+def test_linear_gelu_epilogue_fusions(dev, m, c, k):
+    """fc1 + GELU in one GEMM epilogue, and dgrad * gelu'(h): against torch fp64."""
+    from ssv_amd import ops
+    x, w, b, dy, w2, add = (seeded_randn(90 + i, *s) for i, s in enumerate(((m, c), (k, c), (k,), (m, 64), (64, k), (m, k))))
+    w, w2 = w * 0.1, w2 * 0.1
+    xr = x.double()
+    href = xr @ w.double().t() + b.double()
+    h, act = ops.linear_gelu_fwd(x.to(dev), w.to(dev), b.to(dev))
+    _close(h, href, 1e-5, 1e-5)
+    _close(act, F.gelu(href), 1e-5, 1e-5)
+    hh = href.clone().requires_grad_()
+    (F.gelu(hh) @ w2.double().t()).backward(dy.double())
+    got = ops.linear_dgrad_gelu(dy.to(dev), w2.to(dev), h, addend=add.to(dev))
+    _close(got, hh.grad + add.double(), 2e-4, 2e-5)
+    with pytest.raises(Exception):
+        ops.linear_dgrad_gelu(seeded_randn(1, m, 48).to(dev), seeded_randn(2, 48, k).to(dev), h)      # K % 32 != 0 is refused, not silently unfused
