@@ -57,6 +57,11 @@ __device__ __forceinline__ void store_tile_T(float* __restrict__ base, int64_t r
 // forward and dQ passes, queries/dO in the dK/dV pass) are staged once per workgroup into LDS with coalesced 16-byte loads
 // (row stride 68 floats: conflict-free ds_read_b128 of a 32-float row fragment) and double-buffered: the global loads of tile
 // t+1 are in flight while the MFMAs of tile t run.
+// Scores are kept in log2 units (Q is pre-multiplied by scale * log2 e), so every softmax exponential is one v_exp_f32;
+// the saved log-sum-exp stays in natural units (converted on store / load).
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 constexpr int TS = 68;                                        // LDS row stride (floats) of a staged 32 x 64 tile
 
 template <int NW>
@@ -103,7 +108,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_k(int T, int heads, const fl
   const int64_t tok0 = (int64_t)b * T;
   const int qrow = min(q0 + c, T - 1);
   float qreg[32];
-  load_row32(Q + (tok0 + qrow) * ld + h * DH + half * 32, qreg, scale);
+  load_row32(Q + (tok0 + qrow) * ld + h * DH + half * 32, qreg, scale * LOG2E);
   f32x16 o_lo = zero16(), o_hi = zero16();
   float m = -INFINITY, l = 0.f;
   const float* kbase = K + tok0 * ld + h * DH;
@@ -130,10 +135,10 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_k(int T, int heads, const fl
       }
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float mn = fmaxf(m, mt);
-      const float alpha = expf(m - mn);                       // m = -inf on the first tile -> 0
+      const float alpha = ex2(m - mn);                        // m = -inf on the first tile -> 0
       float ls = 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { s[j] = expf(s[j] - mn); ls += s[j]; }
+      for (int j = 0; j < 16; ++j) { s[j] = ex2(s[j] - mn); ls += s[j]; }
       ls += __shfl_xor(ls, 32, 64);
       l = l * alpha + ls;
       m = mn;
@@ -151,7 +156,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_k(int T, int heads, const fl
   }
   const bool valid = q0 + c < T;
   store_tile_T(O + tok0 * ldo + h * DH, ldo, q0 + c, valid, half, o_lo, o_hi, 1.f / l);
-  if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = m + logf(l);
+  if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = (m + log2f(l)) * LN2;
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward: dQ (and delta)
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const
   const int64_t tok0 = (int64_t)b * T;
   const int qrow = min(q0 + c, T - 1);
   float qreg[32], doreg[32];
-  load_row32(Q + (tok0 + qrow) * ld + h * DH + half * 32, qreg, scale);
+  load_row32(Q + (tok0 + qrow) * ld + h * DH + half * 32, qreg, scale * LOG2E);
   load_row32(dO + (tok0 + qrow) * ldo + h * DH + half * 32, doreg, 1.f);
   float delta = 0.f;
   {
@@ -181,7 +186,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const
     delta += __shfl_xor(delta, 32, 64);
   }
   const int64_t stat = ((int64_t)b * heads + h) * T;
-  const float lse = LSE[stat + qrow];
+  const float lse = LSE[stat + qrow] * LOG2E;
   const bool valid = q0 + c < T;
   if (valid && half == 0) DELTA[stat + q0 + c] = delta;
   f32x16 g_lo = zero16(), g_hi = zero16();
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const
       for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i], doreg[i], dp, 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float p = (k0 + rowof(j, half) < T) ? expf(s[j] - lse) : 0.f;
+        const float p = (k0 + rowof(j, half) < T) ? ex2(s[j] - lse) : 0.f;
         s[j] = p * (dp[j] - delta);                            // dS^T
       }
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   Stage<NW> st;
   float st_stat = 0.f;                                        // threads 0..31: lse, 32..63: delta of the staged query rows
   auto load_stat = [&](int q0) {
-    if (threadIdx.x < 64) st_stat = (threadIdx.x < 32 ? LSE : DELTA)[stat + min(q0 + (int)(threadIdx.x & 31), T - 1)];
+    if (threadIdx.x < 64) st_stat = (threadIdx.x < 32 ? LSE : DELTA)[stat + min(q0 + (int)(threadIdx.x & 31), T - 1)] * (threadIdx.x < 32 ? LOG2E : 1.f);
   };
   st.load(qbase, ld, dobase, ldo, 0, T);
   load_stat(0);
@@ -261,14 +266,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       f32x16 s = zero16(), dp = zero16();
       lds_row32(sq[buf], c, half, qreg);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i] * scale, kreg[i], s, 0, 0, 0);   // rows = query, col = key
+      for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i] * (scale * LOG2E), kreg[i], s, 0, 0, 0);   // rows = query, col = key
       lds_row32(sd[buf], c, half, qreg);
 #pragma unroll
       for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[i], vreg[i], dp, 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int r = rowof(j, half);
-        const float p = (q0 + r < T && kvalid) ? expf(s[j] - sstat[buf][0][r]) : 0.f;
+        const float p = (q0 + r < T && kvalid) ? ex2(s[j] - sstat[buf][0][r]) : 0.f;
         s[j] = p;                                              // P
         dp[j] = p * (dp[j] - sstat[buf][1][r]);                // dS
       }
