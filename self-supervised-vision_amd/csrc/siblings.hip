@@ -98,7 +98,6 @@ __global__ void __launch_bounds__(256) relic_apply_k(int N, int D, const float* 
 __global__ void __launch_bounds__(256) moco_rows_k(int N, int D, int K, int ldk, const float* __restrict__ q, const float* __restrict__ k,
                                                    float* __restrict__ neg, float inv_temp, float* __restrict__ dq_init, double* __restrict__ part) {
   __shared__ float sh[4];
-  __shared__ float s_pos;
   const int r = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   auto bsum = [&](float v) { v = wave_sum(v); __syncthreads(); if (lane == 0) sh[w] = v; __syncthreads(); return (sh[0] + sh[1]) + (sh[2] + sh[3]); };
   auto bmax = [&](float v) { v = wave_max(v); __syncthreads(); if (lane == 0) sh[w] = v; __syncthreads(); return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])); };
@@ -117,7 +116,6 @@ __global__ void __launch_bounds__(256) moco_rows_k(int N, int D, int K, int ldk,
   const float cpos = (expf(pos - lse) - 1.f) * g;
   for (int d = threadIdx.x; d < D; d += 256) dq_init[(int64_t)r * D + d] = cpos * k[(int64_t)r * D + d];      // the positive's share of dq
   if (threadIdx.x == 0) part[r] = (double)(lse - pos);
-  (void)s_pos;
 }
 __global__ void moco_loss_sum_k(int N, const double* __restrict__ part, float* __restrict__ loss) {
   __shared__ double sm[256];

@@ -274,7 +274,7 @@ def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
     one pass, and in the backward fc2's dgrad applies gelu' before it stores - no stand-alone element-wise pass in either direction."""
     m, din = x.shape
     inter = w1.shape[0]
-    if din % 32 or inter < 128 or inter % 32 or w2.shape[0] % 32 or bias_missing(b1, b2):
+    if din % 32 or inter < 128 or inter % 32 or w2.shape[0] % 32 or b1 is None or b2 is None:
         return linear(tape, gelu(tape, linear(tape, x, w1, b1)), w2, b2, addend)
     h, act = ops.linear_gelu_fwd(x, w1, b1)
     a4 = None if addend is None else addend.view(m, 1, 1, -1)
@@ -299,10 +299,6 @@ def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
             return (ops.conv2d_dgrad(dh4, w1, x4.shape, 1, 0, addend=ex4, out=ex4).view(m, din), dadd)
         tape.record((x, addend), y, bwd)
     return y
-
-
-def bias_missing(*biases):
-    return any(b is None for b in biases)
 
 
 def attention(tape, q, k, v, batch, tokens, heads):
