@@ -38,6 +38,7 @@ SIGNATURES = {
     "ssv_last_error": (C.c_char_p, []),
     "ssv_device_cus": (C.c_int, []),
     "ssv_conv2d_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_filter_transpose": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssv_conv2d_dgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp]),
     "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),

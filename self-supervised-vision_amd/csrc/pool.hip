@@ -178,6 +178,38 @@ extern "C" int ssv_gap_bwd(int32_t N, int32_t HW, int32_t C, const float* dy, fl
   return SSV_OK;
 }
 
+namespace {
+
+// wt[c][R-1-r][S-1-s][k] = w[k][r][s][c]: the filter bank of the convolution that computes a stride-1 dgrad (transposed in
+// channels, rotated by 180 degrees); 32 x 32 tiles through LDS so both the read and the write are coalesced
+__global__ void __launch_bounds__(256) filter_transpose_k(int K, int RS, int C, const float* __restrict__ w, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int k = k0 + i, c = c0 + tx;
+    tile[i][tx] = (k < K && c < C) ? w[((int64_t)k * RS + tap) * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int tap_t = RS - 1 - tap;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, k = k0 + tx;
+    if (c < C && k < K) wt[((int64_t)c * RS + tap_t) * K + k] = tile[tx][i];
+  }
+}
+
+}  // namespace
+
+extern "C" int ssv_filter_transpose(int32_t K, int32_t R, int32_t S, int32_t C, const float* w, float* wt, void* stream) {
+  SSV_REQUIRE(K > 0 && R > 0 && S > 0 && C > 0 && w && wt && w != wt, "ssv_filter_transpose: bad arguments");
+  SSV_REQUIRE(R * S <= 65535 && cdiv(K, 32) <= 65535, "ssv_filter_transpose: filter too large");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  hipLaunchKernelGGL(filter_transpose_k, dim3(cdiv(C, 32), cdiv(K, 32), R * S), dim3(256), 0, s, K, R * S, C, w, wt);
+  SSV_CHECK_LAUNCH("ssv_filter_transpose");
+  return SSV_OK;
+}
+
 extern "C" int ssv_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, const float* in, float* out, void* stream) {
   SSV_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && in && out, "ssv_nchw_to_nhwc: bad arguments");
   hipStream_t s = (hipStream_t)stream;

@@ -55,6 +55,7 @@ class ParamArena:
         return seg.view(p.shape)
 
     def zero_grad(self):
+        ops.invalidate_weight_caches()                # weights may have changed since the last backward
         ops.fill_(self._grads, 0.0)
 
 

@@ -334,3 +334,29 @@ def test_ntxent_global_batch_4096(dev):
     np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
     close(zid.grad, a.grad, rtol=5e-4, what="dzi")
     close(zjd.grad, b.grad, rtol=5e-4, what="dzj")
+
+
+def test_filter_transpose_and_stride1_dgrad_route(dev):
+    """ssv_filter_transpose, and the stride-1 dgrad computed as a forward convolution with the transposed / rotated filter, against
+    the dgrad kernel itself and torch fp64."""
+    import torch.nn.functional as F
+    from ssv_amd import _lib, ops
+    from conftest import seeded_randn
+    for (n, h, c, k, r, pad) in ((3, 9, 8, 32, 3, 1), (2, 7, 20, 16, 1, 0), (2, 6, 12, 48, 3, 0), (5, 1, 64, 32, 1, 0)):
+        w = (seeded_randn(1, k, c, r, r) * 0.2).contiguous(memory_format=torch.channels_last).to(dev)
+        wt = torch.empty((c, r, r, k), device=dev)
+        _lib.call("ssv_filter_transpose", k, r, r, c, _lib.ptr(w), _lib.ptr(wt), _lib.stream())
+        want = w.permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0)                        # [K,R,S,C] -> rotate -> [C,R,S,K]
+        assert torch.equal(wt, want.contiguous())
+        ho = h + 2 * pad - r + 1
+        dy = seeded_randn(2, n, ho, ho, k).to(dev)
+        add = seeded_randn(3, n, h, h, c).to(dev)
+        got = ops.conv2d_dgrad(dy, w, (n, h, h, c), 1, pad, addend=add)                   # routed through the forward kernel
+        d = ops.conv_desc((n, h, h, c), (k, c, r, r), 1, pad)
+        ref = torch.empty_like(got)
+        _lib.call("ssv_conv2d_dgrad", ops.C.byref(d), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(add), _lib.ptr(ref), _lib.stream())
+        x64 = torch.zeros(n, c, h, h, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x64, w.cpu().double(), padding=pad).backward(dy.cpu().double().permute(0, 3, 1, 2))
+        truth = x64.grad.permute(0, 2, 3, 1) + add.cpu().double()
+        np.testing.assert_allclose(got.cpu().double().numpy(), truth.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ref.cpu().double().numpy(), truth.numpy(), rtol=1e-4, atol=1e-5)

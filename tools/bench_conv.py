@@ -54,7 +54,14 @@ for (H, W, C, K, R, s, p), (name, cnt) in uniq.items():
     else:
         t_d = float("nan")
     tf = lambda t: flop / (t * 1e-3) / 1e12
-    print(f"      {name:12s} {H:3d}x{W:<3d} {C:5d} {K:5d} {R} {s} {cnt:4d} | {t_f:8.3f} {tf(t_f):6.1f} | {t_d:8.3f} {tf(t_d):6.1f} | {t_w:8.3f} {tf(t_w):6.1f}")
+    t_df = float("nan")
+    if s == 1 and C % 4 == 0 and K % 16 == 0:      # stride 1: dgrad == forward convolution of dy with the transposed, 180-degree rotated filter
+        wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)      # [C, K, R, R] in OHWI memory
+        ref = ops.conv2d_dgrad(dy, w, x.shape, s, p)
+        alt = ops.conv2d_fwd(dy, wt, 1, R - 1 - p)
+        assert alt.shape == ref.shape and float((alt - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-6
+        t_df = timeit(lambda: ops.conv2d_fwd(dy, wt, 1, R - 1 - p))
+    print(f"      {name:12s} {H:3d}x{W:<3d} {C:5d} {K:5d} {R} {s} {cnt:4d} | {t_f:8.3f} {tf(t_f):6.1f} | {t_d:8.3f} {tf(t_d):6.1f} | {t_w:8.3f} {tf(t_w):6.1f} | dgrad-as-fwd {t_df:8.3f} {tf(t_df):6.1f}")
     for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
         if t == t:
             tot[k][0] += t * cnt; tot[k][1] += flop * cnt
