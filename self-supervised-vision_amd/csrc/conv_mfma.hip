@@ -858,7 +858,10 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
   w.it = cdiv(d->K, w.bm);
   w.jt = cdiv(RSC, w.bn);
   const int tiles = w.it * w.jt;
-  int64_t ns = cdiv64(768, tiles);            // ~3 workgroups per CU
+  // one resident round: 3 workgroups per CU for the 128-row kernels, 4 for the 64-row ones.  Round DOWN - one workgroup more
+  // than the chip holds costs a whole second round for the stragglers.
+  const int slots = w.bm == 128 ? 768 : 1024;
+  int64_t ns = slots / tiles;
   const int64_t max_by_rows = cdiv64(M, 256);
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
