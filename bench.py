@@ -165,7 +165,7 @@ def cpu_baseline(batch, size, steps, algo="simclr"):
             "sample": f"{steps} timed steps (1 warm-up) of the same {algo} ResNet-50 {size}x{size} step at batch {batch}, torch fp32 CPU"}
 
 
-def cpu_baseline_dino(cores, batch=2, steps=1):
+def cpu_baseline_dino(cores, batch=2, steps=6):
     from oracle import vit as ovit
     m = ovit.DinoOracle(VITS16, BENCH_CFG["dino"]["proj_head"], lr=5e-4)
     g = torch.Generator().manual_seed(7)
@@ -315,7 +315,7 @@ def main():
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch=16, size=s, steps=2, algo=args.algo)
+        out["cpu_baseline"] = cpu_baseline(batch=16, size=s, steps=5, algo=args.algo)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
