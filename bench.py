@@ -21,7 +21,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_FILES = {"simclr": "r01_c_pmc_hbm_traffic_b%d.json", "dino": "r01_h_pmc_hbm_traffic_dino_b%d.json"}   # rocprofv3 --pmc passes, tools/pmc_traffic.py
+# rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py; newest kernel state first
+PMC_FILES = {"simclr": ("r01_j_pmc_hbm_traffic_b%d.json", "r01_c_pmc_hbm_traffic_b%d.json"), "dino": ("r01_h_pmc_hbm_traffic_dino_b%d.json",)}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -275,20 +276,21 @@ def main():
         conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
         conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
         ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, pmc_path = None, None
         try:   # HBM bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; corrected as the guide prescribes)
             if args.algo not in PMC_FILES:
                 raise KeyError(args.algo)                          # PMC passes exist for the headline workload and for DINO
-            with open(os.path.join(ROOT, "profiles", PMC_FILES[args.algo] % b)) as fh:
+            pmc_path = next(pth for pth in (os.path.join(ROOT, "profiles", f % b) for f in PMC_FILES[args.algo]) if os.path.exists(pth))
+            with open(pmc_path) as fh:
                 pmc = json.load(fh)["per_step_gb"]
             traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")), 1)
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         attn_ms = prof.get("attn", (0.0, 0))[0] / args.prof_steps
         roof = {"bound": "mfma", "kernel": ("implicit-GEMM family running the Linear layers" if args.algo == "dino" else "conv implicit-GEMM family") +
                                            " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (PMC, profiles/%s)" % (PMC_FILES.get(args.algo, "-") % b if args.algo in PMC_FILES else "-"),
+                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, %s)" % (os.path.relpath(pmc_path, ROOT) if traffic is not None else "no PMC pass for this workload"),
                 "algorithmic_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
