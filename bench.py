@@ -31,6 +31,7 @@ def conv_macs_resnet50(h, w, proj_dim=128):
     """Algorithmic work per VIEW: MACs of (conv fwd, conv bwd = dgrad + wgrad without the stem's dgrad, projector fwd)
     and the HBM bytes of the conv family when every operand is moved exactly once (fwd + dgrad + wgrad)."""
     macs = []
+    strided = 0                               # MACs of the stride-2 layers behind the stem: their dgrad runs on the dgrad kernel
     io = []                                   # (input elements, output elements) per conv, for the algorithmic byte count
     ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
     macs.append(ho * wo * 64 * 49 * 3)
@@ -44,18 +45,20 @@ def conv_macs_resnet50(h, w, proj_dim=128):
             io.append((ho * wo * cin, ho * wo * planes))
             h2, w2 = (ho + 2 - 3) // s + 1, (wo + 2 - 3) // s + 1
             macs.append(h2 * w2 * planes * planes * 9)                            # conv2 3x3 (stride here)
+            strided += macs[-1] if s == 2 else 0
             io.append((ho * wo * planes, h2 * w2 * planes))
             macs.append(h2 * w2 * planes * 4 * planes)                            # conv3 1x1
             io.append((h2 * w2 * planes, h2 * w2 * planes * 4))
             if b == 0:
                 macs.append(h2 * w2 * planes * 4 * cin)                           # downsample 1x1
+                strided += macs[-1] if s == 2 else 0
                 io.append((ho * wo * cin, h2 * w2 * planes * 4))
             cin, ho, wo = planes * 4, h2, w2
     fwd = sum(macs)
     bwd = 2 * fwd - macs[0]
     bytes_fwd = 4 * sum(i + o for i, o in io)                        # every operand moved exactly once
     bytes_bwd = 2 * bytes_fwd - 4 * sum(io[0])                       # dgrad + wgrad, no stem dgrad
-    return {"fwd": fwd, "bwd": bwd, "bytes_fwd": bytes_fwd, "bytes_bwd": bytes_bwd}
+    return {"fwd": fwd, "bwd": bwd, "bytes_fwd": bytes_fwd, "bytes_bwd": bytes_bwd, "dgrad_s2": strided, "stem": macs[0]}
 
 
 def step_work(algo, h, w, batch):
@@ -71,7 +74,18 @@ def step_work(algo, h, w, batch):
         head_train, head_fwd, loss_macs = 2048 * 4096 + 2 * 4096 * 4096, 0, 3 * 4096 * 4096
     macs_per_sample = train_views * (c["fwd"] + c["bwd"] + 3 * head_train) + fwd_only_views * (c["fwd"] + head_fwd) + loss_macs
     bytes_per_sample = train_views * (c["bytes_fwd"] + c["bytes_bwd"]) + fwd_only_views * c["bytes_fwd"]
+    # which kernel runs what: stride-1 dgrad (every layer but the seven stride-2 ones) and the heads' dgrad run on the FORWARD kernel
+    dgrad_all = c["fwd"] - c["stem"]
+    per_kernel = {"conv_fwd": train_views * (c["fwd"] + dgrad_all - c["dgrad_s2"] + 2 * head_train) + fwd_only_views * (c["fwd"] + head_fwd) + 2 * loss_macs // 3,
+                  "conv_dgrad": train_views * c["dgrad_s2"],
+                  "conv_wgrad": train_views * (c["fwd"] + head_train) + loss_macs // 3}
+    assert sum(per_kernel.values()) == macs_per_sample
+    KERNEL_WORK.clear()
+    KERNEL_WORK.update({k: 2.0 * v * batch for k, v in per_kernel.items()})
     return 2.0 * macs_per_sample * batch, bytes_per_sample * batch
+
+
+KERNEL_WORK = {}          # algorithmic FLOP per step of each conv kernel class, filled by step_work()
 
 
 ALGOS = {"simclr": ("ssv_amd.models.simclr", "SimCLR"), "byol": ("ssv_amd.models.byol", "BYOL"), "barlow": ("ssv_amd.models.barlow", "BarlowTwins"),
@@ -273,6 +287,10 @@ def main():
         _lib.prof_enable(False)
         hnn.set_view_streams(was_dual)
         classes = {k: {"ms_per_step": round(v[0] / args.prof_steps, 3), "launches_per_step": v[1] // args.prof_steps} for k, v in prof.items() if v[1]}
+        for k, flop in KERNEL_WORK.items():        # per kernel: algorithmic FLOP / its own summed duration (cross-check with profiles/*kernel_stats*.csv)
+            if k in classes and classes[k]["ms_per_step"] > 0:
+                classes[k].update(algorithmic_gflop_per_step=round(flop / 1e9, 1), tflops=round(flop / classes[k]["ms_per_step"] / 1e9, 2),
+                                  avg_launch_ms=round(classes[k]["ms_per_step"] / classes[k]["launches_per_step"], 4))
         conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
         conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
         ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
