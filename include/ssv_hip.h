@@ -52,6 +52,12 @@ typedef struct ssv_conv_desc {
 /* y = conv(x, w) (+ bias[k]) (+ addend)            bias/addend may be NULL */
 int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* stream);
+/* Grouped convolution (conv3x3(groups=32) of the ResNeXt encoders, networks/resnet.py:8-10,57): the grouped filter bank
+ * [K][R][S][C/groups] is expanded to the dense block-diagonal [K][R][S][C] one (zeros elsewhere - exact, they contribute 0) and
+ * run through the dense kernels; the dense weight gradient is gathered back (+= when accumulate).  Correct, not yet fast: the
+ * 3x3 of a 32x4d block does 32x the grouped FLOPs; a group-aware MFMA tiling is the follow-up. */
+int ssv_group_expand(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* wg, float* wd, void* stream);
+int ssv_group_extract(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* dwd, float* dwg, int32_t accumulate, void* stream);
 /* wt[c][R-1-r][S-1-s][k] = w[k][r][s][c].  For stride 1, dgrad(dy, w) == ssv_conv2d_fwd(dy, wt) with pad' = R-1-pad: the host
  * routes stride-1 layers that way (both GEMM operands then stream k-contiguous rows; measured 5-15 % faster than the dgrad kernel) */
 int ssv_filter_transpose(int32_t K, int32_t R, int32_t S, int32_t C, const float* w, float* wt, void* stream);

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
-# arch -> (block kind, blocks per stage, width_per_group)   networks/resnet.py:158-193
+# arch -> (block kind, blocks per stage, width_per_group[, groups])   networks/resnet.py:158-193
 RESNET_SPECS = {
     "resnet18": ("basic", (2, 2, 2, 2), 64),
     "resnet34": ("basic", (3, 4, 6, 3), 64),
@@ -26,9 +26,16 @@ RESNET_SPECS = {
     "resnet152": ("bottleneck", (3, 8, 36, 3), 64),
     "wide_resnet50": ("bottleneck", (3, 4, 6, 3), 128),
     "wide_resnet101": ("bottleneck", (3, 4, 23, 3), 128),
+    "resnext50": ("bottleneck", (3, 4, 6, 3), 4, 32),
+    "resnext101": ("bottleneck", (3, 4, 23, 3), 8, 32),
 }
-ENCODER_DIM = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnet101": 2048,
-               "resnet152": 2048, "wide_resnet50": 2048, "wide_resnet101": 2048}
+ENCODER_DIM = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnet101": 2048, "resnet152": 2048,
+               "wide_resnet50": 2048, "wide_resnet101": 2048, "resnext50": 2048, "resnext101": 2048}
+
+
+def _groups(arch):
+    spec = RESNET_SPECS[arch]
+    return spec[3] if len(spec) > 3 else 1
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -43,7 +50,8 @@ def _plan(arch, reduce_bottom_conv):
     modules order is ``self.modules()`` / state_dict order (downsample is the
     block's last attribute, networks/resnet.py:33,61).
     """
-    kind, counts, base_width = RESNET_SPECS[arch]
+    kind, counts, base_width = RESNET_SPECS[arch][:3]
+    groups = _groups(arch)
     expansion = 1 if kind == "basic" else 4
     stem = ("conv1", 64, 3, 3 if reduce_bottom_conv else 7)
     creation, modules, blocks = [stem], [stem], []
@@ -52,13 +60,13 @@ def _plan(arch, reduce_bottom_conv):
         for b in range(n):
             stride = 2 if (b == 0 and stage > 1) else 1
             prefix = f"layer{stage}.{b}"
-            width = int(planes * base_width / 64)
+            width = int(planes * base_width / 64) * groups               # networks/resnet.py:55
             out_planes = planes * expansion
             has_ds = b == 0 and (stride != 1 or in_planes != out_planes)
             if kind == "basic":
                 convs = [(f"{prefix}.conv1", planes, in_planes, 3), (f"{prefix}.conv2", planes, planes, 3)]
             else:
-                convs = [(f"{prefix}.conv1", width, in_planes, 1), (f"{prefix}.conv2", width, width, 3),
+                convs = [(f"{prefix}.conv1", width, in_planes, 1), (f"{prefix}.conv2", width, width // groups, 3),   # grouped 3x3: [width, width/groups, 3, 3]
                          (f"{prefix}.conv3", out_planes, width, 1)]
             ds = (f"{prefix}.downsample.0", out_planes, in_planes, 1)
             if has_ds:
@@ -152,7 +160,7 @@ def resnet_forward(params, x, arch, reduce_bottom_conv=False):
         else:
             out = F.conv2d(x, params[f"{p}.conv1.weight"])
             out = F.relu(_bn_train(out, params, f"{p}.bn1"))
-            out = F.conv2d(out, params[f"{p}.conv2.weight"], stride=s, padding=1)
+            out = F.conv2d(out, params[f"{p}.conv2.weight"], stride=s, padding=1, groups=_groups(arch))
             out = F.relu(_bn_train(out, params, f"{p}.bn2"))
             out = F.conv2d(out, params[f"{p}.conv3.weight"])
             out = _bn_train(out, params, f"{p}.bn3")

@@ -198,7 +198,50 @@ __global__ void __launch_bounds__(256) filter_transpose_k(int K, int RS, int C, 
   }
 }
 
+// Grouped convolution (ResNeXt, networks/resnet.py:8-10,57): the block-diagonal filter bank as a dense one, zeros off the diagonal.
+// dense[k][tap][c] = (c / Cg == k / Kg) ? grouped[k][tap][c % Cg] : 0;   extract is the inverse gather (with optional +=).
+__global__ void __launch_bounds__(256) group_expand_k(int64_t total, int RS, int Cg, int Kg, int groups, const float* __restrict__ wg, float* __restrict__ wd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int C = Cg * groups;
+  const int c = (int)(i % C);
+  const int64_t kt = i / C;                                   // k * RS + tap
+  const int k = (int)(kt / RS);
+  const int g = k / Kg;
+  wd[i] = (c / Cg == g) ? wg[kt * Cg + (c - g * Cg)] : 0.f;
+}
+__global__ void __launch_bounds__(256) group_extract_k(int64_t total, int RS, int Cg, int Kg, int groups, const float* __restrict__ dwd, float* __restrict__ dwg, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over the grouped tensor
+  if (i >= total) return;
+  const int cg = (int)(i % Cg);
+  const int64_t kt = i / Cg;
+  const int k = (int)(kt / RS);
+  const int g = k / Kg;
+  const float v = dwd[kt * (int64_t)(Cg * groups) + g * Cg + cg];
+  dwg[i] = accumulate ? dwg[i] + v : v;
+}
+
 }  // namespace
+
+extern "C" int ssv_group_expand(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* wg, float* wd, void* stream) {
+  SSV_REQUIRE(K > 0 && R > 0 && S > 0 && Cg > 0 && groups > 0 && K % groups == 0 && wg && wd, "ssv_group_expand: bad arguments (K %% groups == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  const int64_t total = (int64_t)K * R * S * Cg * groups;
+  hipLaunchKernelGGL(group_expand_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, total, R * S, Cg, K / groups, groups, wg, wd);
+  SSV_CHECK_LAUNCH("ssv_group_expand");
+  return SSV_OK;
+}
+
+extern "C" int ssv_group_extract(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* dwd, float* dwg, int32_t accumulate, void* stream) {
+  SSV_REQUIRE(K > 0 && R > 0 && S > 0 && Cg > 0 && groups > 0 && K % groups == 0 && dwd && dwg, "ssv_group_extract: bad arguments (K %% groups == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  const int64_t total = (int64_t)K * R * S * Cg;
+  hipLaunchKernelGGL(group_extract_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, total, R * S, Cg, K / groups, groups, dwd, dwg, accumulate);
+  SSV_CHECK_LAUNCH("ssv_group_extract");
+  return SSV_OK;
+}
 
 extern "C" int ssv_filter_transpose(int32_t K, int32_t R, int32_t S, int32_t C, const float* w, float* wt, void* stream) {
   SSV_REQUIRE(K > 0 && R > 0 && S > 0 && C > 0 && w && wt && w != wt, "ssv_filter_transpose: bad arguments");

@@ -15,12 +15,12 @@ from .. import nn as hnn
 _KAIMING_A = math.sqrt(5)
 
 
-def _fresh_conv(cin, cout, k, stride, pad):
+def _fresh_conv(cin, cout, k, stride, pad, groups=1):
     """nn.Conv2d's construction-time draw (kaiming_uniform_, a=sqrt 5) - it is overwritten later by
     kaiming_normal_, but it must be drawn to keep the global RNG stream aligned with the reference."""
-    w = torch.empty(cout, cin, k, k)
+    w = torch.empty(cout, cin // groups, k, k)
     nn.init.kaiming_uniform_(w, a=_KAIMING_A)
-    return hnn.HipConv2d(cin, cout, k, stride, pad, weight=w)
+    return hnn.HipConv2d(cin, cout, k, stride, pad, weight=w, groups=groups)
 
 
 class _Downsample(nn.Sequential):
@@ -36,12 +36,12 @@ class _ResidualUnit(hnn.HipModule):
     expansion = 1
 
     @staticmethod
-    def plan(cin, planes, stride, base_width):
+    def plan(cin, planes, stride, base_width, groups=1):
         raise NotImplementedError
 
-    def __init__(self, in_planes, planes, stride=1, downsample=None, base_width=64):
+    def __init__(self, in_planes, planes, stride=1, downsample=None, base_width=64, groups=1):
         super().__init__()
-        specs = self.plan(in_planes, planes, stride, base_width)
+        specs = self.plan(in_planes, planes, stride, base_width, groups)
         self.depth = len(specs)
         for i, spec in enumerate(specs, start=1):
             setattr(self, f"conv{i}", _fresh_conv(*spec))
@@ -63,9 +63,9 @@ class _ResidualUnit(hnn.HipModule):
 
 class BasicBlock(_ResidualUnit):
     @staticmethod
-    def plan(cin, planes, stride, base_width):
-        if base_width != 64:
-            raise ValueError("BasicBlock only supports base_width = 64")
+    def plan(cin, planes, stride, base_width, groups=1):
+        if base_width != 64 or groups != 1:
+            raise ValueError("BasicBlock only supports groups = 1 and base_width = 64")
         return [(cin, planes, 3, stride, 1), (planes, planes, 3, 1, 1)]
 
 
@@ -73,23 +73,24 @@ class Bottleneck(_ResidualUnit):
     expansion = 4
 
     @staticmethod
-    def plan(cin, planes, stride, base_width):
-        mid = planes * base_width // 64
-        return [(cin, mid, 1, 1, 0), (mid, mid, 3, stride, 1), (mid, 4 * planes, 1, 1, 0)]      # stride sits on the 3x3
+    def plan(cin, planes, stride, base_width, groups=1):
+        mid = int(planes * base_width / 64) * groups
+        return [(cin, mid, 1, 1, 0), (mid, mid, 3, stride, 1, groups), (mid, 4 * planes, 1, 1, 0)]      # stride (and the groups) sit on the 3x3
 
 
 _STAGE_PLANES = (64, 128, 256, 512)
-_UNSUPPORTED = {"groups": (1,), "replace_stride_with_dilation": (None, [False] * 3, (False,) * 3), "norm_layer": (None,)}
+_UNSUPPORTED = {"replace_stride_with_dilation": (None, [False] * 3, (False,) * 3), "norm_layer": (None,)}
 
 
 class ResNet(hnn.HipModule):
     """forward(img [B,3,H,W] fp32, NCHW or channels_last) -> features [B, 512*expansion].  Keyword surface of the
-    reference constructor; grouped / dilated / custom-norm variants are refused rather than silently computed differently."""
+    reference constructor (grouped 3x3 convolutions = the ResNeXt rows run as dense block-diagonal convolutions); dilated /
+    custom-norm variants are refused rather than silently computed differently."""
 
     def __init__(self, block, layers, num_classes=10, zero_init_residual=False, groups=1, width_per_group=64,
                  replace_stride_with_dilation=None, norm_layer=None, reduce_bottom_conv=False):
         super().__init__()
-        given = dict(groups=groups, replace_stride_with_dilation=replace_stride_with_dilation, norm_layer=norm_layer)
+        given = dict(replace_stride_with_dilation=replace_stride_with_dilation, norm_layer=norm_layer)
         for key, allowed in _UNSUPPORTED.items():
             if given[key] not in allowed:
                 raise NotImplementedError(f"{key}={given[key]!r} is outside the accelerated path")
@@ -97,18 +98,18 @@ class ResNet(hnn.HipModule):
         self.conv1, self.bn1 = _fresh_conv(*stem), hnn.HipBatchNorm(64)
         cin = 64
         for idx, (planes, depth) in enumerate(zip(_STAGE_PLANES, layers), start=1):
-            stage, cin = self._stage(block, cin, planes, depth, 1 if idx == 1 else 2, width_per_group)
+            stage, cin = self._stage(block, cin, planes, depth, 1 if idx == 1 else 2, width_per_group, groups)
             setattr(self, f"layer{idx}", stage)
         self.out_dim = cin
         self._reference_init(zero_init_residual)
 
     @staticmethod
-    def _stage(block, cin, planes, depth, stride, base_width):
+    def _stage(block, cin, planes, depth, stride, base_width, groups=1):
         cout = planes * block.expansion
         # the projection shortcut is constructed (and its weights drawn) BEFORE the unit's own convs
         shortcut = _Downsample(cin, cout, stride) if (stride != 1 or cin != cout) else None
-        units = [block(cin, planes, stride, shortcut, base_width)]
-        units += [block(cout, planes, base_width=base_width) for _ in range(depth - 1)]
+        units = [block(cin, planes, stride, shortcut, base_width, groups)]
+        units += [block(cout, planes, base_width=base_width, groups=groups) for _ in range(depth - 1)]
         return nn.Sequential(*units), cout
 
     def _reference_init(self, zero_init_residual):
@@ -135,7 +136,7 @@ class ResNet(hnn.HipModule):
         return hnn.global_avgpool(tape, x)
 
 
-# name -> (unit, units per stage, fixed constructor keywords); resnext rows exist so the reference names resolve and then refuse
+# name -> (unit, units per stage, fixed constructor keywords)
 _ZOO = {
     "resnet18": (BasicBlock, (2, 2, 2, 2), {}),
     "resnet34": (BasicBlock, (3, 4, 6, 3), {}),

@@ -181,6 +181,27 @@ def conv(tape, x, weight, stride, pad, bias=None):
     return y
 
 
+def grouped_conv(tape, x, weight, groups, stride, pad):
+    """conv2d(groups=g): the grouped filter bank is expanded to its dense block-diagonal form (exact: the zeros contribute 0) and
+    run on the dense MFMA kernels; the dense weight gradient is gathered back into the grouped parameter's gradient."""
+    wd = ops.group_expand(weight, groups)
+    y = ops.conv2d_fwd(x, wd, stride, pad)
+    if tape is not None:
+        need_dx = tape.needs_grad(x)
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dwd = torch.empty_like(wd)
+            ops.conv2d_wgrad(x, dy, wd, dwd, stride, pad, accumulate=False)
+            ops.group_extract(dwd, grad_of(weight, slot), groups, accumulate=True)
+            if not need_dx:
+                return (None,)
+            ex = existing[0]
+            return (ops.conv2d_dgrad(dy, wd, x.shape, stride, pad, addend=ex, out=ex),)
+        tape.record((x,), y, bwd)
+    return y
+
+
 def batchnorm(tape, x, bn, relu=False, residual=None):
     if _STREAMS:                               # running-stat update order across the two view streams: slot 0 first
         st = torch.cuda.current_stream(x.device)
@@ -482,13 +503,15 @@ class HipModule(nn.Module):
 class HipConv2d(HipModule):
     """Bias-free convolution; ``weight`` is [O,I,k,k] in channels_last (OHWI) memory."""
 
-    def __init__(self, cin, cout, k, stride=1, pad=0, weight=None):
+    def __init__(self, cin, cout, k, stride=1, pad=0, weight=None, groups=1):
         super().__init__()
-        w = torch.empty(cout, cin, k, k) if weight is None else weight
+        w = torch.empty(cout, cin // groups, k, k) if weight is None else weight
         self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
-        self.stride, self.pad = stride, pad
+        self.stride, self.pad, self.groups = stride, pad, groups
 
     def _run(self, tape, x):
+        if self.groups > 1:
+            return grouped_conv(tape, x, self.weight, self.groups, self.stride, self.pad)
         return conv(tape, x, self.weight, self.stride, self.pad)
 
     def _apply(self, fn, *a, **k):

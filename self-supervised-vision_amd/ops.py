@@ -473,3 +473,20 @@ def linear_dgrad_gelu(dy, w, h, addend=None, out=None):
     dh = out if out is not None else torch.empty_like(h)
     call("ssv_conv2d_dgrad_gelu", C.byref(d), ptr(dy), ptr(w), ptr(h), ptr(addend), ptr(dh), stream())
     return dh
+
+
+def group_expand(wg, groups):
+    """Grouped filter bank [K, C/groups, R, S] (OHWI memory) -> dense block-diagonal [K, C, R, S] (OHWI memory)."""
+    _lib._dev(wg)
+    wg, (k, cg, r, s_) = _ohwi(wg)
+    wd = torch.empty((k, cg * groups, r, s_), dtype=torch.float32, device=wg.device).contiguous(memory_format=torch.channels_last)
+    call("ssv_group_expand", k, r, s_, cg, groups, ptr(wg), ptr(wd), stream())
+    return wd
+
+
+def group_extract(dwd, dwg, groups, accumulate=True):
+    """dwg (+)= the block-diagonal part of the dense weight gradient dwd."""
+    _lib._dev(dwd, dwg)
+    _, (k, cg, r, s_) = _ohwi(dwg)
+    call("ssv_group_extract", k, r, s_, cg, groups, ptr(dwd), ptr(dwg), int(accumulate), stream())
+    return dwg

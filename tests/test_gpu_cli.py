@@ -107,3 +107,21 @@ def test_main_sibling_algorithms_train(tmp_path, monkeypatch, algo, first_key):
         assert model.memory_bank.ptr == (2 * 80) % 100
         norms = model.memory_bank.bank[:100].norm(dim=1).cpu().numpy()
         np.testing.assert_allclose(norms, 1.0, rtol=1e-4)                         # the queue is full of unit keys after 160 pushes
+
+
+def test_main_simclr_on_resnext50(tmp_path, monkeypatch):
+    """`-m resnext50` (grouped 3x3 convolutions as dense block-diagonal ones) through the CLI."""
+    from ssv_amd import main as cli
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "self-supervised-vision_amd", "configs", "simclr.yaml")))
+    cfg["epochs"], cfg["eval_every"] = 1, 1
+    cfg["data"]["batch_size"] = 16
+    cfg["data"]["synthetic"] = {"num_train": 32, "num_test": 32, "image_size": [32, 32], "num_classes": 10}
+    cfg["linear_eval"]["epochs"] = 1
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.dump(cfg, sort_keys=False))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("WANDB_MODE", "disabled")
+    model = cli.main(["-c", str(path), "-a", "simclr", "-m", "resnext50", "-t", "train", "-o", "run"])
+    state = torch.load(tmp_path / "outputs" / "simclr" / "resnext50" / "run" / "best_model.pt", map_location="cpu")["encoder"]
+    assert tuple(state["layer1.0.conv2.weight"].shape) == (128, 4, 3, 3) and tuple(state["layer4.2.conv2.weight"].shape) == (1024, 32, 3, 3)
+    assert np.isfinite(model.optim.arena.data.cpu().numpy()).all()

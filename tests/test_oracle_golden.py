@@ -150,3 +150,22 @@ def test_knn_accuracy_oracle_matches_reference(golden):
     for (seed, n, d, classes, spread, k), want in zip(g["knn_cases"], g["knn_accuracy"]):
         fvecs, labels = evalknn.clustered_features(int(seed), int(n), int(d), int(classes), float(spread))
         assert evalknn.compute_neighbor_accuracy(fvecs, labels, k=int(k)) == want
+
+
+def test_resnext_oracle_matches_reference(golden):
+    """Grouped 3x3 convolutions (resnext50_32x4d): init draws, features and parameter gradients of the oracle vs the reference."""
+    import torch
+    g = golden["resnext_level"]
+    torch.manual_seed(420)
+    p = oracle.init_resnet("resnext50", True)
+    for k, ref in zip(g["init_keys"], g["init_sums"]):
+        np.testing.assert_allclose(np.array(oracle.tensor_checksum(p[str(k)])), ref, rtol=1e-12, atol=0, err_msg=str(k))
+    for k, v in p.items():
+        if v.dtype.is_floating_point and not k.split(".")[-1].startswith("running"):
+            v.requires_grad_(True)
+    y = oracle.resnet_forward(p, seeded_randn(1400, 4, 3, 32, 32), "resnext50", True)
+    np.testing.assert_allclose(y.detach().numpy(), g["features"], rtol=1e-4, atol=1e-5)
+    y.backward(seeded_randn(1401, 4, 2048))
+    for k, ref in zip(g["grad_keys"], g["grad_sums"]):
+        got = oracle.tensor_checksum(p[str(k)].grad)
+        np.testing.assert_allclose(got[1], ref[1], rtol=2e-3, err_msg=str(k))
