@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_k(int T, int heads, const fl
       for (int j = 0; j < 16; ++j) { o_lo[j] *= alpha; o_hi[j] *= alpha; }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
+        if (k0 + rowof(j, 0) >= T) continue;                   // both keys of this step are padding (wave-uniform): P is 0 there
         const float* vr = sv[buf] + rowof(j, half) * TS;
         o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[c], s[j], o_lo, 0, 0, 0);
         o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 + c], s[j], o_hi, 0, 0, 0);
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
+        if (k0 + rowof(j, 0) >= T) continue;                   // padding keys: dS is 0
         const float* kr = sk[buf] + rowof(j, half) * TS;
         g_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[c], s[j], g_lo, 0, 0, 0);
         g_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[32 + c], s[j], g_hi, 0, 0, 0);
@@ -279,6 +281,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
+        if (q0 + rowof(j, 0) >= T) continue;                   // padding queries: P and dS are 0
         const float* qr = sq[buf] + rowof(j, half) * TS;
         const float* dr = sd[buf] + rowof(j, half) * TS;
         dv_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[c], s[j], dv_lo, 0, 0, 0);
