@@ -331,7 +331,8 @@ def main():
                                f"{loss_desc}" + ("" if args.algo == "dino" else ", SGD-Nesterov"),
                    "input": f"uint8 [B,{s},{s},3] source resident in HBM -> fused GPU two-view augmentation each step",
                    "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
-                   "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if hnn.view_streams() else 1, "last_loss": loss},
+                   "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if hnn.view_streams() else 1, "last_loss": loss,
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1)},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
