@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Many-step sanity run on a small synthetic dataset through the real CLI trainers: the loss must go down and stay finite.
+usage: train_sanity.py <algo> [epochs]"""
+import os, sys, tempfile, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import yaml
+from ssv_amd import main as cli
+
+algo = sys.argv[1]
+epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "self-supervised-vision_amd", "configs")
+cfg = yaml.safe_load(open(os.path.join(root, f"{algo}.yaml")))
+cfg["epochs"], cfg["eval_every"] = epochs, epochs
+cfg["data"]["batch_size"] = 128
+cfg["data"]["synthetic"] = {"num_train": 1024, "num_test": 256, "image_size": [32, 32], "num_classes": 10}
+cfg["linear_eval"]["epochs"] = 1
+cfg["scheduler"]["warmup_epochs"] = min(cfg["scheduler"].get("warmup_epochs", 0), 2)
+if algo == "barlow":
+    cfg["proj_dim"] = 512
+os.environ["WANDB_MODE"] = "disabled"
+with tempfile.TemporaryDirectory() as tmp:
+    path = os.path.join(tmp, "cfg.yaml")
+    open(path, "w").write(yaml.dump(cfg, sort_keys=False))
+    os.chdir(tmp)
+    arch = "vit" if algo == "dino" else "resnet18"
+    model = cli.main(["-c", path, "-a", algo, "-m", arch, "-t", "train", "-o", "run"])
+    log = open(os.path.join(tmp, "outputs", algo, arch, "run", "trainlogs.txt")).read().splitlines()
+    losses = [float(l.split("[loss]")[1].split()[0]) for l in log if "[loss]" in l]
+print(json.dumps({"algo": algo, "epoch_mean_losses": losses}))
