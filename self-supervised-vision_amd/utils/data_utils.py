@@ -42,10 +42,29 @@ def _load_cifar(root, name, train):
 
 
 def _synthetic(spec, train, seed=420):
+    """`kind: noise` (default): i.i.d. uint8 pixels, random labels - for throughput runs and smoke tests.
+    `kind: patterns`: every class is a smooth random colour field (a 4x4 grid of colours, bilinearly enlarged) seen under a random
+    shift, a random contrast and pixel noise - a dataset on which the label is learnable, for end-to-end training checks."""
     n = int(spec.get("num_train", 4096) if train else spec.get("num_test", 1024))
     h, w = spec.get("image_size", [32, 32])
+    classes = int(spec.get("num_classes", 10))
     rng = np.random.default_rng(seed + (0 if train else 1))
-    return rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8), rng.integers(0, int(spec.get("num_classes", 10)), size=n)
+    if spec.get("kind", "noise") == "noise":
+        return rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8), rng.integers(0, classes, size=n)
+    if spec["kind"] != "patterns":
+        raise ValueError(f"unknown synthetic kind {spec['kind']!r} (noise | patterns)")
+    grids = np.random.default_rng(seed + 7).uniform(0.0, 1.0, size=(classes, 4, 4, 3))      # the same templates for train and test
+    ys, xs = np.linspace(0, 3, 2 * h), np.linspace(0, 3, 2 * w)
+    y0, x0 = np.floor(ys).astype(int).clip(0, 2), np.floor(xs).astype(int).clip(0, 2)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    big = np.stack([(g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0 + 1][:, x0] * fy * (1 - fx) + g[y0][:, x0 + 1] * (1 - fy) * fx + g[y0 + 1][:, x0 + 1] * fy * fx)
+                    for g in grids])                                                        # [classes, 2h, 2w, 3]
+    labels = rng.integers(0, classes, size=n)
+    oy, ox = rng.integers(0, h, size=n), rng.integers(0, w, size=n)
+    contrast = rng.uniform(0.6, 1.0, size=(n, 1, 1, 1))
+    imgs = np.stack([big[c, a:a + h, b:b + w] for c, a, b in zip(labels, oy, ox)])
+    imgs = 0.5 + (imgs - 0.5) * contrast + rng.normal(0.0, 0.08, size=imgs.shape)
+    return np.ascontiguousarray((imgs.clip(0, 1) * 255).astype(np.uint8)), labels
 
 
 DATASETS = ("cifar10", "cifar100")

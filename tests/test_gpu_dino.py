@@ -133,3 +133,34 @@ def test_dino_epoch_schedules_and_teacher_ema(dev, golden):
     sd = t.teacher_model.state_dict()
     for k, v in o.teacher.items():
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def test_dino_nine_steps_with_epoch_schedules_track_the_oracle(dev):
+    """Three "epochs" of three steps with the per-epoch updates in between (teacher EMA, weight-decay ramp, teacher temperature,
+    lr warm-up / cosine): there is no BatchNorm / ReLU in this path, so the HIP trainer stays on the CPU oracle's trajectory
+    (measured 2e-7 relative at step 9; bar 1e-4)."""
+    from ssv_amd.models.dino import DINO
+    from ssv_amd.utils import train_utils
+    enc = dict(ENC, num_encoder_layers=3)
+    cfg = dict(CFG, epochs=8, encoder=enc, scheduler={"name": "cosine", "warmup_epochs": 2})
+    t = object.__new__(DINO)
+    t.config, t.device, t.train_loader = cfg, dev, [None]
+    torch.manual_seed(420)
+    t._build("vit")
+    t.scheduler, t.warmup_epochs = train_utils.get_scheduler({**cfg["scheduler"], "epochs": cfg["epochs"]}, optimizer=t.optim)
+    t.warmup_rate = (cfg["optimizer"]["lr"] - 1e-12) / t.warmup_epochs
+    o = ovit.DinoOracle(enc, HEAD, warmup_epochs=2)
+    for step in range(9):
+        b = {"global_1": seeded_randn(10 + 4 * step, 8, 2, 3, 32, 32), "global_2": seeded_randn(11 + 4 * step, 8, 2, 3, 32, 32),
+             "local_1": seeded_randn(12 + 4 * step, 8, 3, 3, 8, 8), "local_2": seeded_randn(13 + 4 * step, 8, 3, 3, 8, 8)}
+        got = t.train_step(b)["loss"]
+        want = o.train_step(b["global_1"], b["global_2"], b["local_1"], b["local_2"])["loss"]
+        np.testing.assert_allclose(got, want, rtol=1e-5, err_msg=f"step {step}")
+        if step % 3 == 2:
+            epoch = step // 3 + 1
+            t._after_epoch(epoch)
+            t.adjust_learning_rate(epoch)
+            o.update_teacher(epoch, cfg["epochs"])
+            o.weight_decay, o.temp_teacher = ovit.cosine_ramp(epoch, cfg["epochs"], 0.4, 0.04), ovit.teacher_temperature(epoch)
+            o.lr = 1e-12 + epoch * (1e-4 - 1e-12) / 2 if epoch <= 2 else t.optim.param_groups[0]["lr"]
+            assert abs(t.optim.param_groups[0]["lr"] - o.lr) < 1e-18 and abs(t.optim.param_groups[0]["weight_decay"] - o.weight_decay) < 1e-15

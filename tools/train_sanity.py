@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Many-step sanity run on a small synthetic dataset through the real CLI trainers: the loss must go down and stay finite.
-usage: train_sanity.py <algo> [epochs]"""
+With `patterns` (a dataset whose label is learnable) the kNN accuracy of every epoch is reported too: it must rise above chance (0.1).
+usage: train_sanity.py <algo> [epochs] [noise|patterns]"""
 import os, sys, tempfile, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import yaml
@@ -12,7 +13,11 @@ root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 cfg = yaml.safe_load(open(os.path.join(root, f"{algo}.yaml")))
 cfg["epochs"], cfg["eval_every"] = epochs, epochs
 cfg["data"]["batch_size"] = 128
-cfg["data"]["synthetic"] = {"num_train": 1024, "num_test": 256, "image_size": [32, 32], "num_classes": 10}
+kind = sys.argv[3] if len(sys.argv) > 3 else "noise"
+cfg["data"]["synthetic"] = {"num_train": 2048 if kind == "patterns" else 1024, "num_test": 512 if kind == "patterns" else 256, "image_size": [32, 32],
+                            "num_classes": 10, "kind": kind}
+if kind == "patterns":
+    cfg["eval_every"] = 1
 cfg["linear_eval"]["epochs"] = 1
 cfg["scheduler"]["warmup_epochs"] = min(cfg["scheduler"].get("warmup_epochs", 0), 2)
 if algo == "barlow":
@@ -26,4 +31,5 @@ with tempfile.TemporaryDirectory() as tmp:
     model = cli.main(["-c", path, "-a", algo, "-m", arch, "-t", "train", "-o", "run"])
     log = open(os.path.join(tmp, "outputs", algo, arch, "run", "trainlogs.txt")).read().splitlines()
     losses = [float(l.split("[loss]")[1].split()[0]) for l in log if "[loss]" in l]
-print(json.dumps({"algo": algo, "epoch_mean_losses": losses}))
+accs = [float(l.split("[accuracy]")[1].split()[0]) for l in log if "[accuracy]" in l]
+print(json.dumps({"algo": algo, "data": kind, "epoch_mean_losses": losses, "knn_accuracy": accs}))
