@@ -32,6 +32,9 @@ constexpr int GBK = 16;   // K-step of the generic (scalar gather) path and the 
 // blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous run of logical tiles so that tiles
 // sharing an operand panel hit the same L2.  Bijective for any grid size.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+#ifdef SSV_NO_XCD_REMAP
+  return orig;
+#endif
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
@@ -394,13 +397,17 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       }
 #pragma unroll
       for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
-      lc0 += BK;                                               // straight-line advance (selects, no branches): keeps the
-      const bool w1 = lc0 >= p.C;                              // k-loop body a single scheduling region
-      lc0 = w1 ? 0 : lc0;
-      ls += w1 ? 1 : 0;
-      const bool w2 = ls == p.S;
-      ls = w2 ? 0 : ls;
-      lr += w2 ? 1 : 0;
+      // k order = (channel chunk, r, s) with the TAPS innermost: consecutive k-tiles re-read the same pixels' 128-byte channel
+      // slice shifted by one tap, so the re-reads hit in L2 (with the channel chunk innermost every tap came back from HBM / the
+      // infinity cache: 8-10x the input bytes on the 3x3 layers).  Straight-line advance (selects, no branches) keeps the k-loop
+      // body a single scheduling region.
+      ls += 1;
+      const bool w1 = ls == p.S;
+      ls = w1 ? 0 : ls;
+      lr += w1 ? 1 : 0;
+      const bool w2 = lr == p.R;
+      lr = w2 ? 0 : lr;
+      lc0 += w2 ? BK : 0;
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
