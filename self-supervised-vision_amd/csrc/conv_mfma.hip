@@ -615,12 +615,13 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff + BRP * i * p.RSC * 4, toff_b);
-    lk0 += BK;                                                 // straight-line advance to the next (tap, k-tile)
-    const bool w1 = lk0 >= p.K;
-    lk0 = w1 ? 0 : lk0;
-    ti += w1 ? 1 : 0;
-    const int tc = ti < ntaps ? ti : ntaps - 1;
-    dho = taps[3 * tc]; dwo = taps[3 * tc + 1]; tapoff = taps[3 * tc + 2];
+    // straight-line advance to the next (k-tile, tap) with the TAPS innermost: consecutive tiles re-read the same dY pixels'
+    // channel slice one tap over and hit in L2 (see the forward kernel)
+    ti += 1;
+    const bool w1 = ti >= ntaps;
+    ti = w1 ? 0 : ti;
+    lk0 += w1 ? BK : 0;
+    dho = taps[3 * ti]; dwo = taps[3 * ti + 1]; tapoff = taps[3 * ti + 2];
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
