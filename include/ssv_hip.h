@@ -61,6 +61,12 @@ int ssv_group_extract(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t group
 /* wt[c][R-1-r][S-1-s][k] = w[k][r][s][c].  For stride 1, dgrad(dy, w) == ssv_conv2d_fwd(dy, wt) with pad' = R-1-pad: the host
  * routes stride-1 layers that way (both GEMM operands then stream k-contiguous rows; measured 5-15 % faster than the dgrad kernel) */
 int ssv_filter_transpose(int32_t K, int32_t R, int32_t S, int32_t C, const float* w, float* wt, void* stream);
+/* y = conv(x, w) and, from the same epilogue, the BatchNorm statistics partials of y: for every group g of 64 consecutive output rows
+ * and every channel c, pmean[g][c] = mean and pm2[g][c] = centred sum of squares of that group (shifted sums around the group's first
+ * row).  ssv_bn_train_fwd_partials merges them (fixed order, double) instead of reading y again.  Needs C % 32 == 0, K % 4 == 0;
+ * groups = ssv_conv2d_fwd_stats_groups(d) = ceil(N*Ho*Wo / 64). */
+int64_t ssv_conv2d_fwd_stats_groups(const ssv_conv_desc* d);
+int ssv_conv2d_fwd_stats(const ssv_conv_desc* d, const float* x, const float* w, float* y, float* pmean, float* pm2, void* stream);
 /* dx = conv_transpose(dy, w) (+ addend)            addend may alias dx (accumulate) or be NULL */
 int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend,
                      float* dx, void* stream);
@@ -84,6 +90,10 @@ int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, c
                      void* ws, size_t ws_bytes, void* stream);
 /* bwd: g = dy * (y>0 if relu); dgamma (+)= sum g*xhat; dbeta (+)= sum g;
  * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dresidual = g if not NULL. */
+int ssv_bn_train_fwd_partials(int64_t M, int32_t C, const float* x, const float* pmean, const float* pm2, int32_t rows_per_group,
+                              const float* gamma, const float* beta, const float* residual, int relu, float eps, float momentum,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
 int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const uint8_t* relu_mask, const float* x,
                      const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                      float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,

@@ -344,6 +344,67 @@ extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const floa
   return SSV_OK;
 }
 
+namespace {
+// Merge `factor` consecutive fine partials (rows-per-block rpb, the last one ragged) into one coarse partial per channel, in double
+// and in fixed order, so that the finalize kernel walks M / (rpb * factor) partials instead of M / rpb.
+__global__ void __launch_bounds__(256)
+bn_partials_coarsen_k(int64_t M, int C, int rpb, int nblk, int factor, const float* __restrict__ pmean, const float* __restrict__ pm2,
+                      float* __restrict__ cmean, float* __restrict__ cm2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.y;
+  if (c >= C) return;
+  const int b0 = j * factor, b1 = min(b0 + factor, nblk);
+  const double last_n = (double)(M - (int64_t)(nblk - 1) * rpb), full_n = (double)rpb;
+  double tot = 0.0, sum = 0.0;
+  for (int b = b0; b < b1; ++b) { const double n = b == nblk - 1 ? last_n : full_n; tot += n; sum += n * (double)pmean[(size_t)b * C + c]; }
+  const double mean = sum / tot;
+  double m2 = 0.0;
+  for (int b = b0; b < b1; ++b) {
+    const double n = b == nblk - 1 ? last_n : full_n, d = (double)pmean[(size_t)b * C + c] - mean;
+    m2 += (double)pm2[(size_t)b * C + c] + n * d * d;
+  }
+  cmean[(size_t)j * C + c] = (float)mean;
+  cm2[(size_t)j * C + c] = (float)m2;
+}
+}  // namespace
+
+// Same as ssv_bn_train_fwd, but the statistics partials come from the producer (ssv_conv2d_fwd_stats): no pass over x for them.
+extern "C" int ssv_bn_train_fwd_partials(int64_t M, int32_t C, const float* x, const float* pmean, const float* pm2, int32_t rows_per_group,
+                                         const float* gamma, const float* beta, const float* residual, int relu, float eps, float momentum,
+                                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                         float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_train_fwd_partials")) return rc;
+  SSV_REQUIRE(x && pmean && pm2 && rows_per_group > 0 && gamma && beta && y && save_mean && save_invstd && ws, "ssv_bn_train_fwd_partials: bad arguments");
+  SSV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "ssv_bn_train_fwd_partials: running_mean/var must both be given or both NULL");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_fwd_partials: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_FWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* scale = (float*)ws;
+  float* shift = scale + C;
+  int nblk = (int)cdiv64(M, rows_per_group), rpb = rows_per_group;
+  if (nblk > 2048) {                                          // two-level merge: 32 fine partials -> one coarse one, then the usual finalize
+    const int factor = 32, ncoarse = cdiv(nblk, factor);
+    float* cmean = shift + C;                                 // fits: ssv_bn_workspace_bytes holds 2 * p.nblk * C + 2 * C floats, ncoarse <= p.nblk
+    float* cm2 = cmean + (size_t)ncoarse * C;
+    SSV_REQUIRE(ncoarse <= p.nblk, "ssv_bn_train_fwd_partials: internal: coarse partials do not fit the workspace");
+    hipLaunchKernelGGL(bn_partials_coarsen_k, dim3(cdiv(C, 256), ncoarse), dim3(256), 0, s, M, C, rpb, nblk, factor, pmean, pm2, cmean, cm2);
+    pmean = cmean; pm2 = cm2; rpb *= factor; nblk = ncoarse;
+  }
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, rpb, nblk, pmean, pm2,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
+  const dim3 grid(p.nblk, p.GY);
+  if (relu) {
+    if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
+    else          hipLaunchKernelGGL((bn_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
+  } else {
+    if (residual) hipLaunchKernelGGL((bn_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
+    else          hipLaunchKernelGGL((bn_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
+  }
+  SSV_CHECK_LAUNCH("ssv_bn_train_fwd_partials");
+  return SSV_OK;
+}
+
 extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const uint8_t* relu_mask, const float* x,
                                 const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                                 float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,

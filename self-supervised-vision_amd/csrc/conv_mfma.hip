@@ -44,7 +44,8 @@ struct ConvKP {
   int M;              // fwd/wgrad: N*Ho*Wo
   int RSC;            // R*S*C
   FastDiv dHoWo, dWo, dC, dS;
-  float* aux_out;     // fused-activation variants only: forward also writes gelu(y) here
+  float* aux_out;     // fused-activation variants only: forward also writes gelu(y) here; statistics variant: pmean
+  float* aux_out2;    // statistics variant: pm2
   const float* aux_in;  //                                   dgrad multiplies by gelu'(aux_in) before the addend
 };
 
@@ -285,16 +286,21 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // bias / residual addend are read 16 bytes per lane too).  LDS traffic of one wave is in order, so no barrier is needed
 // inside; the caller has passed the barrier that ends the K loop.  row_off(r) gives the element offset of output row r of
 // the wave tile, or -1.
-template <int TM, int TN, bool EPI = false, class RowOff>
+// STATS: also reduce, per output column, the rows this wave stores (a group of TM*32 consecutive output rows) to (mean, centred sum
+// of squares) - shifted sums around the group's first row, then a shuffle over the lanes that share a column - and write them as
+// one partial of the BatchNorm that follows (layout of bn_stats_finalize_k with rows-per-block = TM*32).
+template <int TM, int TN, bool EPI = false, bool STATS = false, class RowOff>
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
                                              const float* __restrict__ bias, const float* addend, float* out, RowOff&& row_off,
-                                             float* out_act = nullptr, const float* gate = nullptr) {
+                                             float* out_act = nullptr, const float* gate = nullptr,
+                                             float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
   const bool cok = gcol < ncols;
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st_p = {0.f, 0.f, 0.f, 0.f}, st_s1 = {0.f, 0.f, 0.f, 0.f}, st_s2 = {0.f, 0.f, 0.f, 0.f};
   if (bias && cok) b4 = *reinterpret_cast<const f32x4*>(bias + gcol);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -302,12 +308,14 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
+    if constexpr (STATS) { if (tm == 0) st_p = *reinterpret_cast<const f32x4*>(&ep[c4 * 4]); }     // pivot: first row of the group
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int r = q * RPI + r_in;
       f32x4 v = *reinterpret_cast<const f32x4*>(&ep[r * LDE + c4 * 4]);
       const long long off = row_off(tm * 32 + r);
       if (off >= 0 && cok) {
+        if constexpr (STATS) { const f32x4 dv = v - st_p; st_s1 += dv; st_s2 += dv * dv; }
         v += b4;
         if constexpr (EPI) {
           if (gate) {
@@ -329,12 +337,24 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
       }
     }
   }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int o = C4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st_s1[e] += __shfl_xor(st_s1[e], o, 64); st_s2[e] += __shfl_xor(st_s2[e], o, 64); }
+    }
+    if (r_in == 0 && cok && group_rows > 0) {
+      const float n = (float)group_rows;
+      *reinterpret_cast<f32x4*>(pmean + gcol) = st_p + st_s1 / n;
+      *reinterpret_cast<f32x4*>(pm2 + gcol) = st_s2 - st_s1 * st_s1 / n;
+    }
+  }
 }
 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC, bool EPI = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC, bool EPI = false, bool STATS = false>
 __global__ void __launch_bounds__(256)
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
@@ -480,13 +500,23 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 
   // ---- epilogue: acc reg j of lane l is (row (j&3)+8*(j>>2)+4*(l>>5), col l&31) of its 32x32 tile ----
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
-  static_assert(!EPI || (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE), "the fused-activation forward needs the vectorised epilogue");
+  static_assert(!(EPI || STATS) || (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE), "the fused-activation / statistics forward needs the vectorised epilogue");
   if constexpr (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE) {
     if ((p.K & 3) == 0) {             // 16-byte stores need K % 4 == 0 (uniform): whole rows segments through LDS
       const int rbase = m0 + wr0;
-      epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
-                                [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
-                                EPI ? p.aux_out : nullptr, nullptr);
+      if constexpr (STATS) {
+        // this wave's rows rbase .. rbase + TM*32 are group g of the statistics partials (rows-per-group = TM*32 = 64)
+        constexpr int GR = TM * 32;
+        const int g = rbase / GR;
+        const int valid = min(GR, p.M - rbase);
+        epilogue_vec<TM, TN, false, true>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+                                          [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
+                                          nullptr, nullptr, p.aux_out + (size_t)g * p.K, p.aux_out2 + (size_t)g * p.K, valid > 0 ? valid : 0);
+      } else {
+        epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+                                  [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
+                                  EPI ? p.aux_out : nullptr, nullptr);
+      }
       return;
     }
   }
@@ -852,7 +882,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dWo = make_fastdiv((uint32_t)d->Wo);
   p.dC = make_fastdiv((uint32_t)d->C);
   p.dS = make_fastdiv((uint32_t)d->S);
-  p.aux_out = nullptr; p.aux_in = nullptr;
+  p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr;
   return p;
 }
 
@@ -931,6 +961,31 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
     hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, GBK, false, false>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd");
+  return SSV_OK;
+}
+
+// Forward convolution that also leaves the BatchNorm statistics partials of its output: group g = output rows [64 g, 64 g + 64)
+extern "C" int64_t ssv_conv2d_fwd_stats_groups(const ssv_conv_desc* d) {
+  return d ? cdiv64((int64_t)d->N * d->Ho * d->Wo, 64) : 0;
+}
+
+extern "C" int ssv_conv2d_fwd_stats(const ssv_conv_desc* d, const float* x, const float* w, float* y, float* pmean, float* pm2, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_stats")) return rc;
+  SSV_REQUIRE(x && w && y && pmean && pm2, "ssv_conv2d_fwd_stats: null pointer");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)pmean | (uintptr_t)pm2) & 15) == 0, "ssv_conv2d_fwd_stats: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0, "ssv_conv2d_fwd_stats: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.aux_out = pmean; p.aux_out2 = pm2;
+  if (d->K >= 128) {
+    const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+    hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  } else {
+    const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+    hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  }
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_stats");
   return SSV_OK;
 }
 

@@ -52,10 +52,10 @@ class _ResidualUnit(hnn.HipModule):
         return getattr(self, f"bn{self.depth}")
 
     def _run(self, tape, x):
-        shortcut = x if self.downsample is None else hnn.batchnorm(tape, self.downsample[0]._run(tape, x), self.downsample[1])
+        shortcut = x if self.downsample is None else hnn.batchnorm(tape, self.downsample[0]._run(tape, x, bn_stats=True), self.downsample[1])
         h = x
         for i in range(1, self.depth + 1):
-            h = getattr(self, f"conv{i}")._run(tape, h)
+            h = getattr(self, f"conv{i}")._run(tape, h, bn_stats=True)      # every conv here is followed by its BatchNorm
             closing = i == self.depth
             h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None)
         return h
@@ -129,7 +129,7 @@ class ResNet(hnn.HipModule):
         return ops.nchw_to_nhwc(x)
 
     def _run(self, tape, x):
-        x = hnn.maxpool(tape, hnn.batchnorm(tape, self.conv1._run(tape, x), self.bn1, relu=True))
+        x = hnn.maxpool(tape, hnn.batchnorm(tape, self.conv1._run(tape, x, bn_stats=True), self.bn1, relu=True))
         for idx in range(1, len(_STAGE_PLANES) + 1):
             for unit in getattr(self, f"layer{idx}"):
                 x = unit._run(tape, x)

@@ -161,8 +161,18 @@ def grad_of(p, slot=0):
 
 
 # ------------------------------------------------------------------------------------------- ops on the tape
-def conv(tape, x, weight, stride, pad, bias=None):
-    y = ops.conv2d_fwd(x, weight, stride, pad, bias=bias)
+_FUSE_BN_STATS = os.environ.get("SSV_NO_BN_STATS_FUSION", "0") != "1"
+
+
+def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
+    """``bn_stats``: the caller normalises the output next - let the conv epilogue produce the statistics partials (kept on the
+    output tensor as ``_bn_partials`` for `batchnorm`), which saves BatchNorm's own pass over the conv output."""
+    fused = ops.conv2d_fwd_stats(x, weight, stride, pad) if (bn_stats and bias is None and _FUSE_BN_STATS) else None
+    if fused is not None:
+        y = fused[0]
+        y._bn_partials = (fused[1], fused[2])
+    else:
+        y = ops.conv2d_fwd(x, weight, stride, pad, bias=bias)
     if tape is not None:
         need_dx = tape.needs_grad(x)
 
@@ -209,7 +219,8 @@ def batchnorm(tape, x, bn, relu=False, residual=None):
             st.wait_event(bn._order_event)
     y, mean, invstd, mask = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                              relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
-                                             want_mask=True, skip_mask=tape is None)   # 1 byte per 4 elements for the backward
+                                             want_mask=True, skip_mask=tape is None,   # 1 byte per 4 elements for the backward
+                                             partials=x.__dict__.pop("_bn_partials", None))
     if _STREAMS and _SLOT == 0 and torch.cuda.current_stream(x.device) != torch.cuda.default_stream(x.device):
         if bn._order_event is None:
             object.__setattr__(bn, "_order_event", torch.cuda.Event())
@@ -509,10 +520,10 @@ class HipConv2d(HipModule):
         self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
         self.stride, self.pad, self.groups = stride, pad, groups
 
-    def _run(self, tape, x):
+    def _run(self, tape, x, bn_stats=False):
         if self.groups > 1:
             return grouped_conv(tape, x, self.weight, self.groups, self.stride, self.pad)
-        return conv(tape, x, self.weight, self.stride, self.pad)
+        return conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats)
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)

@@ -45,6 +45,21 @@ def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None):
     return y
 
 
+def conv2d_fwd_stats(x, w, stride=1, pad=0):
+    """y = conv(x, w) plus the BatchNorm statistics partials of y from the same epilogue: (y, pmean, pm2) with one partial per
+    64 output rows.  Returns None when the shape is outside the fused kernel's preconditions (C % 32, K % 4)."""
+    _lib._dev(x, w)
+    w, wshape = _ohwi(w)
+    if wshape[1] % 32 or wshape[0] % 4:
+        return None
+    d = conv_desc(x.shape, wshape, stride, pad)
+    y = _empty((d.N, d.Ho, d.Wo, d.K), x)
+    groups = int(_lib.load().ssv_conv2d_fwd_stats_groups(C.byref(d)))
+    part = _empty((2, groups, d.K), x)
+    call("ssv_conv2d_fwd_stats", C.byref(d), ptr(x), ptr(w), ptr(y), ptr(part[0]), ptr(part[1]), stream())
+    return y, part[0], part[1]
+
+
 _WT_CACHE = {}          # (weight address, stream) -> (storage kept alive, transposed filter): one transpose per weight, stream and step
 
 
@@ -104,14 +119,19 @@ def _rows(x):
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, nbt, relu=False, residual=None,
-                 eps=BN_EPS, momentum=BN_MOMENTUM, want_mask=False, skip_mask=False):
-    """Returns (y, mean, invstd[, relu_mask]).  relu_mask: uint8, one byte per four channels, for the backward."""
+                 eps=BN_EPS, momentum=BN_MOMENTUM, want_mask=False, skip_mask=False, partials=None):
+    """Returns (y, mean, invstd[, relu_mask]).  relu_mask: uint8, one byte per four channels, for the backward.
+    ``partials`` = (pmean, pm2) from conv2d_fwd_stats: the statistics pass over x is skipped."""
     _lib._dev(x, gamma, beta, residual)
     m, c = _rows(x)
     y = torch.empty_like(x)
     mean, invstd = _empty((c,), x), _empty((c,), x)
     mask = torch.empty((m * c // 4,), dtype=torch.uint8, device=x.device) if (want_mask and relu and not skip_mask) else None
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
+    if partials is not None:
+        call("ssv_bn_train_fwd_partials", m, c, ptr(x), ptr(partials[0]), ptr(partials[1]), 64, ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
+             ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mask), ptr(mean), ptr(invstd), ptr(ws), ws.numel(), stream())
+        return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
     call("ssv_bn_train_fwd", m, c, ptr(x), ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
          ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mask), ptr(mean), ptr(invstd), ptr(ws), ws.numel(), stream())
     return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)

@@ -360,3 +360,38 @@ def test_filter_transpose_and_stride1_dgrad_route(dev):
         truth = x64.grad.permute(0, 2, 3, 1) + add.cpu().double()
         np.testing.assert_allclose(got.cpu().double().numpy(), truth.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ref.cpu().double().numpy(), truth.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,h,c,k,r,stride", [(3, 9, 32, 128, 3, 1), (2, 7, 64, 64, 1, 1), (5, 10, 32, 260, 3, 2), (1, 5, 96, 16, 1, 1), (7, 3, 128, 512, 1, 1)])
+def test_conv_epilogue_bn_statistics(dev, n, h, c, k, r, stride):
+    """ssv_conv2d_fwd_stats: same output as the plain forward, and BatchNorm from its partials == BatchNorm with its own statistics
+    pass (ragged row counts: the last 64-row group is partial; K = 260 leaves a ragged column tile)."""
+    from ssv_amd import ops
+    pad = r // 2
+    x = seeded_randn(1, n, h, h, c).to(dev)
+    w = (seeded_randn(2, k, c, r, r) * 0.1).contiguous(memory_format=torch.channels_last).to(dev)
+    y_ref = ops.conv2d_fwd(x, w, stride, pad)
+    y, pmean, pm2 = ops.conv2d_fwd_stats(x, w, stride, pad)
+    assert torch.equal(y, y_ref)
+    m = y.numel() // k
+    assert pmean.shape == ((m + 63) // 64, k)
+    y2 = y.view(m, k).cpu().double()
+    for g in range(pmean.shape[0]):
+        blk = y2[64 * g:64 * g + 64]
+        np.testing.assert_allclose(pmean[g].cpu().numpy(), blk.mean(0).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(pm2[g].cpu().numpy(), ((blk - blk.mean(0)) ** 2).sum(0).numpy(), rtol=1e-3, atol=1e-4)
+    gamma, beta = (seeded_randn(3, k).abs() + 0.5).to(dev), seeded_randn(4, k).to(dev)
+    res = seeded_randn(5, *y.shape).to(dev)
+    outs = []
+    for partials in (None, (pmean, pm2)):
+        rm, rv, nbt = torch.zeros(k, device=dev), torch.ones(k, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+        o = ops.bn_train_fwd(y, gamma, beta, rm, rv, nbt, relu=True, residual=res, want_mask=True, partials=partials)
+        outs.append((o, rm, rv, nbt))
+    (a, arm, arv, anbt), (b, brm, brv, bnbt) = outs
+    np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(brm.cpu().numpy(), arm.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(brv.cpu().numpy(), arv.cpu().numpy(), rtol=1e-5)
+    assert int(anbt) == int(bnbt) == 1
+    assert ops.conv2d_fwd_stats(seeded_randn(6, 1, 4, 4, 16).to(dev), (seeded_randn(7, 8, 16, 1, 1)).contiguous(memory_format=torch.channels_last).to(dev)) is None
