@@ -52,6 +52,10 @@ typedef struct ssv_conv_desc {
 /* y = conv(x, w) (+ bias[k]) (+ addend)            bias/addend may be NULL */
 int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* stream);
+/* [npix][cin] -> [npix][cout]: zero-pad the channel axis (cout > cin) or drop / accumulate back its first cout channels (cout < cin).
+ * The image stem runs with its 3 input channels padded to 4: ssv_conv2d_fwd with C == 4 gathers one filter tap per 16-byte load
+ * (nn.Conv2d(3, 64, 7, 2, 3) / (3, 64, 3, 1, 1), networks/resnet.py:96-99), and ssv_conv2d_wgrad takes its float4 path. */
+int ssv_pad_channels(int64_t npix, int32_t cin, int32_t cout, const float* in, float* out, int32_t accumulate, void* stream);
 /* Grouped convolution (conv3x3(groups=32) of the ResNeXt encoders, networks/resnet.py:8-10,57): the grouped filter bank
  * [K][R][S][C/groups] is expanded to the dense block-diagonal [K][R][S][C] one (zeros elsewhere - exact, they contribute 0) and
  * run through the dense kernels; the dense weight gradient is gathered back (+= when accumulate).  Correct, not yet fast: the

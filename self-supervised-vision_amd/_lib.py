@@ -38,6 +38,7 @@ SIGNATURES = {
     "ssv_last_error": (C.c_char_p, []),
     "ssv_device_cus": (C.c_int, []),
     "ssv_conv2d_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_pad_channels": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ssv_group_expand": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssv_group_extract": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ssv_conv2d_fwd_stats_groups": (_i64, [_cd]),

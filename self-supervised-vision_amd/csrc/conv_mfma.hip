@@ -354,7 +354,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC, bool EPI = false, bool STATS = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false>
 __global__ void __launch_bounds__(256)
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
@@ -374,7 +374,59 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
-  if constexpr (VEC) {
+  if constexpr (VEC && C4) {
+    // ---- C == 4 (the image stem with its 3 channels padded to 4): one 16-byte load = one filter TAP of one pixel, a k-tile = BK/4
+    //      consecutive taps.  Lane group tl owns tap kt*CH + tl of the tile: (r, s) by one fast division, bounds per staged row. ----
+    constexpr int CH = BK / 4, RPP = 256 / CH;
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    const int tl = tid % CH, rsub = tid / CH;
+    const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * 16u);
+    const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.RSC * 4u);
+    int hi0[AP], wi0[AP], aoff[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int m = m0 + rsub + RPP * i;
+      const bool ok = m < p.M;
+      const uint32_t mm = ok ? (uint32_t)m : 0u;
+      const uint32_t n = fdiv(mm, p.dHoWo);
+      const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
+      const uint32_t ho = fdiv(rem, p.dWo);
+      const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+      hi0[i] = ok ? (int)ho * p.stride - p.pad : -(1 << 20);
+      wi0[i] = (int)wo * p.stride - p.pad;
+      aoff[i] = (((int)n * p.H + hi0[i]) * p.W + wi0[i]) * 16;
+    }
+    int boff[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int ko = n0 + rsub + RPP * i;
+      boff[i] = ko < p.K ? ko * p.RSC * 4 : OOB_OFF;
+    }
+    const int ntap = p.R * p.S;
+    int lt = tl;                                               // this lane group's tap in the current tile
+    f32x4 ra[AP], rb[BP];
+    auto load_tile = [&]() {
+      const bool tv = lt < ntap;
+      const int r = (int)fdiv((uint32_t)(tv ? lt : 0), p.dS);
+      const int sx = (tv ? lt : 0) - r * p.S;
+      const int toff_x = (r * p.W + sx) * 16, toff_w = lt * 16;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const bool ok = tv & ((unsigned)(hi0[i] + r) < (unsigned)p.H) & ((unsigned)(wi0[i] + sx) < (unsigned)p.W);
+        ra[i] = bload4(rx, ok ? aoff[i] + toff_x : OOB_OFF, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, (tv && boff[i] != OOB_OFF) ? boff[i] + toff_w : OOB_OFF, 0);
+      lt += CH;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + tl * 4]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (rsub + RPP * i) * LDT + tl * 4]) = rb[i];
+    };
+    k_loop<TM, TN, true, true, LDT, LDT, BK, STAGE, DB, AP + BP>((ntap + CH - 1) / CH, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  } else if constexpr (VEC) {
     // ---- C % BK == 0: every k-tile lies inside one filter tap; float4 staging, BK/4 lanes per row ----
     constexpr int CH = BK / 4, RPP = 256 / CH;
     constexpr int AP = BM / RPP, BP = BN / RPP;
@@ -944,7 +996,15 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
   const ConvKP p = make_kp(d);
   const ConvCfg cfg = conv_cfg();
   const int bk = d->C % 32 == 0 ? cfg.bk : 16;
-  if (d->C % 16 == 0) {
+  if (d->C == 4) {                                             // image stems (3 channels padded to 4): tap-vector gather
+    if (d->K >= 128) {
+      const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+      hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, false, true, false, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
+    } else {
+      const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, false, true, false, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
+    }
+  } else if (d->C % 16 == 0) {
     if (d->K >= 128) {
       const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
 #define CALL(B_, D_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, B_, D_, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)

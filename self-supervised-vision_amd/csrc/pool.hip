@@ -221,7 +221,36 @@ __global__ void __launch_bounds__(256) group_extract_k(int64_t total, int RS, in
   dwg[i] = accumulate ? dwg[i] + v : v;
 }
 
+// out[p][0..cout) = in[p][0..cin) followed by zeros (cout > cin): image batches and stem filters 3 -> 4 channels
+__global__ void __launch_bounds__(256) pad_channels_k(int64_t npix, int cin, int cout, const float* __restrict__ in, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * cout) return;
+  const int64_t pix = i / cout;
+  const int c = (int)(i - pix * cout);
+  out[i] = c < cin ? in[pix * cin + c] : 0.f;
+}
+// out[p][0..cout) (+)= in[p][0..cout) of a cin-wide tensor (cout < cin): the gradient of the padded stem filter back to 3 channels
+__global__ void __launch_bounds__(256) unpad_channels_k(int64_t npix, int cin, int cout, const float* __restrict__ in, float* __restrict__ out, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * cout) return;
+  const int64_t pix = i / cout;
+  const int c = (int)(i - pix * cout);
+  const float v = in[pix * cin + c];
+  out[i] = accumulate ? out[i] + v : v;
+}
+
 }  // namespace
+
+extern "C" int ssv_pad_channels(int64_t npix, int32_t cin, int32_t cout, const float* in, float* out, int32_t accumulate, void* stream) {
+  SSV_REQUIRE(npix > 0 && cin > 0 && cout > 0 && cin != cout && in && out, "ssv_pad_channels: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  const int64_t total = npix * cout;
+  if (cout > cin) hipLaunchKernelGGL(pad_channels_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, npix, cin, cout, in, out);
+  else hipLaunchKernelGGL(unpad_channels_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, npix, cin, cout, in, out, accumulate);
+  SSV_CHECK_LAUNCH("ssv_pad_channels");
+  return SSV_OK;
+}
 
 extern "C" int ssv_group_expand(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* wg, float* wd, void* stream) {
   SSV_REQUIRE(K > 0 && R > 0 && S > 0 && Cg > 0 && groups > 0 && K % groups == 0 && wg && wd, "ssv_group_expand: bad arguments (K %% groups == 0)");

@@ -162,6 +162,7 @@ def grad_of(p, slot=0):
 
 # ------------------------------------------------------------------------------------------- ops on the tape
 _FUSE_BN_STATS = os.environ.get("SSV_NO_BN_STATS_FUSION", "0") != "1"
+_PAD_STEM = os.environ.get("SSV_NO_STEM_PADDING", "0") != "1"
 
 
 def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
@@ -187,6 +188,26 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
             ex = existing[0]
             dx = ops.conv2d_dgrad(dy, weight, x.shape, stride, pad, addend=ex, out=ex)
             return (dx,)
+        tape.record((x,), y, bwd)
+    return y
+
+
+def stem_conv(tape, x, weight, stride, pad):
+    """The 3-channel image convolution with both operands padded to 4 channels: the kernels then move one filter tap per 16-byte
+    load (forward) / take their float4 path (wgrad) instead of gathering scalars.  Exact: the fourth channel is zero on both
+    sides.  No input gradient (images)."""
+    k, c, r, s_ = weight.shape
+    xp = ops.pad_channels(x, 4)                                                  # [N,H,W,4]
+    wp = ops.pad_channels(weight.permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)     # OHWI [K,R,S,4], seen as [K,4,R,S] channels_last
+    y = ops.conv2d_fwd(xp, wp, stride, pad)
+    if tape is not None:
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dwp = torch.empty_like(wp)
+            ops.conv2d_wgrad(xp, dy, wp, dwp, stride, pad, accumulate=False)
+            ops.unpad_channels(dwp.permute(0, 2, 3, 1), grad_of(weight, slot).permute(0, 2, 3, 1), accumulate=True)
+            return (None,)
         tape.record((x,), y, bwd)
     return y
 
@@ -523,6 +544,8 @@ class HipConv2d(HipModule):
     def _run(self, tape, x, bn_stats=False):
         if self.groups > 1:
             return grouped_conv(tape, x, self.weight, self.groups, self.stride, self.pad)
+        if self.weight.shape[1] == 3 and (tape is None or not tape.needs_grad(x)) and _PAD_STEM:
+            return stem_conv(tape, x, self.weight, self.stride, self.pad)
         return conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats)
 
     def _apply(self, fn, *a, **k):

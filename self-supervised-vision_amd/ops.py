@@ -510,3 +510,19 @@ def group_extract(dwd, dwg, groups, accumulate=True):
     _, (k, cg, r, s_) = _ohwi(dwg)
     call("ssv_group_extract", k, r, s_, cg, groups, ptr(dwd), ptr(dwg), int(accumulate), stream())
     return dwg
+
+
+def pad_channels(t, channels):
+    """Zero-pad the LAST axis of a dense tensor to `channels` (e.g. an NHWC image batch or an OHWI filter from 3 to 4 channels)."""
+    _lib._dev(t)
+    cin = t.shape[-1]
+    out = torch.empty(t.shape[:-1] + (channels,), dtype=torch.float32, device=t.device)
+    call("ssv_pad_channels", t.numel() // cin, cin, channels, ptr(t), ptr(out), 0, stream())
+    return out
+
+
+def unpad_channels(t, out, accumulate=True):
+    """out (+)= the first out.shape[-1] channels of t (both dense, channel axis last)."""
+    _lib._dev(t, out)
+    call("ssv_pad_channels", t.numel() // t.shape[-1], t.shape[-1], out.shape[-1], ptr(t), ptr(out), int(accumulate), stream())
+    return out

@@ -395,3 +395,26 @@ def test_conv_epilogue_bn_statistics(dev, n, h, c, k, r, stride):
     np.testing.assert_allclose(brv.cpu().numpy(), arv.cpu().numpy(), rtol=1e-5)
     assert int(anbt) == int(bnbt) == 1
     assert ops.conv2d_fwd_stats(seeded_randn(6, 1, 4, 4, 16).to(dev), (seeded_randn(7, 8, 16, 1, 1)).contiguous(memory_format=torch.channels_last).to(dev)) is None
+
+
+@pytest.mark.parametrize("n,h,k,r,stride,pad", [(3, 20, 64, 7, 2, 3), (2, 9, 64, 3, 1, 1), (2, 13, 132, 7, 2, 3), (1, 7, 16, 3, 1, 1)])
+def test_stem_conv_with_channels_padded_to_four(dev, n, h, k, r, stride, pad):
+    """The C == 4 tap-vector gather (forward) and the float4 wgrad on a 3-channel image padded to 4: against torch fp64."""
+    from ssv_amd import ops
+    x3 = seeded_randn(1, n, h, h, 3)
+    w3 = seeded_randn(2, k, 3, r, r) * 0.2
+    xr, wr = x3.permute(0, 3, 1, 2).double(), w3.double().requires_grad_()
+    ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    dy = seeded_randn(3, *ref.permute(0, 2, 3, 1).shape)
+    ref.backward(dy.permute(0, 3, 1, 2).double())
+    xp = ops.pad_channels(x3.to(dev), 4)
+    assert xp.shape == (n, h, h, 4) and float(xp[..., 3].abs().max()) == 0.0 and torch.equal(xp[..., :3].cpu(), x3)
+    wp = ops.pad_channels(w3.permute(0, 2, 3, 1).contiguous().to(dev), 4).permute(0, 3, 1, 2)
+    y = ops.conv2d_fwd(xp, wp, stride, pad)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=2e-5)
+    dwp = torch.empty_like(wp)
+    ops.conv2d_wgrad(xp, dy.to(dev), wp, dwp, stride, pad, accumulate=False)
+    dw3 = torch.full((k, r, r, 3), 1.0, device=dev)
+    ops.unpad_channels(dwp.permute(0, 2, 3, 1), dw3, accumulate=True)
+    np.testing.assert_allclose(dw3.cpu().double().numpy() - 1.0, wr.grad.permute(0, 2, 3, 1).numpy(), rtol=2e-4, atol=2e-4)
+    assert float(dwp.permute(0, 2, 3, 1)[..., 3].abs().max()) == 0.0                    # the padded input channel is all zeros
