@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py; newest kernel state first
-PMC_FILES = {"simclr": ("r01_m_pmc_hbm_traffic_b%d.json", "r01_l_pmc_hbm_traffic_b%d.json"), "dino": ("r01_l_pmc_hbm_traffic_dino_b%d.json", "r01_h_pmc_hbm_traffic_dino_b%d.json")}
+PMC_FILES = {"simclr": ("r01_n_pmc_hbm_traffic_b%d.json", "r01_l_pmc_hbm_traffic_b%d.json"), "dino": ("r01_l_pmc_hbm_traffic_dino_b%d.json", "r01_h_pmc_hbm_traffic_dino_b%d.json")}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
