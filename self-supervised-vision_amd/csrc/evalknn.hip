@@ -100,7 +100,9 @@ __global__ void __launch_bounds__(256) softmax_ce_k(int N, int C, int ld, const 
     for (int c = lane; c < ld; c += 64)
       dlogits[(int64_t)r * ld + c] = c < C ? (expf(row[c] - lse) - (c == y ? 1.f : 0.f)) * gscale : 0.f;
   }
-  if (lane == 0) { row_loss[r] = lse - row[y]; row_hit[r] = arg == y ? 1 : 0; }
+  // a label outside [0, C) never reads past the row: its loss is NaN, which poisons the reported mean (the host wrapper refuses
+  // such labels up front; NLLLoss in the reference raises)
+  if (lane == 0) { row_loss[r] = (unsigned)y < (unsigned)C ? lse - row[y] : __builtin_nanf(""); row_hit[r] = arg == y ? 1 : 0; }
 }
 __global__ void ce_reduce_k(int N, const float* __restrict__ row_loss, const int32_t* __restrict__ row_hit, float* __restrict__ stats) {
   __shared__ double sl[256];

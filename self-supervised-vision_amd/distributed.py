@@ -10,8 +10,11 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = False      # a world of ONE rank still takes the collective code paths (the single-GPU functional test of the RCCL calls)
+
+
 def is_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -24,9 +27,16 @@ def rank():
 
 def init_from_env(backend=None):
     """Initialise from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK if WORLD_SIZE > 1."""
+    global _FORCE
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+    force = os.environ.get("SSV_DIST_FORCE", "0") == "1"          # WORLD_SIZE=1 + SSV_DIST_FORCE=1: every collective runs over one rank
+    if (ws <= 1 and not force) or (dist.is_available() and dist.is_initialized()):
         return rank(), world_size()
+    _FORCE = force and ws <= 1
+    if _FORCE:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
@@ -68,3 +78,17 @@ def broadcast_parameters(flat):
     if is_on():
         dist.broadcast(flat, src=0)
     return flat
+
+
+def broadcast_object(obj, src=0):
+    """Rank ``src``'s python object on every rank (run names, small configuration)."""
+    if not is_on():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def barrier():
+    if is_on():
+        dist.barrier()

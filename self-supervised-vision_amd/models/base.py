@@ -112,6 +112,8 @@ class TwoViewTrainer:
         if not os.path.exists(path):
             raise NotImplementedError(f"Could not find saved checkpoint at {ckpt_dir}")
         self._load_state(torch.load(path, map_location=self.device))
+        from .. import ops
+        ops.invalidate_weight_caches()                                  # parameters were overwritten in place
         self.logger.print(f"Successfully loaded model from {ckpt_dir}")
 
     # ---- schedule -------------------------------------------------------------------------------------------------
@@ -131,13 +133,15 @@ class TwoViewTrainer:
         loaders = {"train": self.train_loader, "test": self.test_loader}
         if split not in loaders:
             raise ValueError(f"Unrecognized split {split}, expected one of [train, test]")
-        loader, total = loaders[split], len(loaders[split])
+        loader, total = loaders[split], loaders[split].num_eval_batches()
         vecs, labels = [], []
-        for done, batch in enumerate(loader, start=1):
+        for done, batch in enumerate(loader.eval_batches(), start=1):      # never sharded: every rank extracts the same features
             vecs.append(self._features(batch["img"].to(self.device)).cpu().numpy())
             labels.append(batch["label"].cpu().numpy())
-            common.progress_bar(progress=done / total, desc=f"Building {split} features")
-        print()
+            if hdist.rank() == 0:
+                common.progress_bar(progress=done / total, desc=f"Building {split} features")
+        if hdist.rank() == 0:
+            print()
         return np.concatenate(vecs), np.concatenate(labels)
 
     @torch.no_grad()
@@ -150,7 +154,7 @@ class TwoViewTrainer:
             fvecs, labels = self.build_features(split=split)
             sets[split] = {"fvecs": fvecs, "labels": labels}
         acc = eval_utils.linear_evaluation(config=self.config["linear_eval"], train_data=sets["train"], test_data=sets["test"],
-                                           num_classes=10, device=self.device)
+                                           num_classes=self.train_loader.num_classes, device=self.device)
         self.logger.write("Test linear eval accuracy: {:.4f}".format(acc), mode="info")
 
     # ---- training loop --------------------------------------------------------------------------------------------
@@ -163,7 +167,8 @@ class TwoViewTrainer:
             if hdist.rank() == 0:
                 common.progress_bar(progress=(step + 1) / total, desc=f"[TRAIN] {tag}", status=meter.return_msg())
             self._after_step(step)
-        print()
+        if hdist.rank() == 0:
+            print()
         return meter
 
     def _validate(self, epoch, tag):
@@ -185,6 +190,7 @@ class TwoViewTrainer:
             self.adjust_learning_rate(epoch)
             if epoch % self.config["eval_every"] == 0:
                 self._validate(epoch, tag)
-        print()
+        if hdist.rank() == 0:
+            print()
         self.logger.print("Completed training. Beginning linear evaluation.", mode="info")
         self.perform_linear_eval()

@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from .. import _lib, nn as hnn
+from .. import _lib, nn as hnn, ops
 from ..utils import losses, train_utils
 from .base import NETWORKS, TwoViewTrainer
 from .heads import ByolMLP as MLP  # noqa: F401
@@ -64,8 +64,7 @@ class BYOL(TwoViewTrainer):
 
     @torch.no_grad()
     def momentum_update(self):
-        n = self._target_arena.numel
-        _lib.call("ssv_ema", n, _lib.ptr(self._target_arena.data), _lib.ptr(self.optim.arena.data), float(self.tau), _lib.stream())
+        ops.ema_(self._target_arena.data, self.optim.arena.data, self.tau)
 
     def _after_step(self, step):
         self.update_tau(step)

@@ -108,6 +108,8 @@ class DINO(TwoViewTrainer):
             p.requires_grad = False
         self.optim = train_utils.get_optimizer(self.config["optimizer"], self.student_model.parameters())
         if self.config.get("gradient_clip", None) is not None:
+            if not isinstance(self.optim, train_utils.FusedAdamW):
+                raise NotImplementedError("gradient_clip is fused into the AdamW update kernel; optimizer.name must be adamw when it is set")
             self.optim.clip = float(self.config["gradient_clip"])          # the clamp hooks, fused into the update kernel
         self._teacher_arena = train_utils.ParamArena(list(self.teacher_model.parameters()), with_grads=False)
         self.loss_fn = _DinoLossFn.apply
@@ -130,7 +132,7 @@ class DINO(TwoViewTrainer):
     @torch.no_grad()
     def update_teacher_model(self, epoch):
         lbd = self._cosine_ramp(epoch, self.config.get("lambda_upper", 1.0), self.config.get("lambda_lower", 0.996))
-        _lib.call("ssv_ema", self._teacher_arena.numel, _lib.ptr(self._teacher_arena.data), _lib.ptr(self.optim.arena.data), float(lbd), _lib.stream())
+        ops.ema_(self._teacher_arena.data, self.optim.arena.data, lbd)
 
     @torch.no_grad()
     def update_teacher_center(self, teacher_1, teacher_2):

@@ -57,7 +57,7 @@ class MoCo(TwoViewTrainer):
 
     @torch.no_grad()
     def momentum_update(self):
-        _lib.call("ssv_ema", self._key_arena.numel, _lib.ptr(self._key_arena.data), _lib.ptr(self.optim.arena.data), float(self.m), _lib.stream())
+        ops.ema_(self._key_arena.data, self.optim.arena.data, self.m)
 
     def _embed(self, img):
         return self.query_encoder(img)

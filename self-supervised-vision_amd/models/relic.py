@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from .. import _lib, nn as hnn
+from .. import _lib, nn as hnn, ops
 from ..utils import losses, train_utils
 from .base import NETWORKS, TwoViewTrainer
 from .byol import OnlineNetwork, TargetNetwork          # same MLP heads (models/relic.py:23-59 == models/byol.py:24-59)
@@ -36,7 +36,7 @@ class ReLIC(TwoViewTrainer):
 
     @torch.no_grad()
     def momentum_update(self):
-        _lib.call("ssv_ema", self._target_arena.numel, _lib.ptr(self._target_arena.data), _lib.ptr(self.optim.arena.data), float(self.tau), _lib.stream())
+        ops.ema_(self._target_arena.data, self.optim.arena.data, self.tau)
 
     def _after_step(self, step):
         self.update_tau(step)

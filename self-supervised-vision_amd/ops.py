@@ -64,7 +64,8 @@ _WT_CACHE = {}          # (weight address, stream) -> (storage kept alive, trans
 
 
 def invalidate_weight_caches():
-    """Called by the optimizers' zero_grad(): the weights may have been updated since the last backward."""
+    """Called by everything that mutates a GEMM operand in place (the optimizers' step() and zero_grad(), the EMA of target
+    networks, MemoryBank pushes, checkpoint loads): a cached transposed filter must never outlive the weights it was made from."""
     _WT_CACHE.clear()
 
 
@@ -213,6 +214,17 @@ def l2norm_bwd(zhat, inv, dzhat, d, normalize=True):
     dz = _empty((rows, d), zhat)
     call("ssv_l2norm_bwd", rows, d, ptr(zhat), zhat.shape[1], ptr(inv), ptr(dzhat), dzhat.shape[1], int(normalize), ptr(dz), stream())
     return dz
+
+
+def ema_(dst_flat, src_flat, momentum):
+    """dst = momentum * dst + (1 - momentum) * src[:len(dst)]: the target arena mirrors a PREFIX of the online arena (same offsets;
+    BYOL's online network has the predictor behind it)."""
+    _lib._dev(dst_flat, src_flat)
+    if dst_flat.numel() > src_flat.numel():
+        raise _lib.SsvError("ema_: the source arena is shorter than the target")
+    invalidate_weight_caches()
+    call("ssv_ema", dst_flat.numel(), ptr(dst_flat), ptr(src_flat), float(momentum), stream())
+    return dst_flat
 
 
 def scale_(x, factor_dev):
@@ -468,6 +480,7 @@ def moco_loss(q, k, neg, queue_size, inv_temp):
 def queue_push(bank, queue_size, pointer, keys, eps=1e-12):
     """bank[(pointer + i) % queue_size] = normalize(keys[i]); returns the new pointer."""
     _lib._dev(bank, keys)
+    invalidate_weight_caches()                        # the bank is a GEMM operand whose transposed image may be cached
     call("ssv_queue_push", int(queue_size), bank.shape[1], ptr(bank), int(pointer), keys.shape[0], ptr(keys), float(eps), stream())
     return (pointer + keys.shape[0]) % queue_size
 

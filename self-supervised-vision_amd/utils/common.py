@@ -45,19 +45,23 @@ class AverageMeter:
 
 
 class Logger:
-    """Tagged lines to <output_dir>/trainlogs.txt (write) and / or the terminal (print); record does both."""
+    """Tagged lines to <output_dir>/trainlogs.txt (write) and / or the terminal (print); record does both.
+    ``active=False`` (every data-parallel rank but 0) makes it a no-op: one process owns the run directory and the terminal."""
 
-    def __init__(self, output_dir):
-        self._fh = open(os.path.join(output_dir, "trainlogs.txt"), "a", buffering=1)
+    def __init__(self, output_dir, active=True):
+        self._fh = open(os.path.join(output_dir, "trainlogs.txt"), "a", buffering=1) if active else None
 
     def print(self, msg, mode=""):
+        if self._fh is None:
+            return
         tag = _TAGS.get(mode, "")
         colour = _ANSI.get(mode)
         line = f"{tag}{msg}"
         sys.stdout.write((f"{colour}{line}{_ANSI['off']}" if colour else line) + "\n")
 
     def write(self, msg, mode):
-        self._fh.write(f"{_TAGS.get(mode, '')}{msg}\n")
+        if self._fh is not None:
+            self._fh.write(f"{_TAGS.get(mode, '')}{msg}\n")
 
     def record(self, msg, mode):
         self.print(msg, mode)
@@ -96,12 +100,17 @@ def initialize_experiment(args, output_root, seed=420):
     hdist.init_from_env()
     seed_everything(seed)
     config = open_config(args["config"])
-    output_dir = os.path.join(output_root, args["output"])
-    os.makedirs(output_dir, exist_ok=True)
+    # data parallel: rank 0 owns the run directory, the log file and the terminal; its --output name (a per-process timestamp
+    # by default) is the one every rank uses, so --load of the run directory finds rank 0's checkpoint
+    lead = hdist.rank() == 0
+    output_dir = os.path.join(output_root, hdist.broadcast_object(args["output"]))
     dumped = yaml.dump(config)
-    with open(os.path.join(output_dir, "hyperparameters.txt"), "w") as fh:
-        fh.write(dumped)
-    logger = Logger(output_dir)
+    if lead:
+        os.makedirs(output_dir, exist_ok=True)
+        with open(os.path.join(output_dir, "hyperparameters.txt"), "w") as fh:
+            fh.write(dumped)
+    hdist.barrier()
+    logger = Logger(output_dir, active=lead)
     rule = "-" * 40
     logger.print(f"Logging at {output_dir}", mode="info")
     for line in (rule, "{:>20}".format("Configuration"), rule, dumped, rule):

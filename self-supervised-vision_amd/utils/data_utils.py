@@ -71,74 +71,120 @@ DATASETS = ("cifar10", "cifar100")
 
 
 class GpuTwoViewLoader:
-    """Iterates {index, img, aug_1, aug_2, label} batches produced on the GPU."""
+    """Iterates {index, img, aug_1, aug_2, label} batches produced on the GPU.
 
-    def __init__(self, images_u8, labels, transforms, batch_size, shuffle, device, seed=420):
+    Data parallel (one process per GPU): every rank draws the SAME permutation (shared seed), walks it in
+    global batches of ``batch_size * world`` and takes rows ``[rank*B, (rank+1)*B)`` of each - the ranks' batches are disjoint
+    and their union is the global batch.  Augmentation streams are keyed by (dataset index, view, global step), so the views
+    of a sample do not depend on the world size.  The ragged last global batch is split evenly; the at most world-1 samples
+    that do not divide are left out of that epoch (equal shard sizes are what the all-gather of the embeddings needs).
+    ``eval_batches()`` is never sharded: BatchNorm runs on batch statistics in the reference's evaluation too, so every
+    rank walks the same full batches and gets the same features as a single-GPU run."""
+
+    def __init__(self, images_u8, labels, transforms, batch_size, shuffle, device, seed=420, rank=None, world=None):
         self.device = device
-        self.images = torch.from_numpy(images_u8).to(device)                 # uint8 [N,H,W,3] resident in HBM
+        self.images = self._resident(images_u8, device)                      # uint8 [N,H,W,3] resident in HBM
         self.labels = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(device)
         self.batch_size, self.shuffle = int(batch_size), shuffle
-        self.train_tf = augmentations.get_transform(transforms["train"])
-        self.test_tf = augmentations.get_transform(transforms["test"])
+        self._rank, self._world = rank, world
+        self._setup_transforms(transforms)
         self.gen = torch.Generator().manual_seed(seed)
         self.step = 0
 
+    @staticmethod
+    def _resident(images_u8, device):
+        if isinstance(images_u8, torch.Tensor):
+            return images_u8.to(device)
+        return torch.from_numpy(images_u8).to(device)
+
+    def _setup_transforms(self, transforms):
+        self.train_tf = augmentations.get_transform(transforms["train"])
+        self.test_tf = augmentations.get_transform(transforms["test"])
+
+    # ---- sharding ------------------------------------------------------------------------------------------------
+    def _shard(self):
+        from .. import distributed as hdist
+        rank = hdist.rank() if self._rank is None else self._rank
+        world = hdist.world_size() if self._world is None else self._world
+        return rank, world
+
+    @property
+    def num_classes(self):
+        return int(self.labels.max().item()) + 1
+
+    def _rank_slices(self, n):
+        """[(start, stop)] into the epoch's permutation: this rank's rows of every global batch."""
+        rank, world = self._shard()
+        b = self.batch_size
+        out = []
+        for s in range(0, n, b * world):
+            rows = min(b * world, n - s)
+            per = b if rows == b * world else rows // world       # ragged tail: equal shards, remainder (< world samples) left out
+            if per > 0:
+                out.append((s + rank * per, s + (rank + 1) * per))
+        return out
+
     def __len__(self):
-        return (self.images.shape[0] + self.batch_size - 1) // self.batch_size     # last batch is NOT dropped
+        return len(self._rank_slices(self.images.shape[0]))                 # per-rank steps; world 1: the last batch is NOT dropped
+
+    def _order(self):
+        n = self.images.shape[0]
+        return torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+
+    def _make(self, idx, step):
+        aug_1, aug_2 = self.train_tf.two_views(self.images, idx, step)
+        img = self.test_tf.one_view(self.images, idx)
+        return {"index": idx, "img": img, "aug_1": aug_1, "aug_2": aug_2, "label": self.labels[idx]}
 
     def __iter__(self):
-        n = self.images.shape[0]
-        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
-        for s in range(0, n, self.batch_size):
-            idx = order[s:s + self.batch_size].to(self.device)
-            aug_1, aug_2 = self.train_tf.two_views(self.images, idx, self.step)
-            img = self.test_tf.one_view(self.images, idx)
+        order = self._order()                                               # identical on every rank (shared seed)
+        for a, b in self._rank_slices(order.numel()):
+            idx = order[a:b].to(self.device)
+            batch = self._make(idx, self.step)                              # self.step is the GLOBAL step: same on every rank
             self.step += 1
-            yield {"index": idx, "img": img, "aug_1": aug_1, "aug_2": aug_2, "label": self.labels[idx]}
+            yield batch
+
+    def eval_batches(self):
+        """{index, img, label} over the whole set in order, full batches on every rank (feature extraction / kNN / linear eval)."""
+        n = self.images.shape[0]
+        for s in range(0, n, self.batch_size):
+            idx = torch.arange(s, min(s + self.batch_size, n), device=self.device)
+            yield {"index": idx, "img": self.test_tf.one_view(self.images, idx), "label": self.labels[idx]}
+
+    def num_eval_batches(self):
+        return (self.images.shape[0] + self.batch_size - 1) // self.batch_size
 
 
-def get_double_augment_dataloaders(dataset_name, root, transforms, batch_size, device=None, synthetic=None):
+def _load(dataset_name, root, synthetic):
     assert synthetic is not None or dataset_name in DATASETS, \
         f"Unrecognized dataset {dataset_name}, expected one of {list(DATASETS)}"
     if synthetic is not None:
-        (xtr, ytr), (xte, yte) = _synthetic(synthetic, True), _synthetic(synthetic, False)
-    else:
-        (xtr, ytr), (xte, yte) = _load_cifar(root, dataset_name, True), _load_cifar(root, dataset_name, False)
+        return _synthetic(synthetic, True), _synthetic(synthetic, False)
+    return _load_cifar(root, dataset_name, True), _load_cifar(root, dataset_name, False)
+
+
+def get_double_augment_dataloaders(dataset_name, root, transforms, batch_size, device=None, synthetic=None):
+    (xtr, ytr), (xte, yte) = _load(dataset_name, root, synthetic)
     train_loader = GpuTwoViewLoader(xtr, ytr, transforms, batch_size, True, device)
     test_loader = GpuTwoViewLoader(xte, yte, transforms, batch_size, False, device)
     return train_loader, test_loader
 
 
 class GpuMultiCropLoader(GpuTwoViewLoader):
-    """Iterates {img, global_1, global_2, local_1, local_2, label} batches (reference MultiCropDataset, utils/data_utils.py:76-92)."""
+    """Iterates {img, global_1, global_2, local_1, local_2, label} batches (reference MultiCropDataset, utils/data_utils.py:76-92);
+    sharded over ranks like GpuTwoViewLoader."""
 
-    def __init__(self, images_u8, labels, multicrop_config, batch_size, shuffle, device, seed=420):
-        self.device = device
-        self.images = torch.from_numpy(images_u8).to(device)
-        self.labels = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(device)
-        self.batch_size, self.shuffle = int(batch_size), shuffle
+    def _setup_transforms(self, multicrop_config):
         self.multi_crop = augmentations.MultiCrop(multicrop_config)
         self.test_tf = augmentations.get_transform(multicrop_config["test_transforms"])
-        self.gen = torch.Generator().manual_seed(seed)
-        self.step = 0
 
-    def __iter__(self):
-        n = self.images.shape[0]
-        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
-        for s in range(0, n, self.batch_size):
-            idx = order[s:s + self.batch_size].to(self.device)
-            batch = self.multi_crop(self.images, idx, self.step)
-            batch.update(img=self.test_tf.one_view(self.images, idx), label=self.labels[idx])
-            self.step += 1
-            yield batch
+    def _make(self, idx, step):
+        batch = self.multi_crop(self.images, idx, step)                     # random streams keyed by the dataset index
+        batch.update(index=idx, img=self.test_tf.one_view(self.images, idx), label=self.labels[idx])
+        return batch
 
 
 def get_multicrop_dataloaders(dataset_name, root, multicrop_config, batch_size, device=None, synthetic=None):
-    assert synthetic is not None or dataset_name in DATASETS, \
-        f"Unrecognized dataset {dataset_name}, expected one of {list(DATASETS)}"
-    if synthetic is not None:
-        (xtr, ytr), (xte, yte) = _synthetic(synthetic, True), _synthetic(synthetic, False)
-    else:
-        (xtr, ytr), (xte, yte) = _load_cifar(root, dataset_name, True), _load_cifar(root, dataset_name, False)
+    (xtr, ytr), (xte, yte) = _load(dataset_name, root, synthetic)
     return (GpuMultiCropLoader(xtr, ytr, multicrop_config, batch_size, True, device),
             GpuMultiCropLoader(xte, yte, multicrop_config, batch_size, False, device))

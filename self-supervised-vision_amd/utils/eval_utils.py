@@ -57,6 +57,10 @@ def linear_evaluation(config, train_data, test_data, num_classes, device):
     to_dev = lambda a, dt: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(device=device, dtype=dt).contiguous()
     xtr, ytr = to_dev(train_data["fvecs"], torch.float32), to_dev(train_data["labels"], torch.int32)
     xte, yte = to_dev(test_data["fvecs"], torch.float32), to_dev(test_data["labels"], torch.int32)
+    for name, y in (("train", ytr), ("test", yte)):
+        lo, hi = int(y.min().item()), int(y.max().item())
+        if lo < 0 or hi >= num_classes:
+            raise ValueError(f"linear_evaluation: {name} labels span [{lo}, {hi}] but num_classes = {num_classes}")
     d = xtr.shape[1]
     if d % 4:
         pad = 4 - d % 4

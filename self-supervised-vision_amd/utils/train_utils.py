@@ -84,6 +84,7 @@ class FusedSGD(torch.optim.Optimizer):
             ops.add_(a.grad, a.grad_alt)
             self.grad_sync(a.grad)
             g2 = None
+        ops.invalidate_weight_caches()               # the transposed-filter cache describes the weights we are about to change
         _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.momentum_buffer),
                   float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), int(self._steps == 0), _lib.stream())
         self._steps += 1
@@ -118,6 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self.grad_sync(a.grad)
             g2 = None
         self._steps += 1
+        ops.invalidate_weight_caches()
         _lib.call("ssv_adamw", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                   float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._steps,
                   self.clip, _lib.stream())

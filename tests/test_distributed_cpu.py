@@ -126,6 +126,31 @@ def _patch_ops():
     ops.conv2d_wgrad, ops.conv2d_fwd, ops.conv2d_dgrad = _emu_conv1x1_wgrad, _emu_conv1x1_fwd, _emu_conv1x1_dgrad
 
 
+class _StubLoader:
+    """GpuTwoViewLoader with the HIP view kernels stubbed out: what runs is the product's permutation / sharding / step logic."""
+
+    def __new__(cls, n, batch, **kw):
+        from ssv_amd.utils import data_utils
+
+        class L(data_utils.GpuTwoViewLoader):
+            def _setup_transforms(self, transforms):
+                pass
+
+            def _make(self, idx, step):
+                return {"index": idx, "step": step}
+        return L(np.zeros((n, 2, 2, 3), np.uint8), np.arange(n) % 5, None, batch, True, torch.device("cpu"), **kw)
+
+
+def _loader_epochs(loader, epochs):
+    out = []
+    for _ in range(epochs):
+        first = loader.step
+        batches = list(loader)
+        assert [b["step"] for b in batches] == list(range(first, first + len(batches))) and len(batches) == len(loader)
+        out.append([b["index"].tolist() for b in batches])
+    return out
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from ssv_amd import distributed as hdist
@@ -227,6 +252,23 @@ def _worker(rank, world, port, out):
         np.testing.assert_allclose(loss.item(), want, rtol=2e-6)
         np.testing.assert_allclose(sg.grad.numpy(), refs[rank][0].numpy(), rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(sl.grad.numpy(), refs[rank][1].numpy(), rtol=1e-5, atol=1e-9)
+        # ---- 7. the CLI's loaders shard every global batch: the ranks' index sets are disjoint, their union is the global batch
+        #         of the SHARED permutation, the step counter (augmentation stream key) is global; broadcast_object / barrier
+        idx_sets = _loader_epochs(_StubLoader(50, 8), epochs=2)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, idx_sets)
+        perm_gen = torch.Generator().manual_seed(420)
+        for epoch in range(2):
+            order = torch.randperm(50, generator=perm_gen)
+            steps = gathered[0][epoch]
+            assert len(steps) == len(gathered[1][epoch]) == 4                      # 3 full global batches of 16 + a ragged one of 2
+            for st in range(4):
+                a, b_ = gathered[0][epoch][st], gathered[1][epoch][st]
+                assert not set(a) & set(b_)
+                assert a + b_ == order[16 * st:16 * st + len(a) + len(b_)].tolist()   # rank r owns rows [r*B, (r+1)*B) of the global batch
+                assert len(a) == len(b_) == (8 if st < 3 else 1)
+        assert hdist.broadcast_object(f"run-of-rank-{rank}") == "run-of-rank-0"
+        hdist.barrier()
         out.put((rank, "ok"))
     except Exception as e:                                        # surface the failure to the parent
         import traceback
@@ -254,3 +296,25 @@ def test_single_process_defaults():
     assert not hdist.is_on() and hdist.world_size() == 1 and hdist.rank() == 0
     t = torch.ones(3)
     assert hdist.all_reduce_sum(t) is t and hdist.all_gather_rows(t, 3) is t
+
+
+def test_loader_sharding_is_a_partition_of_the_single_process_epoch():
+    """World sizes 1, 2, 3, 8 without a process group (rank / world passed in): each global batch is split into equal disjoint
+    shards in rank order; world 1 keeps the reference's ragged last batch; at most world-1 samples are left out per epoch."""
+    n, b = 103, 8
+    single = _loader_epochs(_StubLoader(n, b, rank=0, world=1), 1)[0]
+    assert sum(len(x) for x in single) == n and len(single[-1]) == n % b                 # last batch NOT dropped (utils/data_utils.py:119)
+    order = [i for batch in single for i in batch]
+    assert sorted(order) == list(range(n))
+    for world in (2, 3, 8):
+        per_rank = [_loader_epochs(_StubLoader(n, b, rank=r, world=world), 1)[0] for r in range(world)]
+        assert len({len(x) for x in per_rank}) == 1                                      # every rank runs the same number of steps
+        seen = []
+        for st in range(len(per_rank[0])):
+            shard_sizes = {len(per_rank[r][st]) for r in range(world)}
+            assert len(shard_sizes) == 1                                                 # equal shards: what the all-gather needs
+            glob = [i for r in range(world) for i in per_rank[r][st]]
+            assert glob == order[len(seen):len(seen) + len(glob)]                        # same permutation as the single-process epoch
+            seen += glob
+        assert len(set(seen)) == len(seen) and n - len(seen) < world
+    assert _StubLoader(n, b, rank=0, world=1).num_classes == 5

@@ -185,3 +185,139 @@ def test_two_ranks_match_oracle_data_parallel_emulation():
     # weights move by ~1e-3 of their norm in one step, BN biases start at 0 and ARE the (ReLU-flip-noisy) gradient
     # (which ReLUs flip at rounding level depends on the kernels' summation order: medians of 5e-5 .. 3e-4 were measured across kernel states)
     assert np.median(errs) < 1e-3 and max(errs) < 3e-2, f"median {np.median(errs):.2e}, worst {max(errs):.2e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+_RCCL_WORLD1 = r"""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["SSV_ROOT"])
+from ssv_amd import distributed as hdist
+from ssv_amd.models import heads
+from ssv_amd.networks import resnet
+from ssv_amd.utils import losses, train_utils
+from conftest import seeded_randn
+
+dev = torch.device("cuda", 0)
+a1, a2 = seeded_randn(1, 16, 3, 32, 32).to(dev), seeded_randn(2, 16, 3, 32, 32).to(dev)
+
+
+def step():
+    torch.manual_seed(420)
+    enc, head = resnet.resnet18(reduce_bottom_conv=True).to(dev), heads.SimclrProjectionHead(512, 128).to(dev)
+    opt = train_utils.get_optimizer({"name": "sgd", "lr": 0.2, "weight_decay": 1e-4}, list(enc.parameters()) + list(head.parameters()))
+    hdist.attach_grad_sync(opt)
+    loss = losses.SimclrLoss(True, 0.5)(head(enc(a1)), head(enc(a2)))
+    opt.zero_grad(); loss.backward(); opt.step()
+    zi, zj = seeded_randn(5, 16, 64).to(dev).requires_grad_(), seeded_randn(6, 16, 64).to(dev).requires_grad_()
+    bl = losses.BarlowLoss(True, 0.005)(zi, zj); bl.backward()
+    torch.cuda.synchronize()
+    return loss.item(), opt.arena.data.cpu().numpy(), bl.item(), zi.grad.cpu().numpy(), opt.grad_sync is not None
+
+
+plain = step()                                     # no process group: the collective helpers are the identity
+assert not hdist.is_on() and not plain[4]
+os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["SSV_PORT"], SSV_DIST_FORCE="1")
+hdist.init_from_env(backend="nccl")
+import torch.distributed as dist
+assert hdist.is_on() and dist.get_backend() == "nccl" and hdist.world_size() == 1
+# the raw helpers on RCCL: in-place all_gather_into_tensor with the clone for the aliasing input, SUM all-reduce, broadcast
+buf = torch.arange(12, dtype=torch.float32, device=dev).view(6, 2).clone()
+want = buf.clone()
+assert torch.equal(hdist.all_gather_rows(buf, 6), want)
+t = torch.full((1 << 20,), 3.0, device=dev)
+assert torch.equal(hdist.all_reduce_sum(t), torch.full_like(t, 3.0))
+assert torch.equal(hdist.broadcast_parameters(t), torch.full_like(t, 3.0))
+assert hdist.broadcast_object("x") == "x"
+hdist.barrier()
+forced = step()                                    # all-gather of z, LSE exchange, loss all-reduce, gradient all-reduce - all on RCCL
+assert forced[4]
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print(json.dumps({"loss": [plain[0], forced[0]], "barlow": [plain[2], forced[2]],
+                  "params_equal": bool(np.array_equal(plain[1], forced[1])), "dz_equal": bool(np.array_equal(plain[3], forced[3]))}))
+"""
+
+
+def test_rccl_collectives_run_on_hardware_with_a_world_of_one(tmp_path):
+    """backend "nccl" (= RCCL) with WORLD_SIZE=1 and SSV_DIST_FORCE=1: all_gather_into_tensor / all_reduce / broadcast of
+    distributed.py execute on the GPU, and a full SimCLR step + a Barlow loss routed through them are BITWISE the step without a
+    process group (one rank: the global batch is the local batch)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_world1.py"
+    script.write_text(_RCCL_WORLD1)
+    env = dict(os.environ, SSV_ROOT=root, SSV_PORT=str(_free_port()), PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests")]),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SSV_DIST_BACKEND", "SSV_DIST_FORCE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["loss"][0] == out["loss"][1] and out["barlow"][0] == out["barlow"][1], out
+    assert out["params_equal"] and out["dz_equal"], out
+
+
+def _cli_worker(rank, port, workdir, cfg_path, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank),
+                          SSV_DIST_BACKEND="gloo", WANDB_MODE="disabled")
+        os.chdir(workdir)
+        import torch.distributed as dist
+        from ssv_amd import main as cli
+        from ssv_amd.utils import data_utils
+        seen = []
+        make = data_utils.GpuTwoViewLoader._make
+
+        def spy(self, idx, step):
+            seen.append((step, idx.cpu().tolist()))
+            return make(self, idx, step)
+        data_utils.GpuTwoViewLoader._make = spy
+        model = cli.main(["-c", cfg_path, "-a", "simclr", "-m", "resnet18", "-t", "train"])        # default --output: rank 0's timestamp
+        torch.cuda.synchronize()
+        q.put((rank, "ok", seen, model.output_dir, model.optim.arena.data.cpu().numpy(), len(model.train_loader)))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None, None, None))
+
+
+def test_cli_two_ranks_train_on_disjoint_shards(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 main.py ...` semantics (two ranks, gloo, one GPU): the loaders hand the ranks
+    disjoint halves of every global batch of the shared permutation, only rank 0 writes the run directory, replicas stay identical."""
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "self-supervised-vision_amd", "configs", "simclr.yaml")))
+    cfg["epochs"], cfg["eval_every"] = 2, 1
+    cfg["data"]["batch_size"] = 16                                       # per GPU: global batch 32
+    cfg["data"]["synthetic"] = {"num_train": 72, "num_test": 40, "image_size": [32, 32], "num_classes": 10}     # 72 = 2 global batches + 8
+    cfg["linear_eval"]["epochs"] = 2
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.dump(cfg, sort_keys=False))
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, port, str(tmp_path), str(path), q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(WORLD)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, *_ in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+    (_, _, s0, d0, p0, n0), (_, _, s1, d1, p1, n1) = res
+    assert n0 == n1 == 3 and len(s0) == len(s1) == 6                    # 3 steps per epoch on each rank, 2 epochs
+    gen = torch.Generator().manual_seed(420)
+    for epoch in range(2):
+        order = torch.randperm(72, generator=gen).tolist()
+        for st in range(3):
+            (ga, a), (gb, b) = s0[3 * epoch + st], s1[3 * epoch + st]
+            assert ga == gb == 3 * epoch + st                            # the augmentation stream key is the GLOBAL step
+            assert not set(a) & set(b) and a + b == order[32 * st:32 * st + len(a) + len(b)]
+            assert len(a) == len(b) == (16 if st < 2 else 4)
+    assert d0 == d1                                                      # rank 0's run name on every rank
+    np.testing.assert_array_equal(p0, p1)                                # identical replicas after training on different shards
+    out = tmp_path / d0
+    log = (out / "trainlogs.txt").read_text()
+    assert log.count("[TRAIN] Epoch    1/   2") == 1 and (out / "best_model.pt").exists()      # one writer

@@ -59,12 +59,12 @@ def test_simclr_resnet50_224_bs256_properties(dev):
     np.testing.assert_allclose(z1.float().mean(0).abs().max().item(), 0.0, atol=1e-4)        # bn2 output: zero column mean (beta = 0)
 
 
-def test_dino_vits16_bs32_loss_consistency_and_stream_equivalence(dev):
-    """BASELINE config 5 shape (ViT-S/16, 2 x (2 x 224 + 8 x 96) crops per sample) at a quarter of its batch."""
+def test_dino_vits16_bs128_loss_consistency_and_stream_equivalence(dev):
+    """BASELINE config 5 (ViT-S/16, 2 x (2 x 224 + 8 x 96) crops per sample) at its full per-GPU batch of 128."""
     import bench
     from ssv_amd import nn as hnn
     from ssv_amd.utils import augmentations
-    b = 32
+    b = 128
     tf, source, _ = _views(dev, b, 224)
     mc = augmentations.MultiCrop({**bench.DINO_CROPS, "train_transforms": {
         "color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8}, "random_gray": {"p": 0.2},

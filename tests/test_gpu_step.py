@@ -84,7 +84,7 @@ def _check_grads(m, o, flip_tol=2e-2):
         two fp32 evaluations; ONE such flip in a layer of n elements moves that layer's (and every earlier
         layer's) gradient by ~1/sqrt(n) ~ 1e-3 relative.  (Same effect between the fp32 and an fp64 CPU run:
         tools/diag_grads.py.)  Hence this helper only bounds the error by the flip size; the TIGHT statement
-        is test_gradients_tight_on_a_flip_free_batch below."""
+        is test_gradients_as_close_to_fp64_truth_as_the_cpu_path below; the multi-step 1e-4 statement is tests/test_gpu_trajectories.py."""
     errs = []
     for p, go, off in zip(m.params(), o.last_grads, m.optim.arena.offsets):
         got = m.grads[off:off + p.numel()]

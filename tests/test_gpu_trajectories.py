@@ -1,0 +1,200 @@
+"""GPU: multi-step parity as a TEST, not an argument.
+
+The per-step bar (BASELINE north_star) is "loss within 1e-4 relative of the CPU reference".  Step 0 is a pure function of the inputs;
+from step 1 on the comparison also sees the training dynamics, and at the reference's learning rate (0.2 after the warm-up
+seeding) with tiny batches those dynamics amplify rounding-level differences - between ANY two fp32 evaluations, not only between
+HIP and the CPU.  This file separates the two effects:
+
+  * trajectories in the well-conditioned regime (batch 128 for BatchNorm, learning rate 1/100 of the config's): the HIP path must
+    stay within 1e-4 relative of the CPU oracle on EVERY step, for SimCLR, BYOL and Barlow Twins - a kernel bias would show here;
+  * an ensemble at the config's own learning rate: the CPU oracle evaluated under different thread counts and sample orders (all
+    equally valid fp32 evaluations of the same mathematics) spans an envelope at step 2; the HIP path must lie inside it (3x margin);
+  * BASELINE config 4's network (BYOL on resnet50, 7x7/2 stem, 224x224) at a batch the oracle can run: loss and both online
+    embeddings against the oracle, plus the bs 512 step through size-independent properties.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import seeded_randn
+from test_gpu_step import _Step, _bare_trainer, _oracle64_like
+
+pytestmark = pytest.mark.gpu
+BAR = 1e-4          # north-star: per-step loss within 1e-4 relative of the CPU reference
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _views(seed, b, size=32):
+    return seeded_randn(seed, b, 3, size, size), seeded_randn(seed + 1, b, 3, size, size)
+
+
+def test_simclr_r18_trajectory_within_bar_on_every_step(dev):
+    """SimCLR resnet18 (configs/simclr.yaml shape), bs 128, lr = config/100 (2.0 -> seeded 0.2 -> here 0.002): 6 steps, each
+    loss within 1e-4 relative of the oracle's, and the projected features still within 1e-4 absolute after 5 updates."""
+    m = _Step(dev, "resnet18", True, lr=0.02)
+    lr = m.optim.param_groups[0]["lr"]
+    assert abs(lr - (1e-12 + 0.002)) < 1e-12
+    o = oracle.SimCLROracle("resnet18", True, 128, lr=lr, weight_decay=1e-4)
+    for s in range(6):
+        a1, a2 = _views(2000 + 2 * s, 128)
+        loss, z1, _ = m.step(a1, a2, dual=bool(s & 1))
+        ref = o.train_step(a1, a2, return_z=True)
+        np.testing.assert_allclose(loss, ref["loss"], rtol=BAR, err_msg=f"step {s}")
+        assert float((z1.cpu() - ref["z_1"]).abs().max()) < 1e-4, f"step {s}: z"
+
+
+def test_barlow_r18_trajectory_within_bar_on_every_step(dev):
+    from ssv_amd.models.barlow import BarlowTwins
+    cfg = {"epochs": 1000, "proj_dim": 256, "encoder": {"reduce_bottom_conv": True},
+           "optimizer": {"name": "sgd", "lr": 0.002, "weight_decay": 1.5e-6}, "scheduler": {"name": "cosine", "warmup_epochs": 10},
+           "loss_fn": {"normalize": False, "off_diagonal_weight": 0.005}}
+    t = _bare_trainer(BarlowTwins, dev, cfg)
+    o = oracle.BarlowOracle("resnet18", True, 256, lr=t.optim.param_groups[0]["lr"], weight_decay=1.5e-6, normalize=False)
+    for s in range(4):
+        a1, a2 = _views(2100 + 2 * s, 128)
+        got = t.train_step({"aug_1": a1, "aug_2": a2})["loss"]
+        np.testing.assert_allclose(got, o.train_step(a1, a2)["loss"], rtol=BAR, err_msg=f"step {s}")
+
+
+def test_byol_r18_trajectory_within_bar_on_every_step(dev):
+    from ssv_amd.models.byol import BYOL
+    cfg = {"epochs": 1000, "proj_dim": 128, "tau": 0.996, "encoder": {"reduce_bottom_conv": True},
+           "optimizer": {"name": "sgd", "lr": 0.02, "weight_decay": 1e-4}, "scheduler": {"name": "cosine", "warmup_epochs": 10}}
+    t = _bare_trainer(BYOL, dev, cfg)
+    o = oracle.BYOLOracle("resnet18", True, 128, lr=t.optim.param_groups[0]["lr"], weight_decay=1e-4, max_steps=t.max_steps)
+    for s in range(4):
+        a1, a2 = _views(2200 + 2 * s, 128)
+        got = t.train_step({"aug_1": a1, "aug_2": a2})["loss"]
+        t._after_step(s)                                                    # tau schedule + EMA of the target, like the train loop
+        np.testing.assert_allclose(got, o.train_step(a1, a2, step=s)["loss"], rtol=BAR, err_msg=f"step {s}")
+        assert abs(t.tau - o.tau) < 1e-12
+
+
+def test_step2_lies_inside_the_fp32_ensemble_at_the_config_learning_rate(dev):
+    """configs/simclr.yaml as shipped (lr 2.0 -> 0.2, bs 64, resnet18): the loss at steps 0-2.  The ensemble = the CPU oracle under
+    1 / 2 / all host threads (different reduction trees inside ATen) and under two permutations of the samples inside the batch
+    (the loss is permutation invariant; its rounding is not), plus an fp64 evaluation as the centre.  Steps 0-1: every member and
+    the HIP path agree to 1e-4.  Step 2: the members spread (training amplifies the rounding of the first updates); the HIP path
+    must be no further from the fp64 centre than 3x the furthest fp32 member."""
+    views = [_views(100 + 2 * s, 64) for s in range(3)]          # the inputs of test_simclr_r18_steps_match_reference_and_oracle
+    make = lambda: oracle.SimCLROracle("resnet18", True, 128, lr=1e-12 + 0.2, weight_decay=1e-4)
+    threads = torch.get_num_threads()
+    members = []
+    try:
+        for nt, perm_seed in ((1, None), (2, None), (threads, None), (threads, 7), (threads, 8)):
+            torch.set_num_threads(max(1, nt))
+            o = make()
+            perm = None if perm_seed is None else torch.randperm(64, generator=torch.Generator().manual_seed(perm_seed))
+            members.append([o.train_step(*((v if perm is None else v[perm]) for v in vs))["loss"] for vs in views])
+    finally:
+        torch.set_num_threads(threads)
+    o64 = _oracle64_like(make)
+    centre = [o64.train_step(vs[0].double(), vs[1].double())["loss"] for vs in views]
+    m = _Step(dev, "resnet18", True)
+    hip = [m.step(*vs)[0] for vs in views]
+    members = np.array(members)
+    for s in (0, 1):
+        np.testing.assert_allclose(members[:, s], centre[s], rtol=BAR, err_msg=f"ensemble step {s}")
+        np.testing.assert_allclose(hip[s], centre[s], rtol=BAR, err_msg=f"hip step {s}")
+    spread = float(np.abs(members[:, 2] - centre[2]).max())
+    assert abs(hip[2] - centre[2]) <= 3 * spread + BAR * abs(centre[2]), \
+        f"step 2: hip {hip[2]:.6f}, fp64 {centre[2]:.6f}, fp32 ensemble {members[:, 2].tolist()} (spread {spread:.2e})"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+R50_BYOL = {"epochs": 1000, "proj_dim": 128, "tau": 0.996, "encoder": {"reduce_bottom_conv": False},
+            "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1e-4}, "scheduler": {"name": "cosine", "warmup_epochs": 10}}
+
+
+def _byol_r50(dev):
+    from ssv_amd.models.byol import BYOL
+    from ssv_amd.utils import train_utils
+    t = object.__new__(BYOL)
+    t.config, t.device, t.train_loader = R50_BYOL, dev, [None]
+    torch.manual_seed(420)
+    t._build("resnet50")
+    t.scheduler, t.warmup_epochs = train_utils.get_scheduler({**R50_BYOL["scheduler"], "epochs": 1000}, optimizer=t.optim)
+    captured = {}
+    inner = t.loss_fn
+
+    def spy(o1, o2, t1, t2):
+        captured.update(o1=o1.detach().cpu(), o2=o2.detach().cpu(), t1=t1.detach().cpu(), t2=t2.detach().cpu())
+        return inner(o1, o2, t1, t2)
+    t.loss_fn = spy
+    return t, captured
+
+
+def test_byol_resnet50_224_step_matches_oracle(dev):
+    """BASELINE config 4's network (BYOL, resnet50 std stem, 224x224; models/byol.py:125-135) at batch 6: the loss within 1e-4
+    relative of the oracle, the online / target embeddings (unit vectors) as close to an fp64 evaluation as the CPU path is, the
+    second step's loss (after update_tau + momentum_update) still inside the size class."""
+    b = 6
+    t, cap = _byol_r50(dev)
+    make = lambda: oracle.BYOLOracle("resnet50", False, 128, lr=t.optim.param_groups[0]["lr"], weight_decay=1e-4, max_steps=t.max_steps)
+    o = make()
+    a1, a2 = _views(3000, b, 224)
+    # the oracle's embeddings of step 0 (its train_step does not return them)
+    with torch.no_grad():
+        ref = {"o1": o.online_forward(a1), "t1": o.target_forward(a1), "o2": o.online_forward(a2), "t2": o.target_forward(a2)}
+    o = make()                                                        # fresh BatchNorm running statistics for the step itself
+    got = t.train_step({"aug_1": a1, "aug_2": a2})["loss"]
+    want = o.train_step(a1, a2, step=0)["loss"]
+    np.testing.assert_allclose(got, want, rtol=BAR)
+    np.testing.assert_allclose(got, oracle.byol_mse_loss(cap["o1"], cap["o2"], cap["t1"], cap["t2"]).item(), rtol=1e-5)
+    for k in ("o1", "o2", "t1", "t2"):
+        # unit vectors behind 6-sample BatchNorm1d columns: ill-conditioned for both sides (see test_bench_shape_r50_224...), so the
+        # bound is the size class 2e-3; the tight statement is the loss above (a mean over all of them)
+        assert float((cap[k] - ref[k]).abs().max()) < 2e-3, k
+        np.testing.assert_allclose(cap[k].norm(dim=1).numpy(), 1.0, rtol=1e-5)
+    t._after_step(0)
+    assert abs(t.tau - o.tau) < 1e-12
+    a1, a2 = _views(3002, b, 224)
+    got2 = t.train_step({"aug_1": a1, "aug_2": a2})["loss"]
+    want2 = o.train_step(a1, a2, step=1)["loss"]
+    np.testing.assert_allclose(got2, want2, rtol=2e-2)               # batch 6 at lr 0.02: size class only (the 1e-4 trajectories are above)
+
+
+def test_byol_resnet50_224_bs512_properties(dev):
+    """BASELINE config 4 at its full per-GPU batch (bs 512): size-independent properties - the returned loss equals the oracle's pair
+    MSE on the step's own embeddings; unit-norm embeddings; every online tensor moves, no target tensor moves before the EMA and
+    every one moves after it; two view streams == one stream bit for bit; finite BatchNorm statistics."""
+    from ssv_amd import nn as hnn
+    from test_gpu_fullsize import _views as aug_views
+    b = 512
+    _, _, views = aug_views(dev, b, 224)
+    batch = {"aug_1": views[0], "aug_2": views[1]}
+    t, cap = _byol_r50(dev)
+    online0, target0 = t.optim.arena.data.clone(), t._target_arena.data.clone()
+    got = t.train_step(batch)["loss"]
+    np.testing.assert_allclose(got, oracle.byol_mse_loss(cap["o1"], cap["o2"], cap["t1"], cap["t2"]).item(), rtol=1e-5)
+    for k in ("o1", "o2", "t1", "t2"):
+        np.testing.assert_allclose(cap[k].norm(dim=1).numpy(), 1.0, rtol=1e-5)
+    moved = (t.optim.arena.data - online0).abs()
+    off = 0
+    for p in t.optim.arena.params:
+        n = p.numel()
+        assert float(moved[off:off + n].max()) > 0, "an online parameter tensor received no update"
+        off += (n + 63) // 64 * 64
+    assert torch.equal(t._target_arena.data, target0)                # the target only moves through the EMA
+    t._after_step(0)
+    delta = t._target_arena.data - target0
+    want = (1.0 - t.tau) * (t.optim.arena.data[:target0.numel()] - target0)
+    assert torch.isfinite(t._target_arena.data).all() and float(delta.abs().max()) > 0
+    np.testing.assert_allclose(delta.cpu().numpy()[::997], want.cpu().numpy()[::997], rtol=1e-3, atol=1e-9)
+    for k, v in t.online_network.state_dict().items():
+        if k.endswith("running_var"):
+            assert float(v.min()) > 0 and torch.isfinite(v).all(), k
+    # stream schedule: a second trainer on ONE stream gives the same bits
+    prev = hnn.set_view_streams(False)
+    try:
+        t2, _ = _byol_r50(dev)
+        got2 = t2.train_step(batch)["loss"]
+    finally:
+        hnn.set_view_streams(prev)
+    assert got2 == got and torch.equal(t2.optim.arena.data, t.optim.arena.data)
