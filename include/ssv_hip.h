@@ -71,6 +71,16 @@ int ssv_filter_transpose(int32_t K, int32_t R, int32_t S, int32_t C, const float
  * groups = ssv_conv2d_fwd_stats_groups(d) = ceil(N*Ho*Wo / 64). */
 int64_t ssv_conv2d_fwd_stats_groups(const ssv_conv_desc* d);
 int ssv_conv2d_fwd_stats(const ssv_conv_desc* d, const float* x, const float* w, float* y, float* pmean, float* pm2, void* stream);
+/* The fused conv -> BatchNorm -> ReLU -> conv chain (networks/resnet.py:39-42,68-73: `out = relu(bn1(conv1(x)))` feeding conv2): the
+ * activation between two convolutions is never written.  `x` is the PRODUCER's raw conv output and the kernel applies
+ * relu(x * in_scale[c] + in_shift[c]) while staging it (padding taps stay zero); in_scale / in_shift come from
+ * ssv_bn_stats_finalize.  pmean / pm2 (both or neither) request the statistics epilogue of ssv_conv2d_fwd_stats; in_scale /
+ * in_shift (both or neither) the fused input; at least one of the two.  Needs C % 32 == 0, K % 4 == 0, C <= 1024 with a fused input. */
+int ssv_conv2d_fwd_bnrelu_in_stats(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift,
+                                   const float* w, float* y, float* pmean, float* pm2, void* stream);
+/* ssv_conv2d_wgrad whose x operand is relu(x * in_scale[c] + in_shift[c]) formed on load (same workspace); in_scale == NULL: plain */
+int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy,
+                               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* dx = conv_transpose(dy, w) (+ addend)            addend may alias dx (accumulate) or be NULL */
 int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend,
                      float* dx, void* stream);
@@ -102,6 +112,23 @@ int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, cons
                      const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                      float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);
+/* Pieces of the fused path.  ssv_bn_stats_finalize: statistics partials (ssv_conv2d_fwd_stats layout) -> save_mean / save_invstd,
+ * the affine scale = gamma * invstd, shift = beta - mean * scale that the consumer convolution applies on load, and the running
+ * statistics update - BatchNorm without its apply pass.  ssv_bn_apply: y = relu?(x * scale + shift (+ residual)) where the residual
+ * is either a materialised tensor (res_scale NULL) or the raw output of the projection shortcut's convolution with ITS BatchNorm
+ * folded in (residual * res_scale + res_shift: networks/resnet.py:71-73 `identity = downsample(x); out += identity; relu`).
+ * ssv_bn_relu_bwd_affine: ssv_bn_train_bwd for a BatchNorm + ReLU whose output was never written - the ReLU gate is recomputed
+ * as x * scale + shift > 0 from the forward's own scale / shift (bit-identical to the forward's decision). */
+int ssv_bn_stats_finalize(int64_t M, int32_t C, const float* pmean, const float* pm2, int32_t rows_per_group,
+                          const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+int ssv_bn_apply(int64_t M, int32_t C, const float* x, const float* scale, const float* shift,
+                 const float* residual, const float* res_scale, const float* res_shift, int relu,
+                 float* y, uint8_t* relu_mask, void* stream);
+int ssv_bn_relu_bwd_affine(int64_t M, int32_t C, const float* dy, const float* x, const float* gamma,
+                           const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
+                           float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* out[c] (+)= sum_m x[m][c]   (bias gradient of nn.Linear); same workspace size as BN */
 int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int accumulate,
                void* ws, size_t ws_bytes, void* stream);

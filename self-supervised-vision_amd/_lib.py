@@ -43,6 +43,11 @@ SIGNATURES = {
     "ssv_group_extract": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ssv_conv2d_fwd_stats_groups": (_i64, [_cd]),
     "ssv_conv2d_fwd_stats": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_fwd_bnrelu_in_stats": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_wgrad_bnrelu_in": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_bn_stats_finalize": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssv_bn_apply": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "ssv_bn_relu_bwd_affine": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_bn_train_fwd_partials": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_filter_transpose": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssv_conv2d_dgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp]),

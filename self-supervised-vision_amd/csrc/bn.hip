@@ -129,21 +129,34 @@ bn_stats_finalize_k(int64_t M, int C, int rpb, int nblk, const float* __restrict
 
 // With RELU the kernel can also write the ReLU mask, one byte per float4 (bit e = element e was positive): the backward
 // then reads 1 byte instead of the 16 bytes of y for each group of four elements.
-template <bool RELU, bool RES>
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
+  f32x4 r;
+  r[0] = __builtin_fmaf(a[0], b[0], c[0]); r[1] = __builtin_fmaf(a[1], b[1], c[1]);
+  r[2] = __builtin_fmaf(a[2], b[2], c[2]); r[3] = __builtin_fmaf(a[3], b[3], c[3]);
+  return r;
+}
+
+// RES: 0 none, 1 add a materialised residual, 2 add a residual that is itself a BatchNorm of a raw conv output
+// (res * rscale + rshift: the projection shortcut's BatchNorm folded into the block's closing kernel)
+template <bool RELU, int RES>
 __global__ void __launch_bounds__(256)
 bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ x, const float* __restrict__ scale,
-           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, uint8_t* __restrict__ mask) {
+           const float* __restrict__ shift, const float* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
+           float* __restrict__ y, uint8_t* __restrict__ mask) {
   const int tid = threadIdx.x;
   const int ct = tid % CT, rt = tid / CT;
   const int c4 = blockIdx.y * CT + ct;
   if (rt >= RT || c4 >= C / 4) return;
   const f32x4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
+  f32x4 rsc = {0, 0, 0, 0}, rsh = {0, 0, 0, 0};
+  if constexpr (RES == 2) { rsc = ld4(rscale + 4 * c4); rsh = ld4(rshift + 4 * c4); }
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
   auto body = [&](int64_t r) {
     const size_t o = (size_t)r * C + 4 * c4;
-    f32x4 v = ld4(x + o) * sc + sh;
-    if constexpr (RES) v += ld4(res + o);
+    f32x4 v = fma4(ld4(x + o), sc, sh);
+    if constexpr (RES == 1) v += ld4(res + o);
+    if constexpr (RES == 2) v += fma4(ld4(res + o), rsc, rsh);
     if constexpr (RELU) {
       if (mask) mask[o >> 2] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -174,11 +187,21 @@ __device__ __forceinline__ f32x4 relu_grad(f32x4 g, const float* __restrict__ y,
   return masked<true>(g, ld4(y + o));
 }
 
-template <bool RELU>
+// RELU: 0 no ReLU behind this BatchNorm, 1 mask from the byte mask / the sign of y, 2 mask recomputed as x * scale + shift > 0
+// (the fused path never materialises y nor a mask for conv -> BN -> ReLU -> conv chains; scale / shift are the forward's own
+// floats, so the recomputed mask is the forward's ReLU bit for bit)
+template <int RELU>
+__device__ __forceinline__ f32x4 bwd_gate(f32x4 g, f32x4 xv, f32x4 sc, f32x4 sh, const float* __restrict__ y, const uint8_t* __restrict__ mask, size_t o) {
+  if constexpr (RELU == 1) return relu_grad(g, y, mask, o);
+  if constexpr (RELU == 2) return masked<true>(g, fma4(xv, sc, sh));
+  return g;
+}
+
+template <int RELU>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
                 const uint8_t* __restrict__ mask, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-                float* __restrict__ psg, float* __restrict__ psgx) {
+                const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ psg, float* __restrict__ psgx) {
   __shared__ f32x4 sm1[256], sm2[256];
   const int tid = threadIdx.x;
   const int ct = tid % CT, rt = tid / CT;
@@ -189,11 +212,13 @@ bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restri
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
   if (active) {
     const f32x4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+    f32x4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+    if constexpr (RELU == 2) { sc = ld4(scale + 4 * c4); sh = ld4(shift + 4 * c4); }
     auto body = [&](int64_t r) {
       const size_t o = (size_t)r * C + 4 * c4;
-      f32x4 g = ld4(dy + o);
-      if constexpr (RELU) g = relu_grad(g, y, mask, o);
-      const f32x4 xh = (ld4(x + o) - mu) * is;
+      const f32x4 xv = ld4(x + o);
+      const f32x4 g = bwd_gate<RELU>(ld4(dy + o), xv, sc, sh, y, mask, o);
+      const f32x4 xh = (xv - mu) * is;
       s1 += g; s2 += g * xh;
     };
     int64_t r = r0 + rt;
@@ -235,25 +260,27 @@ bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, con
   }
 }
 
-template <bool RELU, bool DRES>
+template <int RELU, bool DRES>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
                const uint8_t* __restrict__ mask, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
-               const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
-               float* __restrict__ dx, float* __restrict__ dres) {
+               const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+               const float* __restrict__ k1, const float* __restrict__ k2, float* __restrict__ dx, float* __restrict__ dres) {
   const int tid = threadIdx.x;
   const int ct = tid % CT, rt = tid / CT;
   const int c4 = blockIdx.y * CT + ct;
   if (rt >= RT || c4 >= C / 4) return;
   const f32x4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
   const f32x4 gi = ld4(gamma + 4 * c4) * is, a1 = ld4(k1 + 4 * c4), a2 = ld4(k2 + 4 * c4);
+  f32x4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+  if constexpr (RELU == 2) { sc = ld4(scale + 4 * c4); sh = ld4(shift + 4 * c4); }
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
   auto body = [&](int64_t r) {
     const size_t o = (size_t)r * C + 4 * c4;
-    f32x4 g = ld4(dy + o);
-    if constexpr (RELU) g = relu_grad(g, y, mask, o);
-    const f32x4 xh = (ld4(x + o) - mu) * is;
+    const f32x4 xv = ld4(x + o);
+    const f32x4 g = bwd_gate<RELU>(ld4(dy + o), xv, sc, sh, y, mask, o);
+    const f32x4 xh = (xv - mu) * is;
     st4(dx + o, gi * (g - a1 - xh * a2));
     if constexpr (DRES) st4(dres + o, g);
   };
@@ -314,36 +341,6 @@ extern "C" size_t ssv_bn_workspace_bytes(int64_t M, int32_t C) {
   return ((size_t)2 * p.nblk * C + 2 * (size_t)C) * sizeof(float);
 }
 
-extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
-                                const float* residual, int relu, float eps, float momentum,
-                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
-  if (int rc = check_mc(M, C, "ssv_bn_train_fwd")) return rc;
-  SSV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "ssv_bn_train_fwd: null pointer");
-  SSV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "ssv_bn_train_fwd: running_mean/var must both be given or both NULL");
-  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_fwd: workspace too small");
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(SSV_PROF_BN_FWD, s);
-  const BnPlan p = bn_plan(M, C);
-  float* pmean = (float*)ws;
-  float* pm2 = pmean + (size_t)p.nblk * C;
-  float* scale = pm2 + (size_t)p.nblk * C;
-  float* shift = scale + C;
-  const dim3 grid(p.nblk, p.GY);
-  hipLaunchKernelGGL(bn_stats_k, grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, pmean, pm2);
-  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
-                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
-  if (relu) {
-    if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-    else          hipLaunchKernelGGL((bn_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-  } else {
-    if (residual) hipLaunchKernelGGL((bn_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-    else          hipLaunchKernelGGL((bn_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-  }
-  SSV_CHECK_LAUNCH("ssv_bn_train_fwd");
-  return SSV_OK;
-}
-
 namespace {
 // Merge `factor` consecutive fine partials (rows-per-block rpb, the last one ragged) into one coarse partial per channel, in double
 // and in fixed order, so that the finalize kernel walks M / (rpb * factor) partials instead of M / rpb.
@@ -366,7 +363,72 @@ bn_partials_coarsen_k(int64_t M, int C, int rpb, int nblk, int factor, const flo
   cmean[(size_t)j * C + c] = (float)mean;
   cm2[(size_t)j * C + c] = (float)m2;
 }
+
+// partial sums of the backward: plain sums, same two-level scheme
+__global__ void __launch_bounds__(256)
+bn_sums_coarsen_k(int C, int nblk, int factor, const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.y;
+  if (c >= C) return;
+  const int b0 = j * factor, b1 = min(b0 + factor, nblk);
+  double a = 0.0, b_ = 0.0;
+  for (int b = b0; b < b1; ++b) { a += (double)p1[(size_t)b * C + c]; b_ += (double)p2[(size_t)b * C + c]; }
+  c1[(size_t)j * C + c] = (float)a;
+  c2[(size_t)j * C + c] = (float)b_;
+}
+
+void launch_apply(const BnPlan& p, int64_t M, int C, const float* x, const float* scale, const float* shift, const float* res,
+                  const float* rscale, const float* rshift, int relu, float* y, uint8_t* mask, hipStream_t s) {
+  const dim3 grid(p.nblk, p.GY);
+  const int mode = res ? (rscale ? 2 : 1) : 0;
+#define APPLY(R_, M_) hipLaunchKernelGGL((bn_apply_k<R_, M_>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, scale, shift, res, rscale, rshift, y, mask)
+  if (relu) { if (mode == 2) APPLY(true, 2); else if (mode == 1) APPLY(true, 1); else APPLY(true, 0); }
+  else      { if (mode == 2) APPLY(false, 2); else if (mode == 1) APPLY(false, 1); else APPLY(false, 0); }
+#undef APPLY
+}
+
+// statistics partials (rows_per_group rows each, the last ragged) -> mean / invstd / scale / shift (+ running statistics)
+int launch_finalize(int64_t M, int C, const float* pmean, const float* pm2, int rpb, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_invstd, float* scale, float* shift,
+                    float* coarse, size_t coarse_floats, hipStream_t s) {
+  int nblk = (int)cdiv64(M, rpb);
+  if (nblk > 2048) {                                          // two-level merge: 32 fine partials -> one coarse one, then the usual finalize
+    const int factor = 32, ncoarse = cdiv(nblk, factor);
+    SSV_REQUIRE((size_t)2 * ncoarse * C <= coarse_floats, "bn finalize: workspace too small for the coarse partials");
+    float* cmean = coarse;
+    float* cm2 = cmean + (size_t)ncoarse * C;
+    hipLaunchKernelGGL(bn_partials_coarsen_k, dim3(cdiv(C, 256), ncoarse), dim3(256), 0, s, M, C, rpb, nblk, factor, pmean, pm2, cmean, cm2);
+    pmean = cmean; pm2 = cm2; rpb *= factor; nblk = ncoarse;
+  }
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, rpb, nblk, pmean, pm2,
+                     gamma, beta, eps, momentum, running_mean, running_var, nbt, save_mean, save_invstd, scale, shift);
+  return SSV_OK;
+}
 }  // namespace
+
+extern "C" int ssv_bn_train_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
+                                const float* residual, int relu, float eps, float momentum,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_train_fwd")) return rc;
+  SSV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "ssv_bn_train_fwd: null pointer");
+  SSV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "ssv_bn_train_fwd: running_mean/var must both be given or both NULL");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_FWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* pmean = (float*)ws;
+  float* pm2 = pmean + (size_t)p.nblk * C;
+  float* scale = pm2 + (size_t)p.nblk * C;
+  float* shift = scale + C;
+  const dim3 grid(p.nblk, p.GY);
+  hipLaunchKernelGGL(bn_stats_k, grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, pmean, pm2);
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.rpb, p.nblk, (const float*)pmean, (const float*)pm2,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
+  launch_apply(p, M, C, x, scale, shift, residual, nullptr, nullptr, relu, y, relu_mask, s);
+  SSV_CHECK_LAUNCH("ssv_bn_train_fwd");
+  return SSV_OK;
+}
 
 // Same as ssv_bn_train_fwd, but the statistics partials come from the producer (ssv_conv2d_fwd_stats): no pass over x for them.
 extern "C" int ssv_bn_train_fwd_partials(int64_t M, int32_t C, const float* x, const float* pmean, const float* pm2, int32_t rows_per_group,
@@ -382,28 +444,68 @@ extern "C" int ssv_bn_train_fwd_partials(int64_t M, int32_t C, const float* x, c
   const BnPlan p = bn_plan(M, C);
   float* scale = (float*)ws;
   float* shift = scale + C;
-  int nblk = (int)cdiv64(M, rows_per_group), rpb = rows_per_group;
-  if (nblk > 2048) {                                          // two-level merge: 32 fine partials -> one coarse one, then the usual finalize
-    const int factor = 32, ncoarse = cdiv(nblk, factor);
-    float* cmean = shift + C;                                 // fits: ssv_bn_workspace_bytes holds 2 * p.nblk * C + 2 * C floats, ncoarse <= p.nblk
-    float* cm2 = cmean + (size_t)ncoarse * C;
-    SSV_REQUIRE(ncoarse <= p.nblk, "ssv_bn_train_fwd_partials: internal: coarse partials do not fit the workspace");
-    hipLaunchKernelGGL(bn_partials_coarsen_k, dim3(cdiv(C, 256), ncoarse), dim3(256), 0, s, M, C, rpb, nblk, factor, pmean, pm2, cmean, cm2);
-    pmean = cmean; pm2 = cm2; rpb *= factor; nblk = ncoarse;
-  }
-  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, rpb, nblk, pmean, pm2,
-                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
-  const dim3 grid(p.nblk, p.GY);
-  if (relu) {
-    if (residual) hipLaunchKernelGGL((bn_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-    else          hipLaunchKernelGGL((bn_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-  } else {
-    if (residual) hipLaunchKernelGGL((bn_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-    else          hipLaunchKernelGGL((bn_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, (const float*)scale, (const float*)shift, residual, y, relu_mask);
-  }
+  if (int rc = launch_finalize(M, C, pmean, pm2, rows_per_group, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                               save_mean, save_invstd, scale, shift, shift + C, (size_t)2 * p.nblk * C, s)) return rc;
+  launch_apply(p, M, C, x, scale, shift, residual, nullptr, nullptr, relu, y, relu_mask, s);
   SSV_CHECK_LAUNCH("ssv_bn_train_fwd_partials");
   return SSV_OK;
 }
+
+// ---- the fused path's pieces: statistics -> affine, and the apply on its own ---------------------------------------------------
+extern "C" int ssv_bn_stats_finalize(int64_t M, int32_t C, const float* pmean, const float* pm2, int32_t rows_per_group,
+                                     const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                     float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_stats_finalize")) return rc;
+  SSV_REQUIRE(pmean && pm2 && rows_per_group > 0 && gamma && beta && save_mean && save_invstd && scale && shift && ws, "ssv_bn_stats_finalize: bad arguments");
+  SSV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "ssv_bn_stats_finalize: running_mean/var must both be given or both NULL");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_stats_finalize: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_FWD, s);
+  const BnPlan p = bn_plan(M, C);
+  if (int rc = launch_finalize(M, C, pmean, pm2, rows_per_group, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                               save_mean, save_invstd, scale, shift, (float*)ws, (size_t)2 * p.nblk * C, s)) return rc;
+  SSV_CHECK_LAUNCH("ssv_bn_stats_finalize");
+  return SSV_OK;
+}
+
+extern "C" int ssv_bn_apply(int64_t M, int32_t C, const float* x, const float* scale, const float* shift,
+                            const float* residual, const float* res_scale, const float* res_shift, int relu,
+                            float* y, uint8_t* relu_mask, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_apply")) return rc;
+  SSV_REQUIRE(x && scale && shift && y, "ssv_bn_apply: null pointer");
+  SSV_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || residual), "ssv_bn_apply: res_scale / res_shift go together and need a residual");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_FWD, s);
+  launch_apply(bn_plan(M, C), M, C, x, scale, shift, residual, res_scale, res_shift, relu, y, relu_mask, s);
+  SSV_CHECK_LAUNCH("ssv_bn_apply");
+  return SSV_OK;
+}
+
+namespace {
+// relu_mode: 0 none, 1 byte mask / sign of y, 2 recomputed from x * scale + shift
+int launch_bwd(int64_t M, int C, const float* dy, const float* y, const uint8_t* relu_mask, const float* x, const float* gamma,
+               const float* save_mean, const float* save_invstd, const float* scale, const float* shift, int relu_mode,
+               float* dx, float* dresidual, float* dgamma, float* dbeta, int accumulate, void* ws, hipStream_t s) {
+  const BnPlan p = bn_plan(M, C);
+  float* psg = (float*)ws;
+  float* psgx = psg + (size_t)p.nblk * C;
+  float* k1 = psgx + (size_t)p.nblk * C;
+  float* k2 = k1 + C;
+  const dim3 grid(p.nblk, p.GY);
+#define REDUCE(R_) hipLaunchKernelGGL((bn_bwd_reduce_k<R_>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, save_mean, save_invstd, scale, shift, psg, psgx)
+  if (relu_mode == 2) REDUCE(2); else if (relu_mode == 1) REDUCE(1); else REDUCE(0);
+#undef REDUCE
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
+                     dgamma, dbeta, accumulate, k1, k2);
+  const float* ck1 = k1; const float* ck2 = k2;
+#define BAPPLY(R_, D_) hipLaunchKernelGGL((bn_bwd_apply_k<R_, D_>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, scale, shift, ck1, ck2, dx, dresidual)
+  if (dresidual) { if (relu_mode == 2) BAPPLY(2, true); else if (relu_mode == 1) BAPPLY(1, true); else BAPPLY(0, true); }
+  else           { if (relu_mode == 2) BAPPLY(2, false); else if (relu_mode == 1) BAPPLY(1, false); else BAPPLY(0, false); }
+#undef BAPPLY
+  return SSV_OK;
+}
+}  // namespace
 
 extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const float* y, const uint8_t* relu_mask, const float* x,
                                 const float* gamma, const float* save_mean, const float* save_invstd, int relu,
@@ -415,25 +517,22 @@ extern "C" int ssv_bn_train_bwd(int64_t M, int32_t C, const float* dy, const flo
   if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_train_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_BN_BWD, s);
-  const BnPlan p = bn_plan(M, C);
-  float* psg = (float*)ws;
-  float* psgx = psg + (size_t)p.nblk * C;
-  float* k1 = psgx + (size_t)p.nblk * C;
-  float* k2 = k1 + C;
-  const dim3 grid(p.nblk, p.GY);
-  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, save_mean, save_invstd, psg, psgx);
-  else      hipLaunchKernelGGL((bn_bwd_reduce_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, save_mean, save_invstd, psg, psgx);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
-                     dgamma, dbeta, accumulate, k1, k2);
-  const float* ck1 = k1; const float* ck2 = k2;
-  if (relu) {
-    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<true, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
-    else           hipLaunchKernelGGL((bn_bwd_apply_k<true, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
-  } else {
-    if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_k<false, true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
-    else           hipLaunchKernelGGL((bn_bwd_apply_k<false, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, ck1, ck2, dx, dresidual);
-  }
+  launch_bwd(M, C, dy, y, relu_mask, x, gamma, save_mean, save_invstd, nullptr, nullptr, relu ? 1 : 0, dx, dresidual, dgamma, dbeta, accumulate, ws, s);
   SSV_CHECK_LAUNCH("ssv_bn_train_bwd");
+  return SSV_OK;
+}
+
+// BatchNorm + ReLU backward of the fused path: neither y nor a mask exists; the ReLU gate is x * scale + shift > 0
+extern "C" int ssv_bn_relu_bwd_affine(int64_t M, int32_t C, const float* dy, const float* x, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
+                                      float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_relu_bwd_affine")) return rc;
+  SSV_REQUIRE(dy && x && gamma && save_mean && save_invstd && scale && shift && dx && ws, "ssv_bn_relu_bwd_affine: null pointer");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_relu_bwd_affine: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_BWD, s);
+  launch_bwd(M, C, dy, nullptr, nullptr, x, gamma, save_mean, save_invstd, scale, shift, 2, dx, nullptr, dgamma, dbeta, accumulate, ws, s);
+  SSV_CHECK_LAUNCH("ssv_bn_relu_bwd_affine");
   return SSV_OK;
 }
 

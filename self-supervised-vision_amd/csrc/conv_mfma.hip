@@ -8,22 +8,24 @@
 //                                                                   that only the taps that hit are walked
 //   wgrad : dW[K][R*S*C]     = dY^T [K][M] . im2col(X) [M][R*S*C]   split over M, fixed-order reduce
 //
-// Block = 256 threads = 4 waves (one per SIMD), 128x128 (or 256x64 / 64x128) output tile, K-step 16,
-// each wave owns a (TM x TN) grid of 32x32 accumulators.  Operands are staged global -> VGPR -> LDS
-// with the next tile's loads issued before the current tile's MFMAs (register prefetch, one LDS
-// buffer, ~20 KB) so that 3-4 blocks are resident per CU and hide each other's barriers.
+// Block = 256 threads = 4 waves (one per SIMD), 128x128 (or 256x64 / 64x128) output tile, K-step 32 (16 when the
+// contraction is not a multiple of 32), each wave owns a (TM x TN) grid of 32x32 accumulators.  Operands are staged
+// global -> VGPR -> LDS with the next tile's loads issued under the current tile's MFMAs (register prefetch, one LDS
+// stage, ~37 KB) so that 3 blocks are resident per CU and hide each other's barriers.
+//
+// BatchNorm fusion (XF variants): the INPUT of a convolution that follows conv -> BN -> ReLU is never materialised;
+// the producer's raw output is staged and relu(x * scale[c] + shift[c]) is applied on the way into LDS (forward A
+// operand, wgrad X operand), with padding taps kept at zero.  The per-channel scale / shift come from ssv_bn_stats_finalize.
 //
 // LDS operand images:
-//   ROWK  [row][16 k + 4 pad]  - row-major, k contiguous (source is k-contiguous: NHWC channels / OHWI);
+//   ROWK  [row][BK k + 4 pad]   - row-major, k contiguous (source is k-contiguous: NHWC channels / OHWI);
 //                                fragments are ds_read_b128: lane l takes row (l&31), k = 4*(l>>5)..+3,
 //                                the 4 values feed 4 consecutive MFMAs.  Row stride 20 floats makes the
 //                                16-lane b128 groups conflict-free.
-//   KROW  [16 k][rows]         - k-major (source is row-contiguous: dY / X rows for wgrad, W rows for dgrad);
+//   KROW  [BK k][rows]         - k-major (source is row-contiguous: dY / X rows for wgrad, W rows for dgrad);
 //                                fragments are ds_read_b32, 32 consecutive banks per half-wave.
 // Both operands of one MFMA always take the same k = 8*ks + 4*(l>>5) + t, so any mix is consistent.
 #include "common.h"
-#include <stdlib.h>
-#include <string.h>
 
 namespace {
 
@@ -47,7 +49,11 @@ struct ConvKP {
   float* aux_out;     // fused-activation variants only: forward also writes gelu(y) here; statistics variant: pmean
   float* aux_out2;    // statistics variant: pm2
   const float* aux_in;  //                                   dgrad multiplies by gelu'(aux_in) before the addend
+  const float* xf_scale;  // XF variants: per-input-channel affine of the fused BatchNorm + ReLU applied to the staged input
+  const float* xf_shift;
 };
+
+constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
 
 // exact (erf) GELU and its derivative, as csrc/vit.hip
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
@@ -160,12 +166,6 @@ __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][t], f.b[tn][t], acc[tm][tn], 0, 0, 0);
 }
 
-// K loop over staged tiles.  load_tile() issues the next tile's global loads into registers, store_tile(buf)
-// writes those registers to LDS stage `buf`.
-//   PIPE = false : one LDS stage, two barriers per tile (small LDS footprint, 3 workgroups per CU).
-//   PIPE = true  : two LDS stages and two fragment register sets, ONE barrier per tile, software pipelined so that a
-//                  wave keeps its SIMD's matrix pipe fed on its own: the fragments of substep s+1 are read while the
-//                  16 MFMAs of substep s run, and the next tile's ds_writes sit in front of the last substep's MFMAs.
 // compile-time interleave of one MFMA group with N memory instructions of kind `mask` (LLVM sched groups:
 // 0x8 MFMA, 0x20 VMEM read, 0x100 DS read, 0x200 DS write): MFMA, mem, MFMA, mem, ... then the remaining MFMAs.
 // A VMEM / DS-write wave-instruction holds the wave's issue port for ~50-70 cycles - about one fp32 MFMA (64 cycles
@@ -179,14 +179,9 @@ __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[
     if ((NMFMA) > (NMEM)) __builtin_amdgcn_sched_group_barrier(0x8, (NMFMA) - (NMEM), 0); \
   } while (0)
 
-// K loop over staged tiles.  load_tile() issues the next tile's global loads into registers, store_tile(buf)
-// writes those registers to LDS stage `buf`.
-//   PIPE = false : one LDS stage, two barriers per tile (small LDS footprint, 3 workgroups per CU).
-//   PIPE = true  : two LDS stages and two fragment register sets, ONE barrier per tile, software pipelined so that a
-//                  wave keeps its SIMD's matrix pipe fed on its own: the fragments of substep s+1 are read while the
-//                  MFMAs of substep s run, the next tile's NLD buffer loads are interleaved one-per-MFMA into the first
-//                  substep and its NLD ds_writes into the last one.
-template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int STAGE, bool PIPE, int NLD, class LoadTile, class StoreTile>
+// K loop over staged tiles: ONE LDS stage, two barriers per tile (small LDS footprint -> 3 workgroups per CU hide each other's
+// barriers).  load_tile() issues the next tile's global loads into registers, store_tile(0) writes those registers to LDS.
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int NLD, class LoadTile, class StoreTile>
 __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs, int wr0, int wc0, int lane,
                                        f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile) {
   if (nkt <= 0) return;
@@ -195,7 +190,7 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
   load_tile();
   store_tile(0);
   __syncthreads();
-  if constexpr (!PIPE) {
+  {
 #ifdef SSV_STAMP   // diagnostic build only (tools/): where does one k-tile spend its cycles?  Never in the shipped library.
     unsigned long long t_ld = 0, t_mma = 0, t_b1 = 0, t_st = 0, t_b2 = 0;
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -247,36 +242,6 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
     }
 #endif
 #undef STAMP
-  } else {
-    static_assert(NS % 2 == 0, "pipelined loop alternates two fragment sets");
-    Frags<TM, TN> fr[2];
-    load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As, Bs, wr0, wc0, lane, 0);
-    int cur = 0;
-    // The body is branch-free so that the whole substep is one scheduling region: after the LAST tile it still issues
-    // a tile's worth of loads and stores them to the idle stage - buffer loads cannot fault (out of range reads 0) and
-    // nobody reads that stage.
-    for (int kt = 0; kt < nkt; ++kt) {
-      const float* a = As + cur * STAGE;
-      const float* b = Bs + cur * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < NS; ++ks) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < NS) load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[(ks + 1) & 1], a, b, wr0, wc0, lane, ks + 1);
-        if (ks == 0) load_tile();                       // NLD buffer loads, one per MFMA of this substep
-        else if (ks == NS - 1) store_tile(cur ^ 1);     // other stage: last read before the previous barrier
-        mma_frags<TM, TN>(fr[ks & 1], acc);
-        if (NLD > 0 && ks == 0) {
-          if (A_ROWK && B_ROWK) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // next substep's fragment reads first
-          SSV_INTERLEAVE(NM, NLD, 0x20);
-        } else if (NLD > 0 && ks == NS - 1) {
-          SSV_INTERLEAVE(NM, NLD, 0x200);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-      cur ^= 1;
-      load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr[0], As + cur * STAGE, Bs + cur * STAGE, wr0, wc0, lane, 0);
-    }
   }
 }
 
@@ -354,14 +319,16 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false>
 __global__ void __launch_bounds__(256)
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;                   // ROWK row stride: 16-lane b128 read groups hit 16 distinct 16-B slots
   constexpr int STAGE = (BM + BN) * LDT;
-  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
+  static_assert(!XF || (VEC && !C4), "the fused-input variant is the float4 path");
+  __shared__ __attribute__((aligned(16))) float smem[STAGE];
+  __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
   float* As = smem;
   float* Bs = smem + BM * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -421,11 +388,11 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + tl * 4]) = ra[i];
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + tl * 4]) = ra[i];
 #pragma unroll
-      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (rsub + RPP * i) * LDT + tl * 4]) = rb[i];
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + tl * 4]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, STAGE, DB, AP + BP>((ntap + CH - 1) / CH, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP>((ntap + CH - 1) / CH, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
   } else if constexpr (VEC) {
     // ---- C % BK == 0: every k-tile lies inside one filter tap; float4 staging, BK/4 lanes per row ----
     constexpr int CH = BK / 4, RPP = 256 / CH;
@@ -459,13 +426,20 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;     // 1x1 / no padding: every tap of a valid row is in bounds
     int lr = 0, ls = 0, lc0 = 0;   // loader position (tap r, s, first channel)
     f32x4 ra[AP], rb[BP];
+    int xf_ok = 0, xf_c = 0;       // XF: which of the staged rows hold real pixels (bit i), first channel of this thread's float4
+    if constexpr (XF) {
+      for (int c = tid; c < p.C; c += 256) { xfs[c] = p.xf_scale[c]; xfs[XF_MAXC + c] = p.xf_shift[c]; }
+      __syncthreads();
+    }
     auto load_tile = [&]() {
       const int toff_x = ((lr * p.W + ls) * p.C + lc0) * 4;    // uniform
       const int toff_w = ((lr * p.S + ls) * p.C + lc0) * 4;
+      if constexpr (XF) { xf_ok = 0; xf_c = lc0 + chunk; }
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const bool ok = inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W));
         ra[i] = bload4(rx, ok ? aoff[i] + toff_x : OOB_OFF, 0);
+        if constexpr (XF) xf_ok |= (int)ok << i;
       }
 #pragma unroll
       for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
@@ -482,15 +456,30 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       lc0 += w2 ? BK : 0;
     };
     auto store_tile = [&](int buf) {
+      if constexpr (XF) {
+        // the staged values are the producer's raw conv output: apply its BatchNorm + ReLU here (same fmaf / fmaxf as bn_apply_k,
+        // so the operand is bit-identical to the materialised activation); padding taps stay exactly zero.  A row past M keeps
+        // relu(shift) - harmless, its output row is never stored nor counted.
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&xfs[xf_c]), sh = *reinterpret_cast<const f32x4*>(&xfs[XF_MAXC + xf_c]);
 #pragma unroll
-      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ra[i];
+        for (int i = 0; i < AP; ++i) {
+          f32x4 v = ra[i];
 #pragma unroll
-      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = rb[i];
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f);
+          if (!inb) { const bool ok = (xf_ok >> i) & 1; v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f; }
+          *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, STAGE, DB, AP + BP>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
-    static_assert(BK == GBK && !DB, "generic path is BK=16, single buffer");
+    static_assert(BK == GBK, "generic path is BK=16");
     constexpr int AE = BM / 16, BE = BN / 16;
     const int kk = tid & 15, rsub = tid >> 4;
     int hw0[AE];        // packed (hi0 & 0xffff) | (wi0 << 16)
@@ -552,8 +541,8 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 
   // ---- epilogue: acc reg j of lane l is (row (j&3)+8*(j>>2)+4*(l>>5), col l&31) of its 32x32 tile ----
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
-  static_assert(!(EPI || STATS) || (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE), "the fused-activation / statistics forward needs the vectorised epilogue");
-  if constexpr (VEC && EP_FLOATS <= (DB ? 2 : 1) * STAGE) {
+  static_assert(!(EPI || STATS) || (VEC && EP_FLOATS <= STAGE), "the fused-activation / statistics forward needs the vectorised epilogue");
+  if constexpr (VEC && EP_FLOATS <= STAGE) {
     if ((p.K & 3) == 0) {             // 16-byte stores need K % 4 == 0 (uniform): whole rows segments through LDS
       const int rbase = m0 + wr0;
       if constexpr (STATS) {
@@ -598,13 +587,13 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // dgrad: rows are the input pixels of ONE stride-parity class (blockIdx.y); only taps with
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool EPI = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false>
 __global__ void __launch_bounds__(256)
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;
   constexpr int A_FLOATS = BM * LDT, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
-  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[STAGE];
   __shared__ unsigned rowpix[BM];
   __shared__ int taps[64 * 3];      // (dho, dwo, tapoff) per valid tap
   __shared__ int ntaps_s;
@@ -707,15 +696,15 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (rsub + RPP * i) * LDT + chunk]) = ra[i];
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = rb[i];
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rb[i];
   };
-  k_loop<TM, TN, true, false, LDT, BN, BK, STAGE, DB, AP + BP>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  k_loop<TM, TN, true, false, LDT, BN, BK, AP + BP>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
-  static_assert(!EPI || EP_FLOATS <= (DB ? 2 : 1) * STAGE, "the fused-activation dgrad needs the vectorised epilogue");
-  if constexpr (EP_FLOATS <= (DB ? 2 : 1) * STAGE) {       // C % 4 == 0 is a precondition of this kernel
+  static_assert(!EPI || EP_FLOATS <= STAGE, "the fused-activation dgrad needs the vectorised epilogue");
+  if constexpr (EP_FLOATS <= STAGE) {       // C % 4 == 0 is a precondition of this kernel
     epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
                               [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
                               nullptr, EPI ? p.aux_in : nullptr);
@@ -748,12 +737,16 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // GATHER: 0 generic (fastdiv per staged row and tile), 1 LIN (1x1 / stride 1 / no padding: X row m is x + m*C),
 //         2 S1 (stride 1, any filter/padding: X row of tap (r,s) is x + (m + (r-pad)*W + (s-pad))*C, validity from
 //           (ho, wo) kept incrementally per staged row - no division in the loop)
-template <int BM, int BN, int WGM, int WGN, int BK, bool DB, bool VECB, int GATHER>
+// XF: x is the producer's RAW conv output; the X operand is relu(x * xf_scale[c] + xf_shift[c]) (the activation the forward never
+//     materialised), formed on the way into LDS.  A thread's four channels are loop constants, so are its scale / shift registers.
+template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false>
 __global__ void __launch_bounds__(256)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int STAGE = BK * (BM + BN);
-  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
+  constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);            // the vectorised epilogue's staging area (one 32-row slab per wave)
+  static_assert(!XF || VECB, "the fused-input variant is the float4 path");
+  __shared__ __attribute__((aligned(16))) float smem[STAGE > EP_FLOATS ? STAGE : EP_FLOATS];
   float* As = smem;               // [BK][BM]
   float* Bs = smem + BK * BM;     // [BK][BN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -793,6 +786,9 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   f32x4 rbv[VECB ? BP : 1];
   float rbs[VECB ? 1 : BP];
   int avoff[AP], bvoff[BP];
+  int xf_ok = 0;
+  f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (XF) { if (jok) { xsc = *reinterpret_cast<const f32x4*>(p.xf_scale + cj); xsh = *reinterpret_cast<const f32x4*>(p.xf_shift + cj); } }
 #pragma unroll
   for (int i = 0; i < AP; ++i) avoff[i] = acok ? ((arow + ARP * i) * p.K + i0 + acol) * 4 : OOB_OFF;
 #pragma unroll
@@ -824,10 +820,12 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
       }
     } else if constexpr (GATHER == 2) {
       const int moff = mcur * p.C * 4;
+      if constexpr (XF) xf_ok = 0;
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         const int m = mcur + brow + BRP * i;
         const bool ok = jok & (m < p.M) & ((unsigned)(s1_ho[i] + rj - p.pad) < (unsigned)p.H) & ((unsigned)(s1_wo[i] + sj - p.pad) < (unsigned)p.W);
+        if constexpr (XF) xf_ok |= (int)ok << i;
         const int off = ok ? s1_base[i] + moff : OOB_OFF;
         if constexpr (VECB) rbv[i] = bload4(rx, off, 0);
         else rbs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
@@ -840,6 +838,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
         s1_wo[i] = wo; s1_ho[i] = ho;
       }
     } else {
+      if constexpr (XF) xf_ok = 0;
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         const int m = mcur + brow + BRP * i;
@@ -851,6 +850,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
         const uint32_t wo = rem - ho * (uint32_t)p.Wo;
         const int hi = (int)ho * p.stride - p.pad + rj, wi = (int)wo * p.stride - p.pad + sj;
         ok = ok & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+        if constexpr (XF) xf_ok |= (int)ok << i;
         const int off = ok ? ((((int)n * p.H + hi) * p.W + wi) * p.C + cj) * 4 : OOB_OFF;
         if constexpr (VECB) rbv[i] = bload4(rx, off, 0);
         else rbs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
@@ -860,16 +860,30 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * STAGE + (arow + ARP * i) * BM + acol]) = ra[i];
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[buf * STAGE + (brow + BRP * i) * BN + bcol]) = rbv[i];
-      else Bs[buf * STAGE + (brow + BRP * i) * BN + bcol] = rbs[i];
+      if constexpr (XF) {
+        // same fmaf / fmaxf as bn_apply_k: bit-identical to the materialised activation; padding taps (and, in the LIN mode, rows
+        // past M, whose dY rows are zero anyway) must not pick up relu(shift)
+        f32x4 v = rbv[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], xsc[e], xsh[e]), 0.f);
+        if constexpr (GATHER != 1) { const bool ok = (xf_ok >> i) & 1; v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f; }
+        *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = v;
+      } else if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
+      else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
-  k_loop<TM, TN, false, false, BM, BN, BK, STAGE, DB, (VECB ? AP + BP : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   float* out = partial + (size_t)split * p.K * p.RSC;
+  if ((p.RSC & 3) == 0) {      // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
+    const int rbase = i0 + wr0;
+    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, p.RSC, nullptr, nullptr, out,
+                         [&](int r) -> long long { const int row = rbase + r; return row < p.K ? (long long)row * p.RSC : -1; });
+    return;
+  }
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -934,7 +948,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dWo = make_fastdiv((uint32_t)d->Wo);
   p.dC = make_fastdiv((uint32_t)d->C);
   p.dS = make_fastdiv((uint32_t)d->S);
-  p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr;
+  p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr; p.xf_scale = nullptr; p.xf_shift = nullptr;
   return p;
 }
 
@@ -963,28 +977,41 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
 
 }  // namespace
 
-// ---- variant selection -------------------------------------------------------------------------------------
-// SSV_CONV_CFG (comma list, read once): bk16 | bk32 (K-step), db | sb (double / single LDS buffer).  Default = tuned.
-struct ConvCfg { int bk; bool db; };
-static ConvCfg conv_cfg() {
-  static ConvCfg c = [] {
-    ConvCfg v{32, false};
-    if (const char* e = getenv("SSV_CONV_CFG")) {
-      if (strstr(e, "bk16")) v.bk = 16;
-      if (strstr(e, "bk32")) v.bk = 32;
-      if (strstr(e, "db")) v.db = true;
-      if (strstr(e, "sb")) v.db = false;
-    }
-    return v;
-  }();
-  return c;
+// ---- launch selection (compile-time variants only: no environment, no global state) ---------------------------
+// K-step 32 when the contraction's channel count allows it, else 16; tile by output width.
+namespace {
+
+// forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
+int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
+               float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s) {
+  ConvKP p = make_kp(d);
+  p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
+  const bool stats = pmean != nullptr, xf = in_scale != nullptr;
+  const bool wide = d->K >= 128;
+  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+#define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
+  if (stats || xf) {                                           // C % 32 == 0 checked by the callers
+    if (stats && xf) FWD_TILE(32, true, false, true);
+    else if (stats)  FWD_TILE(32, true, false, false);
+    else             FWD_TILE(32, false, false, true);
+  } else if (d->C == 4) {                                      // image stems (3 channels padded to 4): tap-vector gather
+    FWD_TILE(32, false, true, false);
+  } else if (d->C % 32 == 0) {
+    FWD_TILE(32, false, false, false);
+  } else if (d->C % 16 == 0) {
+    FWD_TILE(16, false, false, false);
+  } else {
+    const unsigned g2 = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 64));
+    hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, GBK, false>), dim3(g2), dim3(256), 0, s, p, x, w, bias, addend, y);
+  }
+#undef FWD_TILE
+#undef FWD
+  return SSV_OK;
 }
 
-#define SSV_DISPATCH_BK_DB(BKV, DBV, CALL)                        \
-  do {                                                            \
-    if ((BKV) == 32) { if (DBV) { CALL(32, true); } else { CALL(32, false); } } \
-    else             { if (DBV) { CALL(16, true); } else { CALL(16, false); } } \
-  } while (0)
+}  // namespace
 
 extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* addend, float* y, void* stream) {
@@ -993,33 +1020,7 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "ssv_conv2d_fwd: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_FWD, s);
-  const ConvKP p = make_kp(d);
-  const ConvCfg cfg = conv_cfg();
-  const int bk = d->C % 32 == 0 ? cfg.bk : 16;
-  if (d->C == 4) {                                             // image stems (3 channels padded to 4): tap-vector gather
-    if (d->K >= 128) {
-      const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-      hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, false, true, false, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
-    } else {
-      const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, false, true, false, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
-    }
-  } else if (d->C % 16 == 0) {
-    if (d->K >= 128) {
-      const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-#define CALL(B_, D_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, B_, D_, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-      SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
-#undef CALL
-    } else {
-      const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-#define CALL(B_, D_) hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, B_, D_, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-      SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
-#undef CALL
-    }
-  } else {
-    const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 64));
-    hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, GBK, false, false>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
-  }
+  launch_fwd(d, x, w, bias, addend, y, nullptr, nullptr, nullptr, nullptr, s);
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd");
   return SSV_OK;
 }
@@ -1030,22 +1031,24 @@ extern "C" int64_t ssv_conv2d_fwd_stats_groups(const ssv_conv_desc* d) {
 }
 
 extern "C" int ssv_conv2d_fwd_stats(const ssv_conv_desc* d, const float* x, const float* w, float* y, float* pmean, float* pm2, void* stream) {
-  if (int rc = check_desc(d, "ssv_conv2d_fwd_stats")) return rc;
-  SSV_REQUIRE(x && w && y && pmean && pm2, "ssv_conv2d_fwd_stats: null pointer");
-  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)pmean | (uintptr_t)pm2) & 15) == 0, "ssv_conv2d_fwd_stats: pointers must be 16-byte aligned");
-  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0, "ssv_conv2d_fwd_stats: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  return ssv_conv2d_fwd_bnrelu_in_stats(d, x, nullptr, nullptr, w, y, pmean, pm2, stream);
+}
+
+extern "C" int ssv_conv2d_fwd_bnrelu_in_stats(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift,
+                                              const float* w, float* y, float* pmean, float* pm2, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_bnrelu_in_stats")) return rc;
+  SSV_REQUIRE(x && w && y, "ssv_conv2d_fwd_bnrelu_in_stats: null pointer");
+  SSV_REQUIRE((pmean == nullptr) == (pm2 == nullptr), "ssv_conv2d_fwd_bnrelu_in_stats: pmean / pm2 must both be given or both NULL");
+  SSV_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "ssv_conv2d_fwd_bnrelu_in_stats: in_scale / in_shift must both be given or both NULL");
+  SSV_REQUIRE(pmean || in_scale, "ssv_conv2d_fwd_bnrelu_in_stats: neither statistics nor a fused input requested - call ssv_conv2d_fwd");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)pmean | (uintptr_t)pm2 | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0,
+              "ssv_conv2d_fwd_bnrelu_in_stats: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0, "ssv_conv2d_fwd_bnrelu_in_stats: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  SSV_REQUIRE(!in_scale || d->C <= XF_MAXC, "ssv_conv2d_fwd_bnrelu_in_stats: a fused input supports at most %d channels (got %d)", XF_MAXC, d->C);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_FWD, s);
-  ConvKP p = make_kp(d);
-  p.aux_out = pmean; p.aux_out2 = pm2;
-  if (d->K >= 128) {
-    const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-    hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
-  } else {
-    const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-    hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
-  }
-  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_stats");
+  launch_fwd(d, x, w, nullptr, nullptr, y, pmean, pm2, in_scale, in_shift, s);
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_bnrelu_in_stats");
   return SSV_OK;
 }
 
@@ -1062,7 +1065,7 @@ extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const
   p.aux_out = act;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
   // K-step 32 only: its LDS stage is what the vectorised epilogue (the one that writes the second tensor) needs
-  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, false, true, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
+  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
   return SSV_OK;
 }
@@ -1080,7 +1083,7 @@ extern "C" int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, co
   p.aux_in = h;
   const int64_t Mc = (int64_t)d->N * d->H * d->W;
   const unsigned gx = (unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128));
-  hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32, false, true>), dim3(gx, 1), dim3(256), 0, s, p, dy, w, addend, dx);
+  hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32, true>), dim3(gx, 1), dim3(256), 0, s, p, dy, w, addend, dx);
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad_gelu");
   return SSV_OK;
 }
@@ -1095,21 +1098,18 @@ extern "C" int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const f
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_DGRAD, s);
   const ConvKP p = make_kp(d);
-  const ConvCfg cfg = conv_cfg();
-  const int bk = d->K % 32 == 0 ? cfg.bk : 16;
+  const bool bk32 = d->K % 32 == 0;
   const int st = d->stride;
   const int Hq = cdiv(d->H, st), Wq = cdiv(d->W, st);            // class (0,0) is the largest
   const int64_t Mc = (int64_t)d->N * Hq * Wq;
   if (d->C >= 128) {
-    const unsigned gx = (unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128));
-#define CALL(B_, D_) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, B_, D_>), dim3(gx, st * st), dim3(256), 0, s, p, dy, w, addend, dx)
-    SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
-#undef CALL
+    const dim3 g((unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128)), st * st);
+    if (bk32) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32>), g, dim3(256), 0, s, p, dy, w, addend, dx);
+    else      hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 16>), g, dim3(256), 0, s, p, dy, w, addend, dx);
   } else {
-    const unsigned gx = (unsigned)(cdiv64(Mc, 256) * cdiv(d->C, 64));
-#define CALL(B_, D_) hipLaunchKernelGGL((conv_dgrad_k<256, 64, 4, 1, B_, D_>), dim3(gx, st * st), dim3(256), 0, s, p, dy, w, addend, dx)
-    SSV_DISPATCH_BK_DB(bk, cfg.db, CALL);
-#undef CALL
+    const dim3 g((unsigned)(cdiv64(Mc, 256) * cdiv(d->C, 64)), st * st);
+    if (bk32) hipLaunchKernelGGL((conv_dgrad_k<256, 64, 4, 1, 32>), g, dim3(256), 0, s, p, dy, w, addend, dx);
+    else      hipLaunchKernelGGL((conv_dgrad_k<256, 64, 4, 1, 16>), g, dim3(256), 0, s, p, dy, w, addend, dx);
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad");
   return SSV_OK;
@@ -1123,43 +1123,47 @@ extern "C" size_t ssv_conv2d_wgrad_workspace_bytes(const ssv_conv_desc* d) {
 
 extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dw,
                                 int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return ssv_conv2d_wgrad_bnrelu_in(d, x, nullptr, nullptr, dy, dw, accumulate, ws, ws_bytes, stream);
+}
+
+extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy,
+                                          float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_desc(d, "ssv_conv2d_wgrad")) return rc;
   SSV_REQUIRE(x && dy && dw && ws, "ssv_conv2d_wgrad: null pointer");
-  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws) & 15) == 0, "ssv_conv2d_wgrad: pointers must be 16-byte aligned");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0, "ssv_conv2d_wgrad: pointers must be 16-byte aligned");
   SSV_REQUIRE(d->K % 4 == 0, "ssv_conv2d_wgrad: needs K %% 4 == 0 (got %d)", d->K);
+  SSV_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "ssv_conv2d_wgrad: in_scale / in_shift must both be given or both NULL");
+  const bool xf = in_scale != nullptr;
+  SSV_REQUIRE(!xf || d->C % 4 == 0, "ssv_conv2d_wgrad: a fused input needs C %% 4 == 0 (got C=%d)", d->C);
   const WgradPlan wp = plan_wgrad(d);
   const size_t need = (size_t)wp.nsplit * d->K * d->R * d->S * d->C * sizeof(float);
   if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_WGRAD, s);
-  const ConvKP p = make_kp(d);
-  const ConvCfg cfg = conv_cfg();
+  ConvKP p = make_kp(d);
+  p.xf_scale = in_scale; p.xf_shift = in_shift;
   const bool vecb = d->C % 4 == 0;
   const int tiles = wp.it * wp.jt;
   const dim3 grid((unsigned)(tiles * wp.nsplit));
   float* part = (float*)ws;
   // gather mode of the X operand (see conv_wgrad_k): LIN, S1 (needs one carry per K-step: BK/Wo + 1 <= Ho, Ho == H, Wo == W) or generic
-  const bool s1ok = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && cfg.bk / d->Wo + 1 <= d->Ho;
+  const bool s1ok = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && 32 / d->Wo + 1 <= d->Ho;
   const int gather = (d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1) ? 1 : (s1ok ? 2 : 0);
-#define WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, V_, G_) \
-  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, B_, D_, V_, G_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
-#define WG_GATHER(BM_, BN_, WM_, WN_, B_, D_) \
-  do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, true, 1); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, true, 2); \
-       else WG_LAUNCH(BM_, BN_, WM_, WN_, B_, D_, true, 0); } while (0)
+#define WG_LAUNCH(BM_, BN_, WM_, WN_, B_, V_, G_, X_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, B_, V_, G_, X_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define WG_GATHER(BM_, BN_, WM_, WN_, X_) \
+  do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 1, X_); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 2, X_); \
+       else WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 0, X_); } while (0)
   if (!vecb) {
-    if (wp.bm == 128) WG_LAUNCH(128, 128, 2, 2, GBK, false, false, 0);
-    else              WG_LAUNCH(64, 128, 1, 4, GBK, false, false, 0);
+    if (wp.bm == 128) WG_LAUNCH(128, 128, 2, 2, GBK, false, 0, false);
+    else              WG_LAUNCH(64, 128, 1, 4, GBK, false, 0, false);
   } else if (wp.bn == 64) {                       // RSC <= 64 (and C % 4 == 0): 64-wide column tile
-    if (wp.bm == 128) { if (cfg.bk == 32) WG_GATHER(128, 64, 2, 2, 32, false); else WG_GATHER(128, 64, 2, 2, 16, false); }
-    else              { if (cfg.bk == 32) WG_GATHER(64, 64, 2, 2, 32, false); else WG_GATHER(64, 64, 2, 2, 16, false); }
+    if (wp.bm == 128) { if (xf) WG_GATHER(128, 64, 2, 2, true); else WG_GATHER(128, 64, 2, 2, false); }
+    else              { if (xf) WG_GATHER(64, 64, 2, 2, true); else WG_GATHER(64, 64, 2, 2, false); }
   } else if (wp.bm == 128) {
-#define CALL(B_, D_) WG_GATHER(128, 128, 2, 2, B_, D_)
-    SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
-#undef CALL
+    if (xf) WG_GATHER(128, 128, 2, 2, true); else WG_GATHER(128, 128, 2, 2, false);
   } else {
-#define CALL(B_, D_) WG_GATHER(64, 128, 1, 4, B_, D_)
-    SSV_DISPATCH_BK_DB(cfg.bk, cfg.db, CALL);
-#undef CALL
+    if (xf) WG_GATHER(64, 128, 1, 4, true); else WG_GATHER(64, 128, 1, 4, false);
   }
 #undef WG_GATHER
 #undef WG_LAUNCH

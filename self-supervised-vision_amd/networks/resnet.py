@@ -52,12 +52,20 @@ class _ResidualUnit(hnn.HipModule):
         return getattr(self, f"bn{self.depth}")
 
     def _run(self, tape, x):
-        shortcut = x if self.downsample is None else hnn.batchnorm(tape, self.downsample[0]._run(tape, x, bn_stats=True), self.downsample[1])
+        """conv -> BN -> ReLU -> conv chains never write the activation between the convolutions: the BatchNorm in the middle only
+        finalises its statistics (hnn.batchnorm(lazy=True)) and the next convolution applies scale / shift / ReLU while it stages its
+        input.  The projection shortcut's BatchNorm is folded into the unit's closing kernel the same way."""
+        shortcut = x
+        if self.downsample is not None:                      # conv1x1 -> BN: no ReLU, its only consumer is the closing BatchNorm below
+            fold = getattr(self, f"conv{self.depth}").has_stats_epilogue()
+            shortcut = hnn.batchnorm(tape, self.downsample[0]._run(tape, x, bn_stats=True), self.downsample[1], lazy=fold)
         h = x
         for i in range(1, self.depth + 1):
             h = getattr(self, f"conv{i}")._run(tape, h, bn_stats=True)      # every conv here is followed by its BatchNorm
             closing = i == self.depth
-            h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None)
+            nxt = None if closing else getattr(self, f"conv{i + 1}")
+            fuse = nxt is not None and nxt.can_fuse_input()
+            h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None, lazy=fuse)
         return h
 
 

@@ -165,28 +165,61 @@ _FUSE_BN_STATS = os.environ.get("SSV_NO_BN_STATS_FUSION", "0") != "1"
 _PAD_STEM = os.environ.get("SSV_NO_STEM_PADDING", "0") != "1"
 
 
+_FUSE_BN_APPLY = os.environ.get("SSV_NO_BN_APPLY_FUSION", "0") != "1"      # diagnostic switch: materialise every activation
+
+
+class LazyAct:
+    """relu?(raw * scale[c] + shift[c]): the output of conv -> BatchNorm(-> ReLU) that is NOT written to HBM.  Its consumers form it
+    on the fly: a convolution while it stages its input (forward and weight gradient), the closing BatchNorm of a residual unit when it
+    adds the projection shortcut.  ``raw`` is the producer's conv output (kept for the backward anyway); scale / shift / mean / invstd
+    come from ssv_bn_stats_finalize.  On the tape it stands where the activation tensor would: gradients are keyed by this object."""
+    __slots__ = ("raw", "scale", "shift", "mean", "invstd", "relu")
+
+    def __init__(self, raw, scale, shift, mean, invstd, relu):
+        self.raw, self.scale, self.shift, self.mean, self.invstd, self.relu = raw, scale, shift, mean, invstd, relu
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def materialize(self):
+        return ops.bn_apply(self.raw, self.scale, self.shift, relu=self.relu)[0]
+
+
 def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
     """``bn_stats``: the caller normalises the output next - let the conv epilogue produce the statistics partials (kept on the
-    output tensor as ``_bn_partials`` for `batchnorm`), which saves BatchNorm's own pass over the conv output."""
-    fused = ops.conv2d_fwd_stats(x, weight, stride, pad) if (bn_stats and bias is None and _FUSE_BN_STATS) else None
-    if fused is not None:
-        y = fused[0]
-        y._bn_partials = (fused[1], fused[2])
+    output tensor as ``_bn_partials`` for `batchnorm`), which saves BatchNorm's own pass over the conv output.
+    ``x`` may be a LazyAct (conv -> BN -> ReLU output that was never written): the kernels then apply it while staging."""
+    lazy = x if isinstance(x, LazyAct) else None
+    want = bn_stats and bias is None and _FUSE_BN_STATS
+    if lazy is not None and not (lazy.relu and bias is None and ops.can_fuse_conv_input(weight.shape[1], weight.shape[0])):
+        raise SsvError("a lazy activation reached a convolution that cannot fuse it (the producer must check ops.can_fuse_conv_input)")
+    affine = None if lazy is None else (lazy.scale, lazy.shift)
+    src = x if lazy is None else lazy.raw
+    if lazy is not None:
+        y, part = ops.conv2d_fwd_fused(src, weight, stride, pad, in_affine=affine, want_stats=want)
+        if part is not None:
+            y._bn_partials = part
     else:
-        y = ops.conv2d_fwd(x, weight, stride, pad, bias=bias)
+        fused = ops.conv2d_fwd_stats(x, weight, stride, pad) if want else None
+        if fused is not None:
+            y = fused[0]
+            y._bn_partials = (fused[1], fused[2])
+        else:
+            y = ops.conv2d_fwd(x, weight, stride, pad, bias=bias)
     if tape is not None:
-        need_dx = tape.needs_grad(x)
+        need_dx = lazy is not None or tape.needs_grad(x)
 
         slot = tape.slot
 
         def bwd(dy, existing):
-            ops.conv2d_wgrad(x, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True)
+            ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine)
             if bias is not None:
                 ops.colsum(dy, grad_of(bias, slot), accumulate=True)
             if not need_dx:
                 return (None,)
             ex = existing[0]
-            dx = ops.conv2d_dgrad(dy, weight, x.shape, stride, pad, addend=ex, out=ex)
+            dx = ops.conv2d_dgrad(dy, weight, src.shape, stride, pad, addend=ex, out=ex)
             return (dx,)
         tape.record((x,), y, bwd)
     return y
@@ -233,19 +266,57 @@ def grouped_conv(tape, x, weight, groups, stride, pad):
     return y
 
 
-def batchnorm(tape, x, bn, relu=False, residual=None):
+def _bn_order_wait(bn, x):
     if _STREAMS:                               # running-stat update order across the two view streams: slot 0 first
         st = torch.cuda.current_stream(x.device)
         if _SLOT == 1 and bn._order_event is not None:
             st.wait_event(bn._order_event)
-    y, mean, invstd, mask = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                             relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
-                                             want_mask=True, skip_mask=tape is None,   # 1 byte per 4 elements for the backward
-                                             partials=x.__dict__.pop("_bn_partials", None))
+
+
+def _bn_order_record(bn, x):
     if _STREAMS and _SLOT == 0 and torch.cuda.current_stream(x.device) != torch.cuda.default_stream(x.device):
         if bn._order_event is None:
             object.__setattr__(bn, "_order_event", torch.cuda.Event())
         bn._order_event.record(torch.cuda.current_stream(x.device))
+
+
+def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
+    """BatchNorm (batch statistics) [+ residual] [+ ReLU] of a conv output.
+
+    ``lazy=True`` (the caller guarantees that the only consumer is a convolution that can fuse its input, or - without ReLU - the
+    closing BatchNorm of a residual unit): nothing but the statistics is computed; the result is a LazyAct.  ``residual`` may be such a
+    LazyAct (the projection shortcut's BatchNorm folded into this kernel)."""
+    partials = x.__dict__.pop("_bn_partials", None)
+    lazy = lazy and partials is not None and residual is None and _FUSE_BN_APPLY
+    res_lazy = residual if isinstance(residual, LazyAct) else None
+    if res_lazy is not None and (partials is None or res_lazy.relu):
+        raise SsvError("a lazy residual needs the statistics partials of this BatchNorm's input and must not carry a ReLU")
+    _bn_order_wait(bn, x)
+    if lazy or res_lazy is not None:
+        m, c = ops._rows(x)
+        mean, invstd, scale, shift = ops.bn_stats_finalize(m, c, partials, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                           eps=bn.eps, momentum=bn.momentum)
+        _bn_order_record(bn, x)
+        if lazy:
+            out = LazyAct(x, scale, shift, mean, invstd, relu)
+            if tape is not None:
+                slot = tape.slot
+
+                def bwd_lazy(dact, existing):
+                    if relu:
+                        dx = ops.bn_relu_bwd_affine(dact, x, bn.weight, mean, invstd, scale, shift, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
+                    else:
+                        dx, _ = ops.bn_train_bwd(dact, None, x, bn.weight, mean, invstd, False, grad_of(bn.weight, slot), grad_of(bn.bias, slot), accumulate=True)
+                    return (_accum(existing[0], dx),)
+                tape.record((x,), out, bwd_lazy)
+            return out
+        y, mask = ops.bn_apply(x, scale, shift, relu=relu, residual=res_lazy.raw, res_affine=(res_lazy.scale, res_lazy.shift), want_mask=tape is not None)
+    else:
+        y, mean, invstd, mask = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                 relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
+                                                 want_mask=True, skip_mask=tape is None,   # 1 byte per 4 elements for the backward
+                                                 partials=partials)
+        _bn_order_record(bn, x)
     if tape is not None:
         slot = tape.slot
 
@@ -540,6 +611,14 @@ class HipConv2d(HipModule):
         w = torch.empty(cout, cin // groups, k, k) if weight is None else weight
         self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
         self.stride, self.pad, self.groups = stride, pad, groups
+
+    def has_stats_epilogue(self):
+        """True when this convolution's forward leaves the BatchNorm statistics partials of its output (ssv_conv2d_fwd_stats)."""
+        return _FUSE_BN_STATS and self.groups == 1 and self.weight.shape[1] % 32 == 0 and self.weight.shape[0] % 4 == 0
+
+    def can_fuse_input(self):
+        """True when this convolution can take a LazyAct (a never-written conv -> BN -> ReLU output) as its input."""
+        return _FUSE_BN_APPLY and _FUSE_BN_STATS and ops.can_fuse_conv_input(self.weight.shape[1] * self.groups, self.weight.shape[0], self.groups)
 
     def _run(self, tape, x, bn_stats=False):
         if self.groups > 1:

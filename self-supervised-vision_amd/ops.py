@@ -60,6 +60,29 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
     return y, part[0], part[1]
 
 
+def conv2d_fwd_fused(x, w, stride=1, pad=0, in_affine=None, want_stats=True):
+    """y = conv(act(x), w) where act is the identity or, with ``in_affine = (scale, shift)``, relu(x * scale[c] + shift[c]) applied while
+    the operand is staged (x is then the producer's RAW conv output: the activation itself is never written).  With ``want_stats``
+    the epilogue also leaves the BatchNorm statistics partials of y: returns (y, (pmean, pm2) | None)."""
+    _lib._dev(x, w)
+    w, wshape = _ohwi(w)
+    d = conv_desc(x.shape, wshape, stride, pad)
+    y = _empty((d.N, d.Ho, d.Wo, d.K), x)
+    part = None
+    if want_stats:
+        groups = int(_lib.load().ssv_conv2d_fwd_stats_groups(C.byref(d)))
+        part = _empty((2, groups, d.K), x)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    call("ssv_conv2d_fwd_bnrelu_in_stats", C.byref(d), ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(y),
+         ptr(part[0]) if want_stats else None, ptr(part[1]) if want_stats else None, stream())
+    return y, (None if part is None else (part[0], part[1]))
+
+
+def can_fuse_conv_input(cin, cout, groups=1):
+    """Preconditions of the fused-input convolution kernels (forward and weight gradient)."""
+    return groups == 1 and cin % 32 == 0 and cin <= 1024 and cout % 4 == 0
+
+
 _WT_CACHE = {}          # (weight address, stream) -> (storage kept alive, transposed filter): one transpose per weight, stream and step
 
 
@@ -103,13 +126,18 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None):
     return dx
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True):
-    """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI)."""
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None):
+    """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI).  ``in_affine = (scale, shift)``: x is a raw conv output and
+    the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation)."""
     _lib._dev(x, dy, dw)
     _, wshape = _ohwi(w_like)
     d = conv_desc(x.shape, wshape, stride, pad)
     nbytes = _lib.load().ssv_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = workspace.get(nbytes, x.device)
+    if in_affine is not None:
+        call("ssv_conv2d_wgrad_bnrelu_in", C.byref(d), ptr(x), ptr(in_affine[0]), ptr(in_affine[1]), ptr(dy), ptr(dw), int(accumulate),
+             ptr(ws), ws.numel(), stream())
+        return dw
     call("ssv_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), int(accumulate), ptr(ws), ws.numel(), stream())
     return dw
 
@@ -136,6 +164,39 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, nbt, relu=False, res
     call("ssv_bn_train_fwd", m, c, ptr(x), ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
          ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mask), ptr(mean), ptr(invstd), ptr(ws), ws.numel(), stream())
     return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
+
+
+def bn_stats_finalize(x_shape_rows, c, partials, gamma, beta, running_mean, running_var, nbt, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Statistics partials of a conv output -> (mean, invstd, scale, shift) + running statistics: BatchNorm without its apply pass."""
+    m = int(x_shape_rows)
+    dev = gamma.device
+    stats = torch.empty((4, c), dtype=torch.float32, device=dev)            # mean | invstd | scale | shift
+    ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), dev)
+    call("ssv_bn_stats_finalize", m, c, ptr(partials[0]), ptr(partials[1]), 64, ptr(gamma), ptr(beta), eps, momentum,
+         ptr(running_mean), ptr(running_var), ptr(nbt), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(ws), ws.numel(), stream())
+    return stats[0], stats[1], stats[2], stats[3]
+
+
+def bn_apply(x, scale, shift, relu=False, residual=None, res_affine=None, want_mask=False):
+    """y = relu?(x * scale + shift (+ residual | + residual * res_scale + res_shift)); returns (y, mask | None)."""
+    _lib._dev(x, scale, shift, residual)
+    m, c = _rows(x)
+    y = torch.empty_like(x)
+    mask = torch.empty((m * c // 4,), dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    rs, rh = res_affine if res_affine is not None else (None, None)
+    call("ssv_bn_apply", m, c, ptr(x), ptr(scale), ptr(shift), ptr(residual), ptr(rs), ptr(rh), int(relu), ptr(y), ptr(mask), stream())
+    return y, mask
+
+
+def bn_relu_bwd_affine(dy, x, gamma, mean, invstd, scale, shift, dgamma, dbeta, accumulate=True):
+    """Backward of a BatchNorm + ReLU whose output was never materialised: the gate is x * scale + shift > 0."""
+    _lib._dev(dy, x)
+    m, c = _rows(x)
+    dx = torch.empty_like(x)
+    ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
+    call("ssv_bn_relu_bwd_affine", m, c, ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(dx),
+         ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
+    return dx
 
 
 def bn_train_bwd(dy, y, x, gamma, mean, invstd, relu, dgamma, dbeta, want_dres=False, accumulate=True, relu_mask=None):

@@ -255,7 +255,7 @@ def test_rccl_collectives_run_on_hardware_with_a_world_of_one(tmp_path):
         env.pop(k, None)
     res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    out = json.loads(res.stdout.strip().splitlines()[-1])
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])      # RCCL prints its own banner lines
     assert out["loss"][0] == out["loss"][1] and out["barlow"][0] == out["barlow"][1], out
     assert out["params_equal"] and out["dz_equal"], out
 

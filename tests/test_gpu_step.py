@@ -408,3 +408,30 @@ def test_resnext50_grouped_convs_match_reference(dev, golden):
     assert np.median(vals) <= 3 * np.median(cpu) + 1e-4 and vals.max() <= 3 * cpu.max() + 1e-3, (float(np.median(vals)), float(np.median(cpu)), float(vals.max()), float(cpu.max()))
     grouped = net.layer1[0].conv2
     assert grouped.groups == 32 and tuple(grouped.weight.shape) == (128, 4, 3, 3)
+
+
+@pytest.mark.parametrize("arch,rbc,size,b", [("resnet50", False, 64, 6), ("resnet18", True, 32, 20)])
+def test_fused_batchnorm_chain_is_bitwise_the_materialised_one(dev, arch, rbc, size, b):
+    """conv -> BN -> ReLU -> conv chains do not write the activation between the convolutions (the consumer applies scale / shift /
+    ReLU while it stages its input, forward and weight gradient; the projection shortcut's BatchNorm is folded into the unit's
+    closing kernel; the backward recomputes the ReLU gate from the forward's own scale / shift).  Same fmaf / fmaxf on the same
+    floats as the stand-alone apply kernel: loss, embeddings, every gradient and the updated parameters must be IDENTICAL bits."""
+    from ssv_amd import nn as hnn
+    a1, a2 = seeded_randn(1500, b, 3, size, size), seeded_randn(1501, b, 3, size, size)
+    outs = []
+    for fuse in (True, False):
+        prev, hnn._FUSE_BN_APPLY = hnn._FUSE_BN_APPLY, fuse
+        try:
+            m = _Step(dev, arch, rbc)
+            loss, z1, z2 = m.step(a1, a2)
+            torch.cuda.synchronize()
+            outs.append((loss, z1.cpu(), z2.cpu(), m.grads.cpu().clone(), m.optim.arena.data.cpu().clone(),
+                         {k: v.cpu().clone() for k, v in m.state().items() if "running" in k}))
+        finally:
+            hnn._FUSE_BN_APPLY = prev
+    f, u = outs
+    assert f[0] == u[0] and torch.equal(f[1], u[1]) and torch.equal(f[2], u[2])
+    assert torch.equal(f[3], u[3]), f"gradients differ: max {float((f[3] - u[3]).abs().max()):.3e}"
+    assert torch.equal(f[4], u[4])
+    for k in f[5]:
+        assert torch.equal(f[5][k], u[5][k]), k
