@@ -81,6 +81,32 @@ int ssv_conv2d_fwd_bnrelu_in_stats(const ssv_conv_desc* d, const float* x, const
 /* ssv_conv2d_wgrad whose x operand is relu(x * in_scale[c] + in_shift[c]) formed on load (same workspace); in_scale == NULL: plain */
 int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy,
                                float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* BatchNorm backward, first half, in the epilogue of the convolution that produces the gradient.  When a launch computes the
+ * gradient w.r.t. the OUTPUT of a BatchNorm (+ residual) + ReLU (the data gradient of the layer that consumed it:
+ * networks/resnet.py:39-44,68-74 run backwards), the gated variants store g = relu'(.) * (conv result + addend) and leave, per group
+ * of 64 output rows and per channel, sum g and sum g * xhat (xhat = (x - mean) * invstd) - the two reductions the BatchNorm backward
+ * needs; ssv_bn_bwd_from_partials finishes it without a reduction pass over (dy, mask, x).  The ReLU bit comes from the forward's
+ * byte mask (`mask`, closing BatchNorm of a residual unit) or is recomputed as x * scale + shift > 0 (`scale` / `shift`, the fused
+ * chain whose activation was never written) - exactly one of the two.  psum_g / psum_gx: [groups][channels] floats, groups from the
+ * matching *_gate_groups (every group is written, zeros included). */
+typedef struct ssv_bn_gate {
+  const float* x;               /* the BatchNorm's input: same shape as this launch's output */
+  const float* scale;           /* forward affine of that BatchNorm, or NULL when `mask` is given */
+  const float* shift;
+  const uint8_t* mask;          /* ReLU byte mask of the BatchNorm's output (ssv_bn_train_fwd / ssv_bn_apply), or NULL */
+  const float* mean;
+  const float* invstd;
+  float* psum_g;
+  float* psum_gx;
+} ssv_bn_gate;
+/* ssv_conv2d_fwd with the gate (stride-1 data gradients run on the forward kernel with the transposed filter).  C % 32 == 0, K % 4 == 0 */
+int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d);
+int ssv_conv2d_fwd_gated(const ssv_conv_desc* d, const float* x, const float* w, const float* addend, float* y,
+                         const ssv_bn_gate* gate, void* stream);
+/* ssv_conv2d_dgrad with the gate.  K % 32 == 0, C % 4 == 0 */
+int64_t ssv_conv2d_dgrad_gate_groups(const ssv_conv_desc* d);
+int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend, float* dx,
+                           const ssv_bn_gate* gate, void* stream);
 /* dx = conv_transpose(dy, w) (+ addend)            addend may alias dx (accumulate) or be NULL */
 int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend,
                      float* dx, void* stream);
@@ -129,6 +155,11 @@ int ssv_bn_apply(int64_t M, int32_t C, const float* x, const float* scale, const
 int ssv_bn_relu_bwd_affine(int64_t M, int32_t C, const float* dy, const float* x, const float* gamma,
                            const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
                            float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* Second half of the BatchNorm backward behind a gated convolution: g is already relu-gated, psum_g / psum_gx hold the partial sums.
+ * dgamma (+)= sum g * xhat, dbeta (+)= sum g, dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)); dx must not alias g. */
+int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, const float* x, const float* gamma,
+                             const float* save_mean, const float* save_invstd, const float* psum_g, const float* psum_gx, int64_t groups,
+                             float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* out[c] (+)= sum_m x[m][c]   (bias gradient of nn.Linear); same workspace size as BN */
 int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int accumulate,
                void* ws, size_t ws_bytes, void* stream);

@@ -22,6 +22,10 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
 
 
+class BnGate(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx")]
+
+
 class AugCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("brightness", "contrast", "saturation", "hue", "p_jitter", "p_gray", "p_flip",
                                           "scale_min", "scale_max", "ratio_min", "ratio_max")]
@@ -51,6 +55,11 @@ SIGNATURES = {
     "ssv_bn_train_fwd_partials": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_filter_transpose": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssv_conv2d_dgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_fwd_gate_groups": (_i64, [_cd]),
+    "ssv_conv2d_fwd_gated": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
+    "ssv_conv2d_dgrad_gate_groups": (_i64, [_cd]),
+    "ssv_conv2d_dgrad_gated": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
+    "ssv_bn_bwd_from_partials": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_bn_workspace_bytes": (_sz, [_i64, _i32]),

@@ -392,8 +392,9 @@ int launch_finalize(int64_t M, int C, const float* pmean, const float* pm2, int 
                     float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_invstd, float* scale, float* shift,
                     float* coarse, size_t coarse_floats, hipStream_t s) {
   int nblk = (int)cdiv64(M, rpb);
-  if (nblk > 2048) {                                          // two-level merge: 32 fine partials -> one coarse one, then the usual finalize
-    const int factor = 32, ncoarse = cdiv(nblk, factor);
+  if (nblk > 2048) {                                          // two-level merge: >= 32 fine partials -> one coarse one, then the usual finalize
+    const int cap = (int)(coarse_floats / ((size_t)2 * C));
+    const int factor = cap > 0 && cdiv(nblk, 32) > cap ? cdiv(nblk, cap) : 32, ncoarse = cdiv(nblk, factor);
     SSV_REQUIRE((size_t)2 * ncoarse * C <= coarse_floats, "bn finalize: workspace too small for the coarse partials");
     float* cmean = coarse;
     float* cm2 = cmean + (size_t)ncoarse * C;
@@ -533,6 +534,34 @@ extern "C" int ssv_bn_relu_bwd_affine(int64_t M, int32_t C, const float* dy, con
   ProfScope ps(SSV_PROF_BN_BWD, s);
   launch_bwd(M, C, dy, nullptr, nullptr, x, gamma, save_mean, save_invstd, scale, shift, 2, dx, nullptr, dgamma, dbeta, accumulate, ws, s);
   SSV_CHECK_LAUNCH("ssv_bn_relu_bwd_affine");
+  return SSV_OK;
+}
+
+extern "C" int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, const float* x, const float* gamma,
+                                        const float* save_mean, const float* save_invstd, const float* psum_g, const float* psum_gx, int64_t groups,
+                                        float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_bwd_from_partials")) return rc;
+  SSV_REQUIRE(g && x && gamma && save_mean && save_invstd && psum_g && psum_gx && groups > 0 && groups < (1ll << 31) && dx && ws, "ssv_bn_bwd_from_partials: bad arguments");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_bwd_from_partials: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_BWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* k1 = (float*)ws;
+  float* k2 = k1 + C;
+  int nblk = (int)groups;
+  if (nblk > 2048) {                                          // two-level merge, as in the forward
+    const int cap = p.nblk;                                   // the workspace holds 2 * p.nblk * C floats behind k1 / k2
+    const int factor = cdiv(nblk, 32) > cap ? cdiv(nblk, cap) : 32, ncoarse = cdiv(nblk, factor);
+    float* c1 = k2 + C;
+    float* c2 = c1 + (size_t)ncoarse * C;
+    hipLaunchKernelGGL(bn_sums_coarsen_k, dim3(cdiv(C, 256), ncoarse), dim3(256), 0, s, C, nblk, factor, psum_g, psum_gx, c1, c2);
+    psum_g = c1; psum_gx = c2; nblk = ncoarse;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, nblk, psum_g, psum_gx, dgamma, dbeta, accumulate, k1, k2);
+  const dim3 grid(p.nblk, p.GY);
+  hipLaunchKernelGGL((bn_bwd_apply_k<0, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, g, (const float*)nullptr, (const uint8_t*)nullptr, x, gamma,
+                     save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, (const float*)k1, (const float*)k2, dx, (float*)nullptr);
+  SSV_CHECK_LAUNCH("ssv_bn_bwd_from_partials");
   return SSV_OK;
 }
 

@@ -26,6 +26,7 @@
 //                                fragments are ds_read_b32, 32 consecutive banks per half-wave.
 // Both operands of one MFMA always take the same k = 8*ks + 4*(l>>5) + t, so any mix is consistent.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -51,6 +52,7 @@ struct ConvKP {
   const float* aux_in;  //                                   dgrad multiplies by gelu'(aux_in) before the addend
   const float* xf_scale;  // XF variants: per-input-channel affine of the fused BatchNorm + ReLU applied to the staged input
   const float* xf_shift;
+  ssv_bn_gate gate;       // GATE variants (this launch computes the gradient w.r.t. a BatchNorm + ReLU output): see epilogue_vec
 };
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
@@ -254,11 +256,16 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // STATS: also reduce, per output column, the rows this wave stores (a group of TM*32 consecutive output rows) to (mean, centred sum
 // of squares) - shifted sums around the group's first row, then a shuffle over the lanes that share a column - and write them as
 // one partial of the BatchNorm that follows (layout of bn_stats_finalize_k with rows-per-block = TM*32).
-template <int TM, int TN, bool EPI = false, bool STATS = false, class RowOff>
+// GATE (1: the ReLU bit recomputed as x * scale + shift > 0, 2: the ReLU bit from the forward's byte mask): the tile is the gradient
+// w.r.t. the OUTPUT of a BatchNorm (+ residual) + ReLU whose input x is bn.x.  The value stored is g = relu'(.) * (acc + addend), and
+// the wave leaves, per column, the two sums the BatchNorm backward needs over its rows - sum g and sum g * xhat - as one partial
+// (bn.psum_g / bn.psum_gx row `group`): the backward's reduction pass over (dy, mask, x) disappears, at the price of reading x here.
+template <int TM, int TN, bool EPI = false, bool STATS = false, int GATE = 0, class RowOff>
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
                                              const float* __restrict__ bias, const float* addend, float* out, RowOff&& row_off,
                                              float* out_act = nullptr, const float* gate = nullptr,
-                                             float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0) {
+                                             float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0,
+                                             const ssv_bn_gate* bn = nullptr, long long group = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
@@ -266,6 +273,13 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   const bool cok = gcol < ncols;
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 st_p = {0.f, 0.f, 0.f, 0.f}, st_s1 = {0.f, 0.f, 0.f, 0.f}, st_s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g_mu = {0.f, 0.f, 0.f, 0.f}, g_is = {0.f, 0.f, 0.f, 0.f}, g_sc = {0.f, 0.f, 0.f, 0.f}, g_sh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (GATE != 0) {
+    if (cok) {
+      g_mu = *reinterpret_cast<const f32x4*>(bn->mean + gcol); g_is = *reinterpret_cast<const f32x4*>(bn->invstd + gcol);
+      if constexpr (GATE == 1) { g_sc = *reinterpret_cast<const f32x4*>(bn->scale + gcol); g_sh = *reinterpret_cast<const f32x4*>(bn->shift + gcol); }
+    }
+  }
   if (bias && cok) b4 = *reinterpret_cast<const f32x4*>(bias + gcol);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -290,6 +304,19 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
           }
         }
         if (addend) v += *reinterpret_cast<const f32x4*>(addend + off + gcol);
+        if constexpr (GATE != 0) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(bn->x + off + gcol);
+          if constexpr (GATE == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[e], g_sc[e], g_sh[e]) > 0.f ? v[e] : 0.f;
+          } else {
+            const unsigned bits = bn->mask[(off + gcol) >> 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bits >> e) & 1u ? v[e] : 0.f;
+          }
+          st_s1 += v;
+          st_s2 += v * ((xv - g_mu) * g_is);
+        }
         *reinterpret_cast<f32x4*>(out + off + gcol) = v;
         if constexpr (EPI) {
           if (out_act) {
@@ -314,12 +341,23 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
       *reinterpret_cast<f32x4*>(pm2 + gcol) = st_s2 - st_s1 * st_s1 / n;
     }
   }
+  if constexpr (GATE != 0) {
+#pragma unroll
+    for (int o = C4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st_s1[e] += __shfl_xor(st_s1[e], o, 64); st_s2[e] += __shfl_xor(st_s2[e], o, 64); }
+    }
+    if (r_in == 0 && cok) {       // every wave writes its partial, zeros included: the finalize kernel reads all of them
+      *reinterpret_cast<f32x4*>(bn->psum_g + group * ncols + gcol) = st_s1;
+      *reinterpret_cast<f32x4*>(bn->psum_gx + group * ncols + gcol) = st_s2;
+    }
+  }
 }
 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0>
 __global__ void __launch_bounds__(256)
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
@@ -553,6 +591,11 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         epilogue_vec<TM, TN, false, true>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
                                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                           nullptr, nullptr, p.aux_out + (size_t)g * p.K, p.aux_out2 + (size_t)g * p.K, valid > 0 ? valid : 0);
+      } else if constexpr (GATE != 0) {
+        static_assert(BM / WGM == 64, "gate partials are per 64 output rows");
+        epilogue_vec<TM, TN, false, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+                                                 [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
+                                                 nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
       } else {
         epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
                                   [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
@@ -561,6 +604,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       return;
     }
   }
+  static_assert(GATE == 0 || (VEC && EP_FLOATS <= STAGE), "the gated epilogue is the vectorised one");
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -587,7 +631,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // dgrad: rows are the input pixels of ONE stride-parity class (blockIdx.y); only taps with
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false, int GATE = 0>
 __global__ void __launch_bounds__(256)
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -610,7 +654,14 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= Mc) return;
+  if (m0 >= Mc) {
+    if constexpr (GATE != 0) {       // a tile past this class's rows: its gate partials must still read as zeros
+      const long long grp = ((long long)blockIdx.y * (gridDim.x / NT) + mt) * (BM / 64) + (wr0 / 64);
+      const int col = n0 + wc0 + lane;                          // BN / WGN columns per wave (64 or 128): lanes stride 64
+      for (int c = col; c < min(n0 + wc0 + BN / WGN, p.C); c += 64) { p.gate.psum_g[grp * p.C + c] = 0.f; p.gate.psum_gx[grp * p.C + c] = 0.f; }
+    }
+    return;
+  }
 
   if (tid == 0) {
     int n = 0;
@@ -704,10 +755,19 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
   static_assert(!EPI || EP_FLOATS <= STAGE, "the fused-activation dgrad needs the vectorised epilogue");
+  static_assert(GATE == 0 || (EP_FLOATS <= STAGE && BM / WGM == 64), "the gated epilogue is the vectorised one, partials per 64 rows");
   if constexpr (EP_FLOATS <= STAGE) {       // C % 4 == 0 is a precondition of this kernel
-    epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
-                              [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
-                              nullptr, EPI ? p.aux_in : nullptr);
+    if constexpr (GATE != 0) {
+      // partial index: (parity class, row tile, 64-row group of the wave) - the grid has the same number of row tiles for every class
+      const long long grp = ((long long)blockIdx.y * (gridDim.x / NT) + mt) * (BM / 64) + (wr0 / 64);
+      epilogue_vec<TM, TN, false, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
+                                               [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
+                                               nullptr, nullptr, nullptr, nullptr, 0, &p.gate, grp);
+    } else {
+      epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
+                                [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
+                                nullptr, EPI ? p.aux_in : nullptr);
+    }
     return;
   }
   const int l31 = lane & 31, h = lane >> 5;
@@ -949,6 +1009,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dC = make_fastdiv((uint32_t)d->C);
   p.dS = make_fastdiv((uint32_t)d->S);
   p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr; p.xf_scale = nullptr; p.xf_shift = nullptr;
+  memset(&p.gate, 0, sizeof(p.gate));
   return p;
 }
 
@@ -983,11 +1044,21 @@ namespace {
 
 // forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
 int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
-               float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s) {
+               float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s, const ssv_bn_gate* gate = nullptr) {
   ConvKP p = make_kp(d);
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
   const bool wide = d->K >= 128;
+  if (gate) {                                                  // C % 32 == 0 checked by the caller
+    p.gate = *gate;
+    const unsigned gg = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+#define FWDG(BM_, BN_, WM_, WN_, G_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(gg), dim3(256), 0, s, p, x, w, bias, addend, y)
+    if (gate->mask) { if (wide) FWDG(128, 128, 2, 2, 2); else FWDG(256, 64, 4, 1, 2); }
+    else            { if (wide) FWDG(128, 128, 2, 2, 1); else FWDG(256, 64, 4, 1, 1); }
+#undef FWDG
+    return SSV_OK;
+  }
   const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
 #define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
@@ -1022,6 +1093,38 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   launch_fwd(d, x, w, bias, addend, y, nullptr, nullptr, nullptr, nullptr, s);
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd");
+  return SSV_OK;
+}
+
+namespace {
+int check_gate(const ssv_bn_gate* g, const char* who) {
+  SSV_REQUIRE(g && g->x && g->mean && g->invstd && g->psum_g && g->psum_gx, "%s: incomplete gate", who);
+  SSV_REQUIRE((g->mask != nullptr) != (g->scale != nullptr && g->shift != nullptr) && (g->scale == nullptr) == (g->shift == nullptr),
+              "%s: a gate carries either the byte mask or scale + shift", who);
+  SSV_REQUIRE((((uintptr_t)g->x | (uintptr_t)g->mean | (uintptr_t)g->invstd | (uintptr_t)g->psum_g | (uintptr_t)g->psum_gx | (uintptr_t)g->scale | (uintptr_t)g->shift) & 15) == 0,
+              "%s: gate pointers must be 16-byte aligned", who);
+  return SSV_OK;
+}
+}  // namespace
+
+extern "C" int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d) {
+  if (!d || d->K <= 0) return 0;
+  const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+  const int bm = d->K >= 128 ? 128 : 256;
+  return cdiv64(M, bm) * (bm / 64);
+}
+
+extern "C" int ssv_conv2d_fwd_gated(const ssv_conv_desc* d, const float* x, const float* w, const float* addend, float* y,
+                                    const ssv_bn_gate* gate, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_gated")) return rc;
+  if (int rc = check_gate(gate, "ssv_conv2d_fwd_gated")) return rc;
+  SSV_REQUIRE(x && w && y, "ssv_conv2d_fwd_gated: null pointer");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)addend) & 15) == 0, "ssv_conv2d_fwd_gated: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0, "ssv_conv2d_fwd_gated: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  launch_fwd(d, x, w, nullptr, addend, y, nullptr, nullptr, nullptr, nullptr, s, gate);
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_gated");
   return SSV_OK;
 }
 
@@ -1112,6 +1215,40 @@ extern "C" int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const f
     else      hipLaunchKernelGGL((conv_dgrad_k<256, 64, 4, 1, 16>), g, dim3(256), 0, s, p, dy, w, addend, dx);
   }
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad");
+  return SSV_OK;
+}
+
+extern "C" int64_t ssv_conv2d_dgrad_gate_groups(const ssv_conv_desc* d) {
+  if (!d || d->C <= 0 || d->stride <= 0) return 0;
+  const int st = d->stride;
+  const int64_t Mc = (int64_t)d->N * cdiv(d->H, st) * cdiv(d->W, st);
+  const int bm = d->C >= 128 ? 128 : 256;
+  return (int64_t)st * st * cdiv64(Mc, bm) * (bm / 64);
+}
+
+extern "C" int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend, float* dx,
+                                      const ssv_bn_gate* gate, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_dgrad_gated")) return rc;
+  if (int rc = check_gate(gate, "ssv_conv2d_dgrad_gated")) return rc;
+  SSV_REQUIRE(dy && w && dx, "ssv_conv2d_dgrad_gated: null pointer");
+  SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)addend) & 15) == 0, "ssv_conv2d_dgrad_gated: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->K % 32 == 0 && d->C % 4 == 0 && d->stride <= 8, "ssv_conv2d_dgrad_gated: needs K %% 32 == 0, C %% 4 == 0, stride <= 8 (got K=%d C=%d)", d->K, d->C);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_DGRAD, s);
+  ConvKP p = make_kp(d);
+  p.gate = *gate;
+  const int st = d->stride;
+  const int64_t Mc = (int64_t)d->N * cdiv(d->H, st) * cdiv(d->W, st);
+#define DG(BM_, BN_, WM_, WN_, G_) hipLaunchKernelGGL((conv_dgrad_k<BM_, BN_, WM_, WN_, 32, false, G_>), g, dim3(256), 0, s, p, dy, w, addend, dx)
+  if (d->C >= 128) {
+    const dim3 g((unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128)), st * st);
+    if (gate->mask) DG(128, 128, 2, 2, 2); else DG(128, 128, 2, 2, 1);
+  } else {
+    const dim3 g((unsigned)(cdiv64(Mc, 256) * cdiv(d->C, 64)), st * st);
+    if (gate->mask) DG(256, 64, 4, 1, 2); else DG(256, 64, 4, 1, 1);
+  }
+#undef DG
+  SSV_CHECK_LAUNCH("ssv_conv2d_dgrad_gated");
   return SSV_OK;
 }
 

@@ -117,21 +117,31 @@ class Tape:
         self.root = root
         self.root_needs_grad = root_needs_grad
         self.slot = _SLOT                     # which gradient slab this pass accumulates into
+        self.uses = {}                        # id(input) -> number of recorded ops that read it
+        self.last = ()                        # during backward: per input of the running op, "no other op will add to its gradient"
 
     def record(self, inputs, output, bwd):
         self.ops.append((inputs, output, bwd))
+        for t in inputs:
+            if t is not None:
+                self.uses[id(t)] = self.uses.get(id(t), 0) + 1
 
     def needs_grad(self, t):
         return t is not self.root or self.root_needs_grad
 
     def backward(self, out, dout):
         grads = {id(out): dout}
+        uses = self.uses
         while self.ops:
             inputs, output, bwd = self.ops.pop()
             g = grads.pop(id(output), None)
+            for t in inputs:
+                if t is not None:
+                    uses[id(t)] -= 1
             if g is None:
                 continue
             existing = [None if t is None else grads.get(id(t)) for t in inputs]
+            self.last = tuple(t is not None and uses[id(t)] == 0 for t in inputs)
             new = bwd(g, existing)
             for t, ng in zip(inputs, new):
                 if t is not None and ng is not None:
@@ -166,6 +176,7 @@ _PAD_STEM = os.environ.get("SSV_NO_STEM_PADDING", "0") != "1"
 
 
 _FUSE_BN_APPLY = os.environ.get("SSV_NO_BN_APPLY_FUSION", "0") != "1"      # diagnostic switch: materialise every activation
+_FUSE_BN_BWD = os.environ.get("SSV_NO_BN_BWD_FUSION", "0") != "1"          # diagnostic switch: BatchNorm backward with its own reduction pass
 
 
 class LazyAct:
@@ -173,10 +184,11 @@ class LazyAct:
     on the fly: a convolution while it stages its input (forward and weight gradient), the closing BatchNorm of a residual unit when it
     adds the projection shortcut.  ``raw`` is the producer's conv output (kept for the backward anyway); scale / shift / mean / invstd
     come from ssv_bn_stats_finalize.  On the tape it stands where the activation tensor would: gradients are keyed by this object."""
-    __slots__ = ("raw", "scale", "shift", "mean", "invstd", "relu")
+    __slots__ = ("raw", "scale", "shift", "mean", "invstd", "relu", "_bn_gate")
 
     def __init__(self, raw, scale, shift, mean, invstd, relu):
         self.raw, self.scale, self.shift, self.mean, self.invstd, self.relu = raw, scale, shift, mean, invstd, relu
+        self._bn_gate = None
 
     @property
     def shape(self):
@@ -219,7 +231,9 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
             if not need_dx:
                 return (None,)
             ex = existing[0]
-            dx = ops.conv2d_dgrad(dy, weight, src.shape, stride, pad, addend=ex, out=ex)
+            # x is the output of a BatchNorm + ReLU and nothing else will add to its gradient: gate + reduce in this epilogue
+            gate = getattr(x, "_bn_gate", None) if (tape.last[0] and _FUSE_BN_BWD) else None
+            dx = ops.conv2d_dgrad(dy, weight, src.shape, stride, pad, addend=ex, out=ex, gate=gate)
             return (dx,)
         tape.record((x,), y, bwd)
     return y
@@ -302,8 +316,14 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
             if tape is not None:
                 slot = tape.slot
 
+                if relu:
+                    out._bn_gate = ops.BnGateCtx(x, mean, invstd, scale=scale, shift=shift)
+
                 def bwd_lazy(dact, existing):
-                    if relu:
+                    part = dact.__dict__.pop("_gate_partials", None)      # consumed here: the buffer may be reused for another gradient
+                    if part is not None:          # the consumer's data gradient already gated dact and reduced it
+                        dx = ops.bn_bwd_from_partials(dact, x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
+                    elif relu:
                         dx = ops.bn_relu_bwd_affine(dact, x, bn.weight, mean, invstd, scale, shift, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
                     else:
                         dx, _ = ops.bn_train_bwd(dact, None, x, bn.weight, mean, invstd, False, grad_of(bn.weight, slot), grad_of(bn.bias, slot), accumulate=True)
@@ -320,9 +340,17 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
     if tape is not None:
         slot = tape.slot
 
+        if relu and mask is not None:
+            y._bn_gate = ops.BnGateCtx(x, mean, invstd, mask=mask)
+
         def bwd(dy, existing):
-            dx, dres = ops.bn_train_bwd(dy, y, x, bn.weight, mean, invstd, relu, grad_of(bn.weight, slot), grad_of(bn.bias, slot),
-                                        want_dres=residual is not None, accumulate=True, relu_mask=mask)
+            part = dy.__dict__.pop("_gate_partials", None)        # consumed here: dy's buffer goes on as the residual gradient
+            if part is not None:                  # dy arrives relu-gated with its partial sums: no reduction pass, and dresidual IS dy
+                dx = ops.bn_bwd_from_partials(dy, x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
+                dres = dy if residual is not None else None
+            else:
+                dx, dres = ops.bn_train_bwd(dy, y, x, bn.weight, mean, invstd, relu, grad_of(bn.weight, slot), grad_of(bn.bias, slot),
+                                            want_dres=residual is not None, accumulate=True, relu_mask=mask)
             if residual is None:
                 return (_accum(existing[0], dx), None)
             return (_accum(existing[0], dx), _accum(existing[1], dres))

@@ -106,22 +106,55 @@ def _transposed_filter(w, wshape):
     return wt
 
 
-def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None):
+class BnGateCtx:
+    """What a convolution's data gradient needs to run the first half of the BatchNorm backward in its epilogue (include/ssv_hip.h,
+    ssv_bn_gate): the BatchNorm's input x, its saved statistics, and the ReLU bit - byte mask or the forward's (scale, shift)."""
+    __slots__ = ("x", "mean", "invstd", "mask", "scale", "shift")
+
+    def __init__(self, x, mean, invstd, mask=None, scale=None, shift=None):
+        self.x, self.mean, self.invstd, self.mask, self.scale, self.shift = x, mean, invstd, mask, scale, shift
+
+
+def _gate_struct(gate, groups, channels, like):
+    part = _empty((2, groups, channels), like)
+    st = _lib.BnGate(ptr(gate.x), ptr(gate.scale), ptr(gate.shift), ptr(gate.mask), ptr(gate.mean), ptr(gate.invstd), ptr(part[0]), ptr(part[1]))
+    return st, part
+
+
+def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=None):
     """dx = conv_transpose(dy, w) (+ addend).  Stride-1 layers (every Linear, every 1x1 and 3x3 stride-1 convolution) are computed
     as the FORWARD convolution of dy with the transposed, 180-degree rotated filter: both GEMM operands are then k-contiguous
-    rows for ds_read_b128, which the dgrad kernel (weights read in place, k-major) cannot have - measured 5-15 % faster."""
+    rows for ds_read_b128, which the dgrad kernel (weights read in place, k-major) cannot have - measured 5-15 % faster.
+    ``gate`` (BnGateCtx): dx is the gradient w.r.t. a BatchNorm + ReLU output and this call is its LAST contribution - the epilogue
+    stores the relu-gated gradient and the partial sums of the BatchNorm backward; they come back as ``dx._gate_partials``
+    (psum_g, psum_gx, groups).  Silently ungated when the shape is outside the gated kernels' preconditions."""
     _lib._dev(dy, w, addend)
     w, wshape = _ohwi(w)
     k, c, r, s_ = wshape
     dx = out if out is not None else _empty(tuple(x_shape), dy)
+    dx.__dict__.pop("_gate_partials", None)            # an accumulated-into buffer never keeps the partial sums of its old content
+    if gate is not None and (k % 32 or c % 4 or tuple(gate.x.shape) != tuple(dx.shape)):
+        gate = None
     if stride == 1 and r == s_ and r - 1 - pad >= 0 and k % 16 == 0 and c % 4 == 0:
         wt = _transposed_filter(w, wshape)
         d = conv_desc(dy.shape, (c, k, r, s_), 1, r - 1 - pad)
         if (d.Ho, d.Wo) != (x_shape[1], x_shape[2]):
             raise _lib.SsvError("conv2d_dgrad: input shape does not match the stride-1 geometry")
+        if gate is not None:
+            groups = int(_lib.load().ssv_conv2d_fwd_gate_groups(C.byref(d)))
+            st, part = _gate_struct(gate, groups, c, dy)
+            call("ssv_conv2d_fwd_gated", C.byref(d), ptr(dy), ptr(wt), ptr(addend), ptr(dx), C.byref(st), stream())
+            dx._gate_partials = (part[0], part[1], groups)
+            return dx
         call("ssv_conv2d_fwd", C.byref(d), ptr(dy), ptr(wt), None, ptr(addend), ptr(dx), stream())
         return dx
     d = conv_desc(x_shape, wshape, stride, pad)
+    if gate is not None and stride <= 8:
+        groups = int(_lib.load().ssv_conv2d_dgrad_gate_groups(C.byref(d)))
+        st, part = _gate_struct(gate, groups, c, dy)
+        call("ssv_conv2d_dgrad_gated", C.byref(d), ptr(dy), ptr(w), ptr(addend), ptr(dx), C.byref(st), stream())
+        dx._gate_partials = (part[0], part[1], groups)
+        return dx
     call("ssv_conv2d_dgrad", C.byref(d), ptr(dy), ptr(w), ptr(addend), ptr(dx), stream())
     return dx
 
@@ -196,6 +229,17 @@ def bn_relu_bwd_affine(dy, x, gamma, mean, invstd, scale, shift, dgamma, dbeta, 
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
     call("ssv_bn_relu_bwd_affine", m, c, ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(dx),
          ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
+    return dx
+
+
+def bn_bwd_from_partials(g, x, gamma, mean, invstd, partials, dgamma, dbeta, accumulate=True):
+    """Second half of the BatchNorm backward behind a gated convolution (g already relu-gated, partial sums given)."""
+    _lib._dev(g, x)
+    m, c = _rows(x)
+    dx = torch.empty_like(x)
+    ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
+    call("ssv_bn_bwd_from_partials", m, c, ptr(g), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(partials[0]), ptr(partials[1]), int(partials[2]),
+         ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
     return dx
 
 

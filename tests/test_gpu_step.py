@@ -435,3 +435,33 @@ def test_fused_batchnorm_chain_is_bitwise_the_materialised_one(dev, arch, rbc, s
     assert torch.equal(f[4], u[4])
     for k in f[5]:
         assert torch.equal(f[5][k], u[5][k]), k
+
+
+@pytest.mark.parametrize("arch,rbc,size,b", [("resnet50", False, 64, 6), ("resnet18", True, 32, 20), ("resnet50", False, 96, 3)])
+def test_batchnorm_backward_reduced_in_the_conv_epilogue_matches_the_two_pass_form(dev, arch, rbc, size, b):
+    """The data gradient that feeds a BatchNorm + ReLU backward gates itself and reduces (sum g, sum g * xhat) in its own epilogue
+    (stride-1 layers on the forward kernel, stride-2 layers on the dgrad kernel, byte-mask and recomputed-gate variants); the
+    stand-alone reduction pass is skipped.  Same ReLU bits, same sums in a different order: the forward is bit-identical and every
+    gradient tensor agrees to rounding (1e-5 relative l2; no ReLU flip can occur, the masks are the forward's)."""
+    from ssv_amd import nn as hnn
+    a1, a2 = seeded_randn(1600, b, 3, size, size), seeded_randn(1601, b, 3, size, size)
+    outs = []
+    for fuse in (True, False):
+        prev, hnn._FUSE_BN_BWD = hnn._FUSE_BN_BWD, fuse
+        try:
+            m = _Step(dev, arch, rbc)
+            loss, z1, z2 = m.step(a1, a2)
+            torch.cuda.synchronize()
+            outs.append((loss, z1.cpu(), m, m.grads.cpu().clone()))
+        finally:
+            hnn._FUSE_BN_BWD = prev
+    (lf, zf, m, gf), (lu, zu, _, gu) = outs
+    assert lf == lu and torch.equal(zf, zu)
+    worst = 0.0
+    for p, off in zip(m.params(), m.optim.arena.offsets):
+        a, r = gf[off:off + p.numel()].double(), gu[off:off + p.numel()].double()
+        if float(r.norm()) < 1e-5:
+            assert float(a.abs().max()) < 1e-5
+            continue
+        worst = max(worst, float((a - r).norm() / r.norm()))
+    assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"
