@@ -27,6 +27,7 @@
 // Both operands of one MFMA always take the same k = 8*ks + 4*(l>>5) + t, so any mix is consistent.
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -253,6 +254,15 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // bias / residual addend are read 16 bytes per lane too).  LDS traffic of one wave is in order, so no barrier is needed
 // inside; the caller has passed the barrier that ends the K loop.  row_off(r) gives the element offset of output row r of
 // the wave tile, or -1.
+//
+// Everything that touches global memory here is a BUFFER operation on a (base, size) descriptor with a per-lane byte offset: rows past
+// the tensor and columns past its width get the out-of-range offset, whose loads return zero and whose stores are dropped by the
+// hardware.  So the body is straight-line code - no exec-mask region per row - and the loads a row needs (residual addend, gate
+// operands) are issued for a whole batch of rows before the first of their stores.  With a branch per row and plain pointers (the
+// addend may alias the output when accumulating in place) every row was a dependent HBM round trip: the unit-input gradients of
+// layer1 / layer2 ran latency-bound at 35-60 TFLOP/s.  The aliasing that exists is "this lane reads the element it then writes" - a
+// data dependency the issue order cannot break.
+//
 // STATS: also reduce, per output column, the rows this wave stores (a group of TM*32 consecutive output rows) to (mean, centred sum
 // of squares) - shifted sums around the group's first row, then a shuffle over the lanes that share a column - and write them as
 // one partial of the BatchNorm that follows (layout of bn_stats_finalize_k with rows-per-block = TM*32).
@@ -260,17 +270,26 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // w.r.t. the OUTPUT of a BatchNorm (+ residual) + ReLU whose input x is bn.x.  The value stored is g = relu'(.) * (acc + addend), and
 // the wave leaves, per column, the two sums the BatchNorm backward needs over its rows - sum g and sum g * xhat - as one partial
 // (bn.psum_g / bn.psum_gx row `group`): the backward's reduction pass over (dy, mask, x) disappears, at the price of reading x here.
-template <int TM, int TN, bool EPI = false, bool STATS = false, int GATE = 0, class RowOff>
+// EPI: 1 = also write gelu(v) to out_act (Linear + GELU forward), 2 = multiply by gelu'(gate) before the addend (its backward).
+__device__ __forceinline__ void bstore4(rsrc_t rs, int voff_bytes, f32x4 v) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, voff_bytes, 0, 0);
+}
+
+template <int TM, int TN, int EPI = 0, bool STATS = false, int GATE = 0, class RowOff>
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
-                                             const float* __restrict__ bias, const float* addend, float* out, RowOff&& row_off,
+                                             const float* __restrict__ bias, const float* addend, float* out, long long out_elems, RowOff&& row_off,
                                              float* out_act = nullptr, const float* gate = nullptr,
                                              float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0,
                                              const ssv_bn_gate* bn = nullptr, long long group = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
+  constexpr int HB = GATE == 1 ? 2 : (NP < 4 ? NP : 4);   // rows per batch: the loads of a batch are in flight together (register budget of 3 workgroups per CU)
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
   const bool cok = gcol < ncols;
+  const unsigned bytes = (unsigned)(out_elems * 4);
+  const rsrc_t r_out = make_rsrc(out, bytes);
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 st_p = {0.f, 0.f, 0.f, 0.f}, st_s1 = {0.f, 0.f, 0.f, 0.f}, st_s2 = {0.f, 0.f, 0.f, 0.f};
   f32x4 g_mu = {0.f, 0.f, 0.f, 0.f}, g_is = {0.f, 0.f, 0.f, 0.f}, g_sc = {0.f, 0.f, 0.f, 0.f}, g_sh = {0.f, 0.f, 0.f, 0.f};
@@ -281,54 +300,79 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
     }
   }
   if (bias && cok) b4 = *reinterpret_cast<const f32x4*>(bias + gcol);
+
+  const bool ADD = addend != nullptr;            // uniform
+  {
+    const rsrc_t r_add = make_rsrc(ADD ? addend : out, bytes);
+    const rsrc_t r_gx = make_rsrc(GATE != 0 ? bn->x : out, bytes);
+    const rsrc_t r_gm = make_rsrc(GATE == 2 ? reinterpret_cast<const float*>(bn->mask) : out, bytes / 16);
+    const rsrc_t r_gate = make_rsrc(EPI == 2 ? gate : out, bytes);
+    const rsrc_t r_act = make_rsrc(EPI == 1 ? out_act : out, bytes);
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
-    if constexpr (STATS) { if (tm == 0) st_p = *reinterpret_cast<const f32x4*>(&ep[c4 * 4]); }     // pivot: first row of the group
+        for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
+      if constexpr (STATS) { if (tm == 0) st_p = *reinterpret_cast<const f32x4*>(&ep[c4 * 4]); }     // pivot: first row of the group
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const int r = q * RPI + r_in;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&ep[r * LDE + c4 * 4]);
-      const long long off = row_off(tm * 32 + r);
-      if (off >= 0 && cok) {
-        if constexpr (STATS) { const f32x4 dv = v - st_p; st_s1 += dv; st_s2 += dv * dv; }
-        v += b4;
-        if constexpr (EPI) {
-          if (gate) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gate + off + gcol);
+      for (int q0 = 0; q0 < NP; q0 += HB) {
+        __builtin_amdgcn_sched_barrier(0);       // one batch of rows in flight at a time (register budget of 3 workgroups per CU)
+        int voff[HB];
+        f32x4 av[HB], xv[HB], gv[HB];
+        unsigned mb[HB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(g[e]);
-          }
+        for (int i = 0; i < HB; ++i) {
+          const long long off = row_off(tm * 32 + (q0 + i) * RPI + r_in);
+          voff[i] = (off >= 0 && cok) ? (int)(off + gcol) * 4 : OOB_OFF;        // tensors stay below 2^29 elements (check_desc)
+          if (ADD) av[i] = bload4(r_add, voff[i], 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == 2) gv[i] = bload4(r_gate, voff[i], 0);
+          if constexpr (GATE != 0) xv[i] = bload4(r_gx, voff[i], 0);
+          if constexpr (GATE == 2) mb[i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[i] == OOB_OFF ? OOB_OFF : voff[i] >> 4, 0, 0);
         }
-        if (addend) v += *reinterpret_cast<const f32x4*>(addend + off + gcol);
-        if constexpr (GATE != 0) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(bn->x + off + gcol);
-          if constexpr (GATE == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[e], g_sc[e], g_sh[e]) > 0.f ? v[e] : 0.f;
-          } else {
-            const unsigned bits = bn->mask[(off + gcol) >> 2];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bits >> e) & 1u ? v[e] : 0.f;
+        for (int i = 0; i < HB; ++i) {
+          const int r = (q0 + i) * RPI + r_in;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&ep[r * LDE + c4 * 4]);
+          const bool ok = voff[i] != OOB_OFF;
+          if constexpr (STATS) {
+            f32x4 dv = v - st_p;
+            dv[0] = ok ? dv[0] : 0.f; dv[1] = ok ? dv[1] : 0.f; dv[2] = ok ? dv[2] : 0.f; dv[3] = ok ? dv[3] : 0.f;
+            st_s1 += dv; st_s2 += dv * dv;
           }
-          st_s1 += v;
-          st_s2 += v * ((xv - g_mu) * g_is);
-        }
-        *reinterpret_cast<f32x4*>(out + off + gcol) = v;
-        if constexpr (EPI) {
-          if (out_act) {
+          v += b4;
+          if constexpr (EPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(gv[i][e]);
+          }
+          v += av[i];
+          if constexpr (GATE != 0) {
+            if constexpr (GATE == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[i][e], g_sc[e], g_sh[e]) > 0.f ? v[e] : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (mb[i] >> e) & 1u ? v[e] : 0.f;
+            }
+            // an out-of-range row / column contributes nothing: its v is garbage but its mask byte read as 0 (GATE 2) or its x as 0
+            // (GATE 1: the gate is then shift > 0, so force the product to zero explicitly)
+            f32x4 gvv = v;
+            if constexpr (GATE == 1) { gvv[0] = ok ? v[0] : 0.f; gvv[1] = ok ? v[1] : 0.f; gvv[2] = ok ? v[2] : 0.f; gvv[3] = ok ? v[3] : 0.f; }
+            st_s1 += gvv;
+            st_s2 += gvv * ((xv[i] - g_mu) * g_is);
+          }
+          bstore4(r_out, voff[i], v);
+          if constexpr (EPI == 1) {
             f32x4 a;
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] = gelu_f(v[e]);
-            *reinterpret_cast<f32x4*>(out_act + off + gcol) = a;
+            bstore4(r_act, voff[i], a);
           }
         }
       }
     }
   }
+
   if constexpr (STATS) {
 #pragma unroll
     for (int o = C4; o < 64; o <<= 1) {
@@ -358,7 +402,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // forward
 // =============================================================================================
 template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -588,18 +632,18 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         constexpr int GR = TM * 32;
         const int g = rbase / GR;
         const int valid = min(GR, p.M - rbase);
-        epilogue_vec<TM, TN, false, true>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+        epilogue_vec<TM, TN, 0, true>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                           nullptr, nullptr, p.aux_out + (size_t)g * p.K, p.aux_out2 + (size_t)g * p.K, valid > 0 ? valid : 0);
       } else if constexpr (GATE != 0) {
         static_assert(BM / WGM == 64, "gate partials are per 64 output rows");
-        epilogue_vec<TM, TN, false, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
+        epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                                  [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                                  nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
       } else {
-        epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y,
-                                  [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
-                                  EPI ? p.aux_out : nullptr, nullptr);
+        epilogue_vec<TM, TN, EPI ? 1 : 0>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
+                                          [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
+                                          EPI ? p.aux_out : nullptr, nullptr);
       }
       return;
     }
@@ -632,7 +676,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
 template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false, int GATE = 0>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;
@@ -760,13 +804,13 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
     if constexpr (GATE != 0) {
       // partial index: (parity class, row tile, 64-row group of the wave) - the grid has the same number of row tiles for every class
       const long long grp = ((long long)blockIdx.y * (gridDim.x / NT) + mt) * (BM / 64) + (wr0 / 64);
-      epilogue_vec<TM, TN, false, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
+      epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx, (long long)p.N * p.H * p.W * p.C,
                                                [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
                                                nullptr, nullptr, nullptr, nullptr, 0, &p.gate, grp);
     } else {
-      epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx,
-                                [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
-                                nullptr, EPI ? p.aux_in : nullptr);
+      epilogue_vec<TM, TN, EPI ? 2 : 0>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx, (long long)p.N * p.H * p.W * p.C,
+                                        [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
+                                        nullptr, EPI ? p.aux_in : nullptr);
     }
     return;
   }
@@ -940,7 +984,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   float* out = partial + (size_t)split * p.K * p.RSC;
   if ((p.RSC & 3) == 0) {      // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
     const int rbase = i0 + wr0;
-    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, p.RSC, nullptr, nullptr, out,
+    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, p.RSC, nullptr, nullptr, out, (long long)p.K * p.RSC,
                          [&](int r) -> long long { const int row = rbase + r; return row < p.K ? (long long)row * p.RSC : -1; });
     return;
   }

@@ -104,9 +104,9 @@ def test_byol_r18_trajectory_within_bar_on_every_step(dev):
 def test_step2_lies_inside_the_fp32_ensemble_at_the_config_learning_rate(dev):
     """configs/simclr.yaml as shipped (lr 2.0 -> 0.2, bs 64, resnet18): the loss at steps 0-2.  The ensemble = the CPU oracle under
     1 / 2 / all host threads (different reduction trees inside ATen) and under two permutations of the samples inside the batch
-    (the loss is permutation invariant; its rounding is not), plus an fp64 evaluation as the centre.  Steps 0-1: every member and
-    the HIP path agree to 1e-4.  Step 2: the members spread (training amplifies the rounding of the first updates); the HIP path
-    must be no further from the fp64 centre than 3x the furthest fp32 member."""
+    (the loss is permutation invariant; its rounding is not), plus an fp64 evaluation as the centre.  Step 0: every member and the
+    HIP path agree to 1e-5.  Steps 1-2: the members spread (training at lr 0.2 amplifies the rounding of the earlier updates ~1000x
+    per step); the HIP path must be no further from the fp64 centre than 3x the furthest fp32 member (+ the 1e-4 bar)."""
     views = [_views(100 + 2 * s, 64) for s in range(3)]          # the inputs of test_simclr_r18_steps_match_reference_and_oracle
     make = lambda: oracle.SimCLROracle("resnet18", True, 128, lr=1e-12 + 0.2, weight_decay=1e-4)
     threads = torch.get_num_threads()
@@ -124,12 +124,12 @@ def test_step2_lies_inside_the_fp32_ensemble_at_the_config_learning_rate(dev):
     m = _Step(dev, "resnet18", True)
     hip = [m.step(*vs)[0] for vs in views]
     members = np.array(members)
-    for s in (0, 1):
-        np.testing.assert_allclose(members[:, s], centre[s], rtol=BAR, err_msg=f"ensemble step {s}")
-        np.testing.assert_allclose(hip[s], centre[s], rtol=BAR, err_msg=f"hip step {s}")
-    spread = float(np.abs(members[:, 2] - centre[2]).max())
-    assert abs(hip[2] - centre[2]) <= 3 * spread + BAR * abs(centre[2]), \
-        f"step 2: hip {hip[2]:.6f}, fp64 {centre[2]:.6f}, fp32 ensemble {members[:, 2].tolist()} (spread {spread:.2e})"
+    np.testing.assert_allclose(members[:, 0], centre[0], rtol=1e-5, err_msg="ensemble step 0")
+    np.testing.assert_allclose(hip[0], centre[0], rtol=1e-5, err_msg="hip step 0")          # a pure function of the inputs
+    for s in (1, 2):
+        spread = float(np.abs(members[:, s] - centre[s]).max())
+        assert abs(hip[s] - centre[s]) <= 3 * spread + BAR * abs(centre[s]), \
+            f"step {s}: hip {hip[s]:.6f}, fp64 {centre[s]:.6f}, fp32 ensemble {members[:, s].tolist()} (spread {spread:.2e})"
 
 
 # ---------------------------------------------------------------------------------------------------------------------

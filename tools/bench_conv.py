@@ -1,69 +1,128 @@
-"""Per-layer-shape timing of the conv kernels (ResNet-50 @224, given batch): TFLOP/s for fwd / dgrad / wgrad."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from ssv_amd import ops
+#!/usr/bin/env python3
+"""Per-layer table of the conv implicit-GEMM kernels on the ResNet-50 @224 shapes (all 53 convolutions, identical shapes merged):
+for forward, data gradient and weight gradient - the variant the training step really launches (statistics epilogue, fused input
+BatchNorm, gated epilogue), its time, TFLOP/s of algorithmic work, and how its grid quantises onto the chip
+(workgroups / (3 resident per CU x 256 CUs) = "waves of 768").
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    python tools/bench_conv.py [batch per view = 512] [repeats = 5] [out.csv]
+"""
+import csv
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ssv_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 REP = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+OUT = sys.argv[3] if len(sys.argv) > 3 else None
 dev = torch.device("cuda:0")
-shapes = []   # (name, H, W, C, K, R, stride, pad, count)
-shapes.append(("stem7x7", 224, 224, 3, 64, 7, 2, 3, 1))
-cin, h = 64, 56
-for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
-    for b in range(blocks):
-        s = stride if b == 0 else 1
-        shapes.append((f"l{planes}.{b}.c1", h, h, cin, planes, 1, 1, 0, 1))
-        shapes.append((f"l{planes}.{b}.c2", h, h, planes, planes, 3, s, 1, 1))
-        h2 = (h + 2 - 3) // s + 1
-        shapes.append((f"l{planes}.{b}.c3", h2, h2, planes, planes * 4, 1, 1, 0, 1))
-        if b == 0:
-            shapes.append((f"l{planes}.{b}.ds", h, h, cin, planes * 4, 1, s, 0, 1))
-        cin, h = planes * 4, h2
-# merge identical shapes
-uniq = {}
-for n, H, W, C, K, R, s, p, c in shapes:
-    key = (H, W, C, K, R, s, p)
-    if key in uniq:
-        uniq[key][1] += 1
-    else:
-        uniq[key] = [n, 1]
+
+
+def resnet50_shapes():
+    shapes = [("stem", 224, 3, 64, 7, 2, 3, "plain")]            # name, H, C, K, R, stride, pad, input kind
+    cin, h = 64, 56
+    for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for b in range(blocks):
+            s = stride if b == 0 else 1
+            shapes.append((f"p{planes}.{b}.conv1", h, cin, planes, 1, 1, 0, "plain"))
+            shapes.append((f"p{planes}.{b}.conv2", h, planes, planes, 3, s, 1, "lazy"))
+            h2 = (h + 2 - 3) // s + 1
+            shapes.append((f"p{planes}.{b}.conv3", h2, planes, planes * 4, 1, 1, 0, "lazy"))
+            if b == 0:
+                shapes.append((f"p{planes}.{b}.downsample", h, cin, planes * 4, 1, s, 0, "plain"))
+            cin, h = planes * 4, h2
+    uniq = {}
+    for n, H, C, K, R, s, p, kind in shapes:
+        key = (H, C, K, R, s, p, kind)
+        if key in uniq:
+            uniq[key][1] += 1
+        else:
+            uniq[key] = [n, 1]
+    return uniq
+
 
 def timeit(fn):
-    fn(); torch.cuda.synchronize()
+    fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(REP):
         fn()
-    e1.record(); torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
     return e0.elapsed_time(e1) / REP
 
-tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
-print(f"B={B}  {'layer':12s} {'HxW':>7s} {'C':>5s} {'K':>5s} R s  cnt | {'fwd ms':>8s} {'TF':>6s} | {'dgrad ms':>8s} {'TF':>6s} | {'wgrad ms':>8s} {'TF':>6s}")
-for (H, W, C, K, R, s, p), (name, cnt) in uniq.items():
-    x = torch.randn(B, H, W, C, device=dev)
-    w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+
+def grid_fwd(m, k):
+    return -(-m // 128) * -(-k // 128) if k >= 128 else -(-m // 256) * -(-k // 64)
+
+
+rows, tot = [], {}
+hdr = ["layer", "count", "HxW", "C", "K", "RxS", "stride", "GFLOP", "fwd_variant", "fwd_ms", "fwd_TF", "fwd_wgs", "fwd_waves768",
+       "dgrad_variant", "dgrad_ms", "dgrad_TF", "dgrad_wgs", "wgrad_variant", "wgrad_ms", "wgrad_TF"]
+print(f"ResNet-50 @224, batch {B} per view, {REP} repeats")
+print(" ".join(f"{h:>13s}" for h in hdr))
+for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
+    if C == 3:
+        x = ops.pad_channels(torch.randn(B, H, H, 3, device=dev), 4)
+        w = ops.pad_channels((torch.randn(K, 3, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)
+        Cx = 4
+    else:
+        x = torch.randn(B, H, H, C, device=dev)
+        w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+        Cx = C
     y = ops.conv2d_fwd(x, w, s, p)
+    Ho = y.shape[1]
+    m = B * Ho * Ho
+    flop = 2.0 * y.numel() * C * R * R                        # algorithmic: the 3 real channels for the stem
     dy = torch.randn_like(y)
     dw = torch.zeros_like(w)
-    flop = 2.0 * y.numel() * C * R * R
-    t_f = timeit(lambda: ops.conv2d_fwd(x, w, s, p))
-    t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, s, p, accumulate=True))
-    if C % 4 == 0 and K % 16 == 0:
-        t_d = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, s, p))
+    aff = (torch.rand(Cx, device=dev) + 0.5, torch.randn(Cx, device=dev) * 0.1)
+    stats_ok = Cx % 32 == 0 and K % 4 == 0
+    if kind == "lazy" and ops.can_fuse_conv_input(Cx, K):
+        fv = "stats+bn_in"
+        t_f = timeit(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True))
+        wv = "bn_in"
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, s, p, accumulate=True, in_affine=aff))
     else:
-        t_d = float("nan")
+        fv = "stats" if stats_ok else ("c4" if Cx == 4 else "plain")
+        t_f = timeit((lambda: ops.conv2d_fwd_stats(x, w, s, p)) if stats_ok else (lambda: ops.conv2d_fwd(x, w, s, p)))
+        wv = "plain"
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, s, p, accumulate=True))
+    if C == 3:
+        dv, t_d, dwgs = "-", float("nan"), 0
+    else:
+        # the data gradient feeds a BatchNorm backward: gated epilogue (recomputed gate for the fused chain, byte mask for a unit output)
+        gx = torch.randn_like(x)
+        mean, invstd = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
+        if kind == "lazy":
+            gate = ops.BnGateCtx(gx, mean, invstd, scale=aff[0], shift=aff[1])
+        else:
+            gate = ops.BnGateCtx(gx, mean, invstd, mask=torch.randint(0, 16, (x.numel() // 4,), device=dev, dtype=torch.uint8))
+        addend = torch.randn_like(x) if kind == "plain" else None
+        dv = ("fwd-kernel" if s == 1 else "dgrad-kernel") + "+gate" + ("+addend" if addend is not None else "")
+        t_d = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, s, p, addend=addend, gate=gate))
+        dwgs = grid_fwd(B * H * H, C) if s == 1 else s * s * grid_fwd(B * (-(-H // s)) ** 2, C)
     tf = lambda t: flop / (t * 1e-3) / 1e12
-    t_df = float("nan")
-    if s == 1 and C % 4 == 0 and K % 16 == 0:      # stride 1: dgrad == forward convolution of dy with the transposed, 180-degree rotated filter
-        wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)      # [C, K, R, R] in OHWI memory
-        ref = ops.conv2d_dgrad(dy, w, x.shape, s, p)
-        alt = ops.conv2d_fwd(dy, wt, 1, R - 1 - p)
-        assert alt.shape == ref.shape and float((alt - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-6
-        t_df = timeit(lambda: ops.conv2d_fwd(dy, wt, 1, R - 1 - p))
-    print(f"      {name:12s} {H:3d}x{W:<3d} {C:5d} {K:5d} {R} {s} {cnt:4d} | {t_f:8.3f} {tf(t_f):6.1f} | {t_d:8.3f} {tf(t_d):6.1f} | {t_w:8.3f} {tf(t_w):6.1f} | dgrad-as-fwd {t_df:8.3f} {tf(t_df):6.1f}")
+    wgs = grid_fwd(m, K)
+    row = [name, cnt, f"{H}x{H}", C, K, f"{R}x{R}", s, round(flop / 1e9, 1), fv, round(t_f, 3), round(tf(t_f), 1), wgs, round(wgs / 768, 2),
+           dv, round(t_d, 3), round(tf(t_d), 1) if t_d == t_d else "", dwgs, wv, round(t_w, 3), round(tf(t_w), 1)]
+    rows.append(row)
+    print(" ".join(f"{str(v):>13s}" for v in row), flush=True)
     for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
         if t == t:
-            tot[k][0] += t * cnt; tot[k][1] += flop * cnt
+            a = tot.setdefault(k, [0.0, 0.0])
+            a[0] += t * cnt
+            a[1] += flop * cnt
+    del x, y, dy, w, dw
 for k, (t, f) in tot.items():
-    print(f"total {k:6s}: {t:8.2f} ms  {f / (t * 1e-3) / 1e12:6.1f} TF")
+    print(f"total {k:6s}: {t:8.2f} ms per view  {f / (t * 1e-3) / 1e12:6.1f} TFLOP/s")
+    rows.append([f"TOTAL {k}", "", "", "", "", "", "", round(f / 1e9, 1), "", round(t, 2), round(f / (t * 1e-3) / 1e12, 1)] + [""] * 9)
+if OUT:
+    with open(OUT, "w", newline="") as fh:
+        wtr = csv.writer(fh)
+        wtr.writerow(hdr)
+        wtr.writerows(rows)
