@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Aggregate a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass (--output-format csv) into matrix-pipe
+utilisation per kernel class of one training step.
+
+    pmc_mfma.py <counter_collection.csv> <steps in the run> <out.json> [algorithmic GFLOP per step of the conv family]
+
+Per dispatch rocprofv3 reports the counters summed over their instances:
+  * SQ_VALU_MFMA_BUSY_CYCLES - cycles the MFMA pipe of a SIMD is busy, summed over all 1024 SIMDs (256 CUs x 4).  One
+    v_mfma_f32_32x32x2_f32 holds its SIMD's pipe for 64 cycles and does 4096 FLOP, so EXECUTED FLOP = 64 x busy cycles: the file also
+    gives executed vs algorithmic FLOP (tile padding, the stem's 4th channel, dense ResNeXt groups show up here);
+  * GRBM_GUI_ACTIVE - GPU-active cycles summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS section): kernel cycles = value / 8;
+  * mfma_busy_frac = MFMA busy / (kernel cycles x 1024 SIMDs): the fraction of all matrix-pipe cycles of the chip that did MFMA work
+    while the kernel ran (MfmaUtil of counter_defs.yaml); SQ_BUSY_CYCLES is kept as reported for reference.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+from pmc_traffic import classify
+
+SIMDS, XCDS = 1024, 8
+
+
+def main():
+    path, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    algo_gflop = float(sys.argv[4]) if len(sys.argv) > 4 else None
+    per = defaultdict(lambda: defaultdict(float))
+    launches = defaultdict(set)
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            c = classify(row["Kernel_Name"])
+            per[c][row["Counter_Name"]] += float(row["Counter_Value"])
+            launches[c].add(row["Dispatch_Id"])
+    res = {}
+    for c, v in sorted(per.items()):
+        busy, gui, sq = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), v.get("GRBM_GUI_ACTIVE", 0.0), v.get("SQ_BUSY_CYCLES", 0.0)
+        cyc = gui / XCDS
+        res[c] = {"launches": len(launches[c]) // steps, "mfma_busy_cycles_per_step": round(busy / steps), "kernel_cycles_per_step": round(cyc / steps),
+                  "sq_busy_cycles_per_step": round(sq / steps), "mfma_busy_frac": round(busy / (cyc * SIMDS), 4) if cyc else None,
+                  "executed_gflop_per_step": round(64.0 * busy / steps / 1e9, 1)}
+    conv = [res[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in res]
+    summary = {}
+    if conv:
+        busy = sum(r["mfma_busy_cycles_per_step"] for r in conv)
+        cyc = sum(r["kernel_cycles_per_step"] for r in conv)
+        summary = {"conv_family_mfma_busy_frac": round(busy / (cyc * SIMDS), 4), "conv_family_executed_gflop_per_step": round(64.0 * busy / 1e9, 1)}
+        if algo_gflop:
+            summary["conv_family_algorithmic_gflop_per_step"] = algo_gflop
+            summary["executed_over_algorithmic"] = round(64.0 * busy / 1e9 / algo_gflop, 3)
+        total_cyc = sum(r["kernel_cycles_per_step"] for r in res.values())
+        summary["whole_step_mfma_busy_frac"] = round(sum(r["mfma_busy_cycles_per_step"] for r in res.values()) / (total_cyc * SIMDS), 4)
+    json.dump({"normalisation": "MFMA busy cycles (sum over SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); executed FLOP = 64 x busy cycles (fp32 32x32x2: 64 cycles, 4096 FLOP)",
+               "steps_in_run": steps, "summary": summary, "per_class": res}, open(out, "w"), indent=1)
+    print(json.dumps({"summary": summary, "per_class": res}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
