@@ -198,6 +198,15 @@ int ssv_ntxent_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const
 int ssv_ntxent_loss(int32_t rows, const float* lse, const float* pos, float scale, float* loss, void* stream);
 int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
                    const float* lse_all, float inv_temp, float gscale, float* dZ, void* stream);
+/* The same loss for projection widths beyond the register-resident kernels (ldz > 128; the reference accepts any D): the host forms the
+ * Gram block S[2*Bloc][lds] = Z_loc . Z_all^T with ssv_conv2d_fwd (lds = 2*Nglob rounded up to 16, pad columns are products with zero
+ * rows), ssv_ntxent_gram_fwd reads lse / pos off it, ssv_ntxent_gram_weights turns it IN PLACE into
+ * W'[r][c] = gscale * (e^{S_rc-lse_r} + e^{S_rc-lse_c} - 2 [c = pos(r)]) (0 on the diagonal and the pad), and dZ = W' . Z_all is
+ * ssv_conv2d_dgrad - two GEMMs on the MFMA kernels, no width limit. */
+int ssv_ntxent_gram_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t lds, const float* S, float inv_temp,
+                        float* lse, float* pos, void* stream);
+int ssv_ntxent_gram_weights(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t lds, float* S, const float* lse_all,
+                            float inv_temp, float gscale, void* stream);
 
 /* ---- BYOL loss: nn.MSELoss pair models/byol.py:89,129-130 on [B][D] matrices ---------------
  * loss = (sum (o1-t2)^2 + sum (o2-t1)^2) / (B*D); do1 = 2*(o1-t2)*gscale, do2 likewise. */
@@ -366,7 +375,11 @@ int ssv_sgd(int64_t n, float* p, const float* g, float* buf, float lr, float wei
 
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -------
  * classes: see SSV_PROF_* ; when enabled every entry point brackets its launches with an
- * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device). */
+ * event pair on `stream`.  ssv_prof_collect synchronises the events (not the device).
+ * Threading: this is the library's only process-wide mutable state besides the thread-local error string.  It is OFF by default (an
+ * entry point then pays one relaxed atomic load); when on, the record list is guarded by a mutex and a launch's begin / end pair is
+ * matched through a thread-local slot, so host threads driving different streams may call concurrently.  The library reads no
+ * environment variables and keeps no other state between calls. */
 enum { SSV_PROF_CONV_FWD = 0, SSV_PROF_CONV_DGRAD, SSV_PROF_CONV_WGRAD, SSV_PROF_BN_FWD, SSV_PROF_BN_BWD,
        SSV_PROF_POOL, SSV_PROF_LOSS, SSV_PROF_OPTIM, SSV_PROF_AUG, SSV_PROF_MISC, SSV_PROF_ATTN, SSV_PROF_NORM, SSV_PROF_NCLASS };
 int ssv_prof_enable(int on);

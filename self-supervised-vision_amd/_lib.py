@@ -77,6 +77,8 @@ SIGNATURES = {
     "ssv_ntxent_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
     "ssv_ntxent_loss": (C.c_int, [_i32, _vp, _vp, _f32, _vp, _vp]),
     "ssv_ntxent_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "ssv_ntxent_gram_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
+    "ssv_ntxent_gram_weights": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp]),
     "ssv_reduce_workspace_bytes": (_sz, [_i64]),
     "ssv_mse_pair_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_scale": (C.c_int, [_i64, _vp, _vp, _vp]),

@@ -336,6 +336,62 @@ extern "C" int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t
   return SSV_OK;
 }
 
+// ---- NT-Xent for projection widths beyond the register-resident kernels (ldz > 128): the Gram block S = Z_loc Z_all^T comes from the
+//      GEMM kernel (ssv_conv2d_fwd, written to memory), these two kernels do the row work, and dZ = W' Z is a GEMM again. ----------
+namespace {
+// one wavefront per local row: lse over the columns c != r, and the positive logit
+__global__ void __launch_bounds__(256)
+ntxent_gram_rows_k(int Nglob, int Bloc, int seg0, int lds, const float* __restrict__ S, float inv_temp, float* __restrict__ lse, float* __restrict__ pos) {
+  const int lane = threadIdx.x & 63, lr = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (lr >= 2 * Bloc) return;
+  const int R2 = 2 * Nglob, rg = global_row(lr, Bloc, Nglob, seg0), pg = rg < Nglob ? rg + Nglob : rg - Nglob;
+  const float* row = S + (size_t)lr * lds;
+  float m = -INFINITY;
+  for (int c = lane; c < R2; c += 64) if (c != rg) m = fmaxf(m, row[c] * inv_temp);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < R2; c += 64) if (c != rg) sum += expf(row[c] * inv_temp - m);
+  sum = wave_sum(sum);
+  if (lane == 0) { lse[lr] = m + logf(sum); pos[lr] = row[pg] * inv_temp; }
+}
+// in place: S[lr][c] <- gscale * (e^{s - lse_r} + e^{s - lse_c} - 2 [c == pos(r)]) for c != r, 0 on the diagonal and on the pad columns
+__global__ void __launch_bounds__(256)
+ntxent_gram_weights_k(int Nglob, int Bloc, int seg0, int lds, float* __restrict__ S, const float* __restrict__ lse_all, float inv_temp, float gscale) {
+  const int lr = blockIdx.y;
+  const int R2 = 2 * Nglob, rg = global_row(lr, Bloc, Nglob, seg0), pg = rg < Nglob ? rg + Nglob : rg - Nglob;
+  const float lse_r = lse_all[rg];
+  float* row = S + (size_t)lr * lds;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < lds; c += gridDim.x * 256) {
+    float w = 0.f;
+    if (c < R2 && c != rg) {
+      const float sv = row[c] * inv_temp;
+      w = gscale * (expf(sv - lse_r) + expf(sv - lse_all[c]) - (c == pg ? 2.f : 0.f));
+    }
+    row[c] = w;
+  }
+}
+}  // namespace
+
+extern "C" int ssv_ntxent_gram_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t lds, const float* S, float inv_temp,
+                                   float* lse, float* pos, void* stream) {
+  SSV_REQUIRE(Nglob > 0 && Bloc > 0 && seg0 >= 0 && seg0 + Bloc <= Nglob && lds >= 2 * Nglob && S && lse && pos, "ssv_ntxent_gram_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  hipLaunchKernelGGL(ntxent_gram_rows_k, dim3(cdiv(2 * Bloc, 4)), dim3(256), 0, s, Nglob, Bloc, seg0, lds, S, inv_temp, lse, pos);
+  SSV_CHECK_LAUNCH("ssv_ntxent_gram_fwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_gram_weights(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t lds, float* S, const float* lse_all,
+                                       float inv_temp, float gscale, void* stream) {
+  SSV_REQUIRE(Nglob > 0 && Bloc > 0 && seg0 >= 0 && seg0 + Bloc <= Nglob && lds >= 2 * Nglob && S && lse_all && 2 * Bloc <= 65535, "ssv_ntxent_gram_weights: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_LOSS, s);
+  hipLaunchKernelGGL(ntxent_gram_weights_k, dim3(min(cdiv(lds, 256), 64), 2 * Bloc), dim3(256), 0, s, Nglob, Bloc, seg0, lds, S, lse_all, inv_temp, gscale);
+  SSV_CHECK_LAUNCH("ssv_ntxent_gram_weights");
+  return SSV_OK;
+}
+
 extern "C" size_t ssv_reduce_workspace_bytes(int64_t n) { return (size_t)reduce_blocks(n) * sizeof(double); }
 
 extern "C" int ssv_mse_pair_fwd_bwd(int64_t n, const float* o1, const float* o2, const float* t1, const float* t2,

@@ -1,5 +1,7 @@
 // Library runtime: error string, version, per-class HIP-event timing, fill.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include <string.h>
 
@@ -23,14 +25,19 @@ extern "C" int ssv_device_cus(void) {
 }
 
 // ---- profiling ------------------------------------------------------------------------------
+// The ONLY process-wide mutable state of the library besides the thread-local error string, and off by default: when disabled an
+// entry point pays one relaxed atomic load.  When enabled, the record list is guarded by a mutex, and the begin / end pair of one
+// launch is matched through a thread-local slot, so concurrent callers (one host thread per stream) do not corrupt each other.
 struct ProfRec { int cls; hipEvent_t a, b; };
-static bool g_prof_on = false;
-static std::vector<ProfRec> g_recs;          // records of the current collection window
-static std::vector<ProfRec> g_free;          // recycled event pairs
-static int g_open = -1;
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_recs;          // records of the current collection window (under g_prof_mu)
+static std::vector<ProfRec> g_free;          // recycled event pairs (under g_prof_mu)
+static thread_local int g_open = -1;         // index of this thread's record between begin and end
 
 void ssv_prof_begin(int cls, hipStream_t s) {
-  if (!g_prof_on) return;
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   ProfRec r;
   if (!g_free.empty()) { r = g_free.back(); g_free.pop_back(); }
   else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
@@ -40,18 +47,26 @@ void ssv_prof_begin(int cls, hipStream_t s) {
   g_open = (int)g_recs.size() - 1;
 }
 void ssv_prof_end(int cls, hipStream_t s) {
-  if (!g_prof_on || g_open < 0) return;
+  if (g_open < 0) return;
   (void)cls;
-  (void)hipEventRecord(g_recs[g_open].b, s);
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (g_open < (int)g_recs.size()) (void)hipEventRecord(g_recs[g_open].b, s);
   g_open = -1;
 }
-extern "C" int ssv_prof_enable(int on) { g_prof_on = on != 0; return SSV_OK; }
-extern "C" int ssv_prof_reset(void) {
+extern "C" int ssv_prof_enable(int on) { g_prof_on.store(on != 0, std::memory_order_relaxed); return SSV_OK; }
+static int prof_reset_locked() {
   for (auto& r : g_recs) g_free.push_back(r);
-  g_recs.clear(); g_open = -1;
+  g_recs.clear();
   return SSV_OK;
 }
+extern "C" int ssv_prof_reset(void) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  g_open = -1;
+  return prof_reset_locked();
+}
 extern "C" int ssv_prof_collect(double* ms, int64_t* n) {
+  SSV_REQUIRE(ms && n, "ssv_prof_collect: null pointer");
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   for (int i = 0; i < SSV_PROF_NCLASS; ++i) { ms[i] = 0.0; n[i] = 0; }
   for (auto& r : g_recs) {
     if (hipEventSynchronize(r.b) != hipSuccess) SSV_FAIL(SSV_ERR_LAUNCH, "prof: event sync failed");
@@ -59,7 +74,8 @@ extern "C" int ssv_prof_collect(double* ms, int64_t* n) {
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) SSV_FAIL(SSV_ERR_LAUNCH, "prof: elapsed failed");
     ms[r.cls] += t; n[r.cls] += 1;
   }
-  return ssv_prof_reset();
+  g_open = -1;
+  return prof_reset_locked();
 }
 
 // ---- fill -----------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 [O,I,H,W] tensors in channels_last memory format (= OHWI in memory).  Every function only enqueues
 kernels on the current HIP stream; torch provides allocation, nothing else."""
 import ctypes as C
+import math
 
 import torch
 
@@ -36,12 +37,40 @@ def _ohwi(w):
     return w, tuple(w.shape)
 
 
+# The conv kernels address every tensor through a buffer descriptor with a non-negative 32-bit byte offset, so one launch handles
+# tensors below 2 GiB (check_desc in csrc/conv_mfma.hip).  Larger batches are split along N HERE: NHWC tensors are contiguous per
+# sample, a chunk is a plain sub-range of every operand, and each chunk is its own launch on the same stream.
+_MAX_ELEMS = (1 << 29) - (1 << 22)
+
+
+def _batch_chunks(n, per_sample_elems, rows_per_sample=None):
+    """[(n0, n1)] such that every chunk keeps all tensors below the per-launch limit.  ``rows_per_sample`` (output rows per sample):
+    chunk rows are kept a multiple of 64 so that the 64-row statistics partials of the chunks concatenate to exactly the partials of
+    the unsplit launch."""
+    worst = max(per_sample_elems)
+    if n * worst < _MAX_ELEMS:
+        return [(0, n)]
+    nc = (_MAX_ELEMS - 1) // worst
+    if rows_per_sample is not None:
+        q = 64 // math.gcd(rows_per_sample, 64)
+        nc = nc // q * q
+    if nc < 1:
+        raise _lib.SsvError("a single sample exceeds the 2 GiB per-launch tensor limit of the convolution kernels")
+    return [(s0, min(s0 + nc, n)) for s0 in range(0, n, nc)]
+
+
+def _sub(t, n0, n1):
+    return None if t is None else t[n0:n1]
+
+
 def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None):
     _lib._dev(x, w, bias, addend)
     w, wshape = _ohwi(w)
     d = conv_desc(x.shape, wshape, stride, pad)
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
-    call("ssv_conv2d_fwd", C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(addend), ptr(y), stream())
+    for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K)):
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad)
+        call("ssv_conv2d_fwd", C.byref(dc), ptr(x[n0:n1]), ptr(w), ptr(bias), ptr(_sub(addend, n0, n1)), ptr(y[n0:n1]), stream())
     return y
 
 
@@ -49,14 +78,10 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
     """y = conv(x, w) plus the BatchNorm statistics partials of y from the same epilogue: (y, pmean, pm2) with one partial per
     64 output rows.  Returns None when the shape is outside the fused kernel's preconditions (C % 32, K % 4)."""
     _lib._dev(x, w)
-    w, wshape = _ohwi(w)
+    _, wshape = _ohwi(w)
     if wshape[1] % 32 or wshape[0] % 4:
         return None
-    d = conv_desc(x.shape, wshape, stride, pad)
-    y = _empty((d.N, d.Ho, d.Wo, d.K), x)
-    groups = int(_lib.load().ssv_conv2d_fwd_stats_groups(C.byref(d)))
-    part = _empty((2, groups, d.K), x)
-    call("ssv_conv2d_fwd_stats", C.byref(d), ptr(x), ptr(w), ptr(y), ptr(part[0]), ptr(part[1]), stream())
+    y, part = conv2d_fwd_fused(x, w, stride, pad, in_affine=None, want_stats=True)
     return y, part[0], part[1]
 
 
@@ -67,14 +92,20 @@ def conv2d_fwd_fused(x, w, stride=1, pad=0, in_affine=None, want_stats=True):
     _lib._dev(x, w)
     w, wshape = _ohwi(w)
     d = conv_desc(x.shape, wshape, stride, pad)
+    if in_affine is None and not want_stats:
+        return conv2d_fwd(x, w, stride, pad), None
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
-    part = None
-    if want_stats:
-        groups = int(_lib.load().ssv_conv2d_fwd_stats_groups(C.byref(d)))
-        part = _empty((2, groups, d.K), x)
+    lib = _lib.load()
+    groups = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(d)))
+    part = _empty((2, groups, d.K), x) if want_stats else None
     sc, sh = in_affine if in_affine is not None else (None, None)
-    call("ssv_conv2d_fwd_bnrelu_in_stats", C.byref(d), ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(y),
-         ptr(part[0]) if want_stats else None, ptr(part[1]) if want_stats else None, stream())
+    g0 = 0
+    for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo if want_stats else None):
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad)
+        gc = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(dc)))
+        call("ssv_conv2d_fwd_bnrelu_in_stats", C.byref(dc), ptr(x[n0:n1]), ptr(sc), ptr(sh), ptr(w), ptr(y[n0:n1]),
+             ptr(part[0][g0:g0 + gc]) if want_stats else None, ptr(part[1][g0:g0 + gc]) if want_stats else None, stream())
+        g0 += gc
     return y, (None if part is None else (part[0], part[1]))
 
 
@@ -121,6 +152,11 @@ def _gate_struct(gate, groups, channels, like):
     return st, part
 
 
+def _gate_sub(gate, n0, n1):
+    return BnGateCtx(gate.x[n0:n1], gate.mean, gate.invstd, mask=None if gate.mask is None else gate.mask[n0 * gate.x[0].numel() // 4:n1 * gate.x[0].numel() // 4],
+                     scale=gate.scale, shift=gate.shift)
+
+
 def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=None):
     """dx = conv_transpose(dy, w) (+ addend).  Stride-1 layers (every Linear, every 1x1 and 3x3 stride-1 convolution) are computed
     as the FORWARD convolution of dy with the transposed, 180-degree rotated filter: both GEMM operands are then k-contiguous
@@ -135,27 +171,39 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     dx.__dict__.pop("_gate_partials", None)            # an accumulated-into buffer never keeps the partial sums of its old content
     if gate is not None and (k % 32 or c % 4 or tuple(gate.x.shape) != tuple(dx.shape)):
         gate = None
-    if stride == 1 and r == s_ and r - 1 - pad >= 0 and k % 16 == 0 and c % 4 == 0:
-        wt = _transposed_filter(w, wshape)
-        d = conv_desc(dy.shape, (c, k, r, s_), 1, r - 1 - pad)
-        if (d.Ho, d.Wo) != (x_shape[1], x_shape[2]):
-            raise _lib.SsvError("conv2d_dgrad: input shape does not match the stride-1 geometry")
-        if gate is not None:
-            groups = int(_lib.load().ssv_conv2d_fwd_gate_groups(C.byref(d)))
-            st, part = _gate_struct(gate, groups, c, dy)
-            call("ssv_conv2d_fwd_gated", C.byref(d), ptr(dy), ptr(wt), ptr(addend), ptr(dx), C.byref(st), stream())
-            dx._gate_partials = (part[0], part[1], groups)
-            return dx
-        call("ssv_conv2d_fwd", C.byref(d), ptr(dy), ptr(wt), None, ptr(addend), ptr(dx), stream())
-        return dx
-    d = conv_desc(x_shape, wshape, stride, pad)
-    if gate is not None and stride <= 8:
-        groups = int(_lib.load().ssv_conv2d_dgrad_gate_groups(C.byref(d)))
-        st, part = _gate_struct(gate, groups, c, dy)
-        call("ssv_conv2d_dgrad_gated", C.byref(d), ptr(dy), ptr(w), ptr(addend), ptr(dx), C.byref(st), stream())
-        dx._gate_partials = (part[0], part[1], groups)
-        return dx
-    call("ssv_conv2d_dgrad", C.byref(d), ptr(dy), ptr(w), ptr(addend), ptr(dx), stream())
+    lib = _lib.load()
+    n = dy.shape[0]
+    chunks = _batch_chunks(n, (dy[0].numel(), dx[0].numel()))
+    as_fwd = stride == 1 and r == s_ and r - 1 - pad >= 0 and k % 16 == 0 and c % 4 == 0
+    if gate is not None and not as_fwd and stride > 8:
+        gate = None
+    wt = _transposed_filter(w, wshape) if as_fwd else None
+    parts = []
+    for n0, n1 in chunks:
+        dyc, dxc, adc = dy[n0:n1], dx[n0:n1], _sub(addend, n0, n1)
+        if as_fwd:
+            d = conv_desc(dyc.shape, (c, k, r, s_), 1, r - 1 - pad)
+            if (d.Ho, d.Wo) != (x_shape[1], x_shape[2]):
+                raise _lib.SsvError("conv2d_dgrad: input shape does not match the stride-1 geometry")
+            if gate is not None:
+                groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))
+                st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
+                call("ssv_conv2d_fwd_gated", C.byref(d), ptr(dyc), ptr(wt), ptr(adc), ptr(dxc), C.byref(st), stream())
+                parts.append(part)
+            else:
+                call("ssv_conv2d_fwd", C.byref(d), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
+        else:
+            d = conv_desc(dxc.shape, wshape, stride, pad)
+            if gate is not None:
+                groups = int(lib.ssv_conv2d_dgrad_gate_groups(C.byref(d)))
+                st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
+                call("ssv_conv2d_dgrad_gated", C.byref(d), ptr(dyc), ptr(w), ptr(adc), ptr(dxc), C.byref(st), stream())
+                parts.append(part)
+            else:
+                call("ssv_conv2d_dgrad", C.byref(d), ptr(dyc), ptr(w), ptr(adc), ptr(dxc), stream())
+    if parts:
+        part = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)      # partial SUMS: any grouping of the rows adds up the same
+        dx._gate_partials = (part[0], part[1], part.shape[1])
     return dx
 
 
@@ -164,14 +212,13 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=
     the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation)."""
     _lib._dev(x, dy, dw)
     _, wshape = _ohwi(w_like)
-    d = conv_desc(x.shape, wshape, stride, pad)
-    nbytes = _lib.load().ssv_conv2d_wgrad_workspace_bytes(C.byref(d))
-    ws = workspace.get(nbytes, x.device)
-    if in_affine is not None:
-        call("ssv_conv2d_wgrad_bnrelu_in", C.byref(d), ptr(x), ptr(in_affine[0]), ptr(in_affine[1]), ptr(dy), ptr(dw), int(accumulate),
-             ptr(ws), ws.numel(), stream())
-        return dw
-    call("ssv_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), int(accumulate), ptr(ws), ws.numel(), stream())
+    lib = _lib.load()
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    for i, (n0, n1) in enumerate(_batch_chunks(x.shape[0], (x[0].numel(), dy[0].numel()))):
+        xc, dyc = x[n0:n1], dy[n0:n1]
+        d = conv_desc(xc.shape, wshape, stride, pad)
+        ws = workspace.get(lib.ssv_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
+        call("ssv_conv2d_wgrad_bnrelu_in", C.byref(d), ptr(xc), ptr(sc), ptr(sh), ptr(dyc), ptr(dw), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
     return dw
 
 
@@ -354,6 +401,21 @@ def ntxent_fwd(zall, nglob, b, seg0, inv_temp):
     pos = _empty((2 * b,), zall)
     call("ssv_ntxent_fwd", nglob, b, seg0, zall.shape[1], ptr(zall), float(inv_temp), ptr(lse), ptr(pos), stream())
     return lse, pos
+
+
+def ntxent_gram_fwd(gram, nglob, b, seg0, inv_temp):
+    """(lse, pos) of this rank's 2*b rows from the materialised Gram block [2*b, lds] (wide embeddings)."""
+    _lib._dev(gram)
+    lse, pos = _empty((2 * b,), gram), _empty((2 * b,), gram)
+    call("ssv_ntxent_gram_fwd", nglob, b, seg0, gram.shape[1], ptr(gram), float(inv_temp), ptr(lse), ptr(pos), stream())
+    return lse, pos
+
+
+def ntxent_gram_weights(gram, lse_all, nglob, b, seg0, inv_temp, gscale):
+    """In place: the Gram block becomes the weight matrix W' whose product with Z_all is dZ."""
+    _lib._dev(gram, lse_all)
+    call("ssv_ntxent_gram_weights", nglob, b, seg0, gram.shape[1], ptr(gram), ptr(lse_all), float(inv_temp), float(gscale), stream())
+    return gram
 
 
 def ntxent_loss(lse, pos, scale):

@@ -26,18 +26,26 @@ class _NTXentFn(torch.autograd.Function):
     def forward(ctx, zi, zj, normalize, temperature):
         b, d = zi.shape
         ld = _pad32(d)
-        if ld > 128:
-            raise _lib.SsvError(f"SimclrLoss: projection dim {d} > 128 is not supported by the register-resident NT-Xent kernel yet")
+        wide = ld > 128                  # beyond the register-resident kernels: Gram block through the GEMM kernels (any width)
         world, rank = hdist.world_size(), hdist.rank()
         nglob, seg0 = b * world, b * rank
-        zall = torch.empty((2 * nglob, ld), dtype=torch.float32, device=zi.device)
+        rows = (2 * nglob + 15) // 16 * 16 if wide else 2 * nglob          # wide: the row count is a GEMM dimension (multiple of 16)
+        zall = torch.empty((rows, ld), dtype=torch.float32, device=zi.device)
+        if rows > 2 * nglob:
+            ops.fill_(zall[2 * nglob:], 0.0)
         _, inv_i = ops.l2norm_fwd(zi.detach().contiguous(), normalize, ld, out=zall[seg0:seg0 + b])
         _, inv_j = ops.l2norm_fwd(zj.detach().contiguous(), normalize, ld, out=zall[nglob + seg0:nglob + seg0 + b])
         if world > 1:
             hdist.all_gather_rows(zall[:nglob], b)
-            hdist.all_gather_rows(zall[nglob:], b)
+            hdist.all_gather_rows(zall[nglob:2 * nglob], b)
         inv_t = 1.0 / float(temperature)
-        lse_loc, pos_loc = ops.ntxent_fwd(zall, nglob, b, seg0, inv_t)
+        gram = None
+        if wide:
+            zloc = torch.cat((zall[seg0:seg0 + b], zall[nglob + seg0:nglob + seg0 + b]), 0)
+            gram = ops.conv2d_fwd(zloc.view(2 * b, 1, 1, ld), zall).view(2 * b, rows)          # S = Z_loc Z_all^T on the MFMA GEMM
+            lse_loc, pos_loc = ops.ntxent_gram_fwd(gram, nglob, b, seg0, inv_t)
+        else:
+            lse_loc, pos_loc = ops.ntxent_fwd(zall, nglob, b, seg0, inv_t)
         loss = ops.ntxent_loss(lse_loc, pos_loc, 1.0 / (2 * nglob))
         if world > 1:
             hdist.all_reduce_sum(loss)                       # every rank returns the global-batch loss
@@ -48,13 +56,17 @@ class _NTXentFn(torch.autograd.Function):
             hdist.all_gather_rows(lse_all[nglob:], b)
         else:
             lse_all = lse_loc
-        ctx.saved = (zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, bool(normalize))
+        ctx.saved = (zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, bool(normalize), gram)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, normalize = ctx.saved
-        dzall = ops.ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_t, inv_t / (2 * nglob))
+        zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, normalize, gram = ctx.saved
+        if gram is not None:             # wide embeddings: W' in place over the Gram block, then dZ = W' Z_all as a GEMM
+            ops.ntxent_gram_weights(gram, lse_all, nglob, b, seg0, inv_t, inv_t / (2 * nglob))
+            dzall = ops.conv2d_dgrad(gram.view(2 * b, 1, 1, -1), zall, (2 * b, 1, 1, zall.shape[1])).view(2 * b, zall.shape[1])
+        else:
+            dzall = ops.ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_t, inv_t / (2 * nglob))
         ops.scale_(dzall, dloss.contiguous())                # chain rule with the upstream scalar, read on the device
         dzi = ops.l2norm_bwd(zall[seg0:seg0 + b], inv_i, dzall[:b], d, normalize)
         dzj = ops.l2norm_bwd(zall[nglob + seg0:nglob + seg0 + b], inv_j, dzall[b:], d, normalize)

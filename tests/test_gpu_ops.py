@@ -418,3 +418,56 @@ def test_stem_conv_with_channels_padded_to_four(dev, n, h, k, r, stride, pad):
     ops.unpad_channels(dwp.permute(0, 2, 3, 1), dw3, accumulate=True)
     np.testing.assert_allclose(dw3.cpu().double().numpy() - 1.0, wr.grad.permute(0, 2, 3, 1).numpy(), rtol=2e-4, atol=2e-4)
     assert float(dwp.permute(0, 2, 3, 1)[..., 3].abs().max()) == 0.0                    # the padded input channel is all zeros
+
+
+@pytest.mark.parametrize("n,d,norm,temp", [(24, 256, True, 0.5), (21, 200, True, 0.2), (40, 512, False, 1.0)])
+def test_ntxent_wide_embeddings_run_through_the_gemm_kernels(dev, n, d, norm, temp):
+    """proj_dim > 128 (the reference's SimclrLoss takes any D): the Gram block comes from the MFMA GEMM kernel, lse / weights from
+    the row kernels, dZ from a second GEMM - against the oracle, with a non-unit upstream gradient and a row count (2N = 42) that is
+    padded to the GEMM's multiple of 16."""
+    from ssv_amd.utils import losses
+    zi, zj = seeded_randn(91, n, d) * (1.0 if norm else 0.2), seeded_randn(92, n, d) * (1.0 if norm else 0.2)
+    a, b = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+    ref = oracle.ntxent_loss(a, b, norm, temp)
+    (ref * 1.7).backward()
+    zid, zjd = zi.to(dev).requires_grad_(), zj.to(dev).requires_grad_()
+    loss = losses.SimclrLoss(norm, temp)(zid, zjd)
+    (loss * 1.7).backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=5e-6)
+    close(zid.grad, a.grad, rtol=2e-4, what="dzi")
+    close(zjd.grad, b.grad, rtol=2e-4, what="dzj")
+
+
+def test_batches_beyond_the_per_launch_limit_are_split_on_the_host(dev, monkeypatch):
+    """The conv kernels address a tensor through 32-bit byte offsets (< 2 GiB per launch); ops.* split larger batches along N.  With
+    the limit lowered to a few thousand elements every path splits: forward (+ statistics partials, + fused input), data gradient
+    (+ gate), weight gradient.  Forward, partials and the gated gradient are bit-identical to the unsplit launch (same per-row
+    arithmetic, 64-row partial groups aligned to the chunks); the weight gradient sums its chunks in a different order."""
+    from ssv_amd import ops
+    n, h, c, k = 24, 8, 32, 64
+    x = seeded_randn(11, n, h, h, c).to(dev)
+    w = (seeded_randn(12, k, c, 3, 3) * 0.1).contiguous(memory_format=torch.channels_last).to(dev)
+    aff = (torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1)
+    dy = seeded_randn(13, n, h, h, k).to(dev)
+    gx = seeded_randn(14, n, h, h, c).to(dev)
+    mean, invstd = torch.randn(c, device=dev) * 0.1, torch.rand(c, device=dev) + 0.5
+    mask = torch.randint(0, 16, (x.numel() // 4,), device=dev, dtype=torch.uint8)
+
+    def run():
+        y, part = ops.conv2d_fwd_fused(x, w, 1, 1, in_affine=aff, want_stats=True)
+        y2 = ops.conv2d_fwd(x, w, 1, 1)
+        dx = ops.conv2d_dgrad(dy, w, x.shape, 1, 1, addend=gx.clone(), gate=ops.BnGateCtx(gx, mean, invstd, mask=mask))
+        sums = (dx._gate_partials[0].sum(0), dx._gate_partials[1].sum(0))
+        dx2 = ops.conv2d_dgrad(dy, w, x.shape, 1, 1, gate=ops.BnGateCtx(gx, mean, invstd, scale=aff[0], shift=aff[1]))
+        dw = torch.zeros_like(w)
+        ops.conv2d_wgrad(x, dy, w, dw, 1, 1, accumulate=True, in_affine=aff)
+        return y, part[0], part[1], y2, dx.clone(), dx2.clone(), sums, dw
+    whole = run()
+    monkeypatch.setattr(ops, "_MAX_ELEMS", 8 * h * h * k + 1)          # 8 samples per launch -> 3 chunks of 8 (8*64 rows: multiple of 64)
+    assert len(ops._batch_chunks(n, (h * h * c, h * h * k), rows_per_sample=h * h)) == 3
+    split = run()
+    for i in (0, 1, 2, 3, 4, 5):
+        assert torch.equal(whole[i], split[i]), i
+    for a, b in zip(whole[6], split[6]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    close(split[7], whole[7], rtol=1e-5, what="wgrad over chunks")
