@@ -9,9 +9,17 @@ Batches keep the reference keys: index, img, aug_1, aug_2, label.
 Datasets: CIFAR-10/100 are read from the standard python pickles under ``root`` if they are
 already there (no download: the target boxes have no network); ``synthetic: {...}`` in the
 ``data`` block of the YAML generates a seeded uint8 dataset of the requested shape instead.
+
+A dataset that does not fit the HBM budget (``data.max_resident_gb``, default: everything resident) is STREAMED: it stays in pinned host
+memory as uint8, the epoch's permutation is cut into chunks of ``stream_chunk_batches`` steps, and a background thread gathers the next
+chunk's images (this rank's rows only) into a pinned staging buffer and uploads them on a side stream into the other half of a
+double-buffered device chunk while the current chunk trains.  Batches are bit-identical to the resident path (same permutation, same
+augmentation streams keyed by dataset index).  JPEG decoding is not part of this path: the dataset is decoded uint8 (as CIFAR's pickles
+are); an ImageNet-scale run feeds it a pre-decoded uint8 array.
 """
 import os
 import pickle
+import threading
 
 import numpy as np
 import torch
@@ -70,6 +78,17 @@ def _synthetic(spec, train, seed=420):
 DATASETS = ("cifar10", "cifar100")
 
 
+def _gather_rows(host, ids, out):
+    """out[i] = host[ids[i]] for uint8 image rows.  Viewed as int64 words when the row size allows it: index_select then moves 8 bytes
+    per element instead of 1 (measured 3.4x faster on the host)."""
+    n, m = host.shape[0], ids.numel()
+    row = host[0].numel()
+    if row % 8 == 0:
+        torch.index_select(host.view(n, row).view(torch.int64), 0, ids, out=out[:m].view(m, row).view(torch.int64))
+    else:
+        torch.index_select(host, 0, ids, out=out[:m])
+
+
 class GpuTwoViewLoader:
     """Iterates {index, img, aug_1, aug_2, label} batches produced on the GPU.
 
@@ -81,21 +100,26 @@ class GpuTwoViewLoader:
     ``eval_batches()`` is never sharded: BatchNorm runs on batch statistics in the reference's evaluation too, so every
     rank walks the same full batches and gets the same features as a single-GPU run."""
 
-    def __init__(self, images_u8, labels, transforms, batch_size, shuffle, device, seed=420, rank=None, world=None):
+    def __init__(self, images_u8, labels, transforms, batch_size, shuffle, device, seed=420, rank=None, world=None,
+                 max_resident_bytes=None, stream_chunk_batches=8):
         self.device = device
-        self.images = self._resident(images_u8, device)                      # uint8 [N,H,W,3] resident in HBM
+        host = images_u8 if isinstance(images_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(images_u8))
+        self.shape = tuple(host.shape)
+        self.streamed = max_resident_bytes is not None and host.numel() > max_resident_bytes and torch.device(device).type == "cuda"
+        if self.streamed:
+            self.host = host.pin_memory()                                    # uint8 [N,H,W,3] in pinned host memory
+            self.images = None
+            self.chunk_batches = max(1, int(stream_chunk_batches))
+            self._copy_stream = torch.cuda.Stream(device)
+        else:
+            self.host = None
+            self.images = host.to(device)                                    # uint8 [N,H,W,3] resident in HBM
         self.labels = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(device)
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self._rank, self._world = rank, world
         self._setup_transforms(transforms)
         self.gen = torch.Generator().manual_seed(seed)
         self.step = 0
-
-    @staticmethod
-    def _resident(images_u8, device):
-        if isinstance(images_u8, torch.Tensor):
-            return images_u8.to(device)
-        return torch.from_numpy(images_u8).to(device)
 
     def _setup_transforms(self, transforms):
         self.train_tf = augmentations.get_transform(transforms["train"])
@@ -125,34 +149,100 @@ class GpuTwoViewLoader:
         return out
 
     def __len__(self):
-        return len(self._rank_slices(self.images.shape[0]))                 # per-rank steps; world 1: the last batch is NOT dropped
+        return len(self._rank_slices(self.shape[0]))                        # per-rank steps; world 1: the last batch is NOT dropped
 
     def _order(self):
-        n = self.images.shape[0]
+        n = self.shape[0]
         return torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
 
-    def _make(self, idx, step):
-        aug_1, aug_2 = self.train_tf.two_views(self.images, idx, step)
-        img = self.test_tf.one_view(self.images, idx)
-        return {"index": idx, "img": img, "aug_1": aug_1, "aug_2": aug_2, "label": self.labels[idx]}
+    def _make(self, idx, step, images=None, rows=None):
+        """idx: dataset indices (they key the augmentation streams and pick the labels); images / rows: where the pixels are - the
+        resident dataset indexed by idx, or a streamed chunk indexed by its local rows."""
+        images = self.images if images is None else images
+        rows = idx if rows is None else rows
+        views = self.train_tf.apply(images, rows, self.train_tf.draw(images, idx, step, 2))
+        img = self.test_tf.one_view(images, rows)
+        return {"index": idx, "img": img, "aug_1": views[0], "aug_2": views[1], "label": self.labels[idx]}
 
     def __iter__(self):
         order = self._order()                                               # identical on every rank (shared seed)
-        for a, b in self._rank_slices(order.numel()):
+        slices = self._rank_slices(order.numel())
+        if self.streamed:
+            yield from self._iter_streamed(order, slices)
+            return
+        for a, b in slices:
             idx = order[a:b].to(self.device)
             batch = self._make(idx, self.step)                              # self.step is the GLOBAL step: same on every rank
             self.step += 1
             yield batch
 
+    # ---- streaming ----------------------------------------------------------------------------------------------------
+    def _iter_streamed(self, order, slices):
+        """Double-buffered chunks: while chunk c trains out of one device buffer, a background thread gathers chunk c+1 (pinned
+        staging) and uploads it into the other on the side stream.  Events order (i) upload -> first use, (ii) last use -> overwrite."""
+        kb = self.chunk_batches
+        chunks = [slices[i:i + kb] for i in range(0, len(slices), kb)]
+        cap = max(sum(b - a for a, b in ch) for ch in chunks)
+        if getattr(self, "_cap", 0) < cap:
+            self._stage = [torch.empty((cap,) + self.shape[1:], dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._dev = [torch.empty((cap,) + self.shape[1:], dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self._cap = cap
+        uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+        released = [None, None]                                             # compute-stream events: the buffer's last reader has been enqueued
+
+        failure = []
+
+        def fetch(c, k):
+            try:
+                ids = torch.cat([order[a:b] for a, b in chunks[c]])
+                _gather_rows(self.host, ids, self._stage[k])                                # host gather (releases the GIL)
+                with torch.cuda.stream(self._copy_stream):
+                    if released[k] is not None:
+                        self._copy_stream.wait_event(released[k])
+                    self._dev[k][:ids.numel()].copy_(self._stage[k][:ids.numel()], non_blocking=True)
+                    uploaded[k].record(self._copy_stream)
+            except BaseException as exc:                                    # surfaced on the training thread at the next join
+                failure.append(exc)
+
+        worker = threading.Thread(target=fetch, args=(0, 0))
+        worker.start()
+        for c, ch in enumerate(chunks):
+            k = c & 1
+            worker.join()
+            if failure:
+                raise failure[0]
+            if c + 1 < len(chunks):
+                uploaded[k ^ 1].synchronize() if c >= 1 else None           # the staging buffer's previous upload must have left the host
+                worker = threading.Thread(target=fetch, args=(c + 1, k ^ 1))
+                worker.start()
+            torch.cuda.current_stream(self.device).wait_event(uploaded[k])
+            r0 = 0
+            for a, b in ch:
+                idx = order[a:b].to(self.device)
+                rows = torch.arange(r0, r0 + (b - a), device=self.device)
+                batch = self._make(idx, self.step, images=self._dev[k], rows=rows)
+                r0 += b - a
+                self.step += 1
+                yield batch
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            released[k] = ev
+
     def eval_batches(self):
         """{index, img, label} over the whole set in order, full batches on every rank (feature extraction / kNN / linear eval)."""
-        n = self.images.shape[0]
+        n = self.shape[0]
         for s in range(0, n, self.batch_size):
-            idx = torch.arange(s, min(s + self.batch_size, n), device=self.device)
-            yield {"index": idx, "img": self.test_tf.one_view(self.images, idx), "label": self.labels[idx]}
+            e = min(s + self.batch_size, n)
+            idx = torch.arange(s, e, device=self.device)
+            if self.streamed:
+                chunk = self.host[s:e].to(self.device, non_blocking=True)
+                img = self.test_tf.one_view(chunk, torch.arange(e - s, device=self.device))
+            else:
+                img = self.test_tf.one_view(self.images, idx)
+            yield {"index": idx, "img": img, "label": self.labels[idx]}
 
     def num_eval_batches(self):
-        return (self.images.shape[0] + self.batch_size - 1) // self.batch_size
+        return (self.shape[0] + self.batch_size - 1) // self.batch_size
 
 
 def _load(dataset_name, root, synthetic):
@@ -163,10 +253,15 @@ def _load(dataset_name, root, synthetic):
     return _load_cifar(root, dataset_name, True), _load_cifar(root, dataset_name, False)
 
 
-def get_double_augment_dataloaders(dataset_name, root, transforms, batch_size, device=None, synthetic=None):
+def _stream_kwargs(max_resident_gb, stream_chunk_batches):
+    return dict(max_resident_bytes=None if max_resident_gb is None else int(float(max_resident_gb) * (1 << 30)), stream_chunk_batches=stream_chunk_batches)
+
+
+def get_double_augment_dataloaders(dataset_name, root, transforms, batch_size, device=None, synthetic=None, max_resident_gb=None, stream_chunk_batches=8):
     (xtr, ytr), (xte, yte) = _load(dataset_name, root, synthetic)
-    train_loader = GpuTwoViewLoader(xtr, ytr, transforms, batch_size, True, device)
-    test_loader = GpuTwoViewLoader(xte, yte, transforms, batch_size, False, device)
+    kw = _stream_kwargs(max_resident_gb, stream_chunk_batches)
+    train_loader = GpuTwoViewLoader(xtr, ytr, transforms, batch_size, True, device, **kw)
+    test_loader = GpuTwoViewLoader(xte, yte, transforms, batch_size, False, device, **kw)
     return train_loader, test_loader
 
 
@@ -178,13 +273,16 @@ class GpuMultiCropLoader(GpuTwoViewLoader):
         self.multi_crop = augmentations.MultiCrop(multicrop_config)
         self.test_tf = augmentations.get_transform(multicrop_config["test_transforms"])
 
-    def _make(self, idx, step):
-        batch = self.multi_crop(self.images, idx, step)                     # random streams keyed by the dataset index
-        batch.update(index=idx, img=self.test_tf.one_view(self.images, idx), label=self.labels[idx])
+    def _make(self, idx, step, images=None, rows=None):
+        images = self.images if images is None else images
+        rows = idx if rows is None else rows
+        batch = self.multi_crop(images, rows, step, sample_ids=idx)         # random streams keyed by the dataset index
+        batch.update(index=idx, img=self.test_tf.one_view(images, rows), label=self.labels[idx])
         return batch
 
 
-def get_multicrop_dataloaders(dataset_name, root, multicrop_config, batch_size, device=None, synthetic=None):
+def get_multicrop_dataloaders(dataset_name, root, multicrop_config, batch_size, device=None, synthetic=None, max_resident_gb=None, stream_chunk_batches=8):
     (xtr, ytr), (xte, yte) = _load(dataset_name, root, synthetic)
-    return (GpuMultiCropLoader(xtr, ytr, multicrop_config, batch_size, True, device),
-            GpuMultiCropLoader(xte, yte, multicrop_config, batch_size, False, device))
+    kw = _stream_kwargs(max_resident_gb, stream_chunk_batches)
+    return (GpuMultiCropLoader(xtr, ytr, multicrop_config, batch_size, True, device, **kw),
+            GpuMultiCropLoader(xte, yte, multicrop_config, batch_size, False, device, **kw))

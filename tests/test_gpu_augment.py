@@ -78,3 +78,25 @@ def test_center_view_and_loader(dev):
         assert torch.equal(batch["label"].cpu(), torch.from_numpy(labels)[batch["index"].cpu()])
         seen += batch["index"].cpu().tolist()
     assert sorted(seen) == list(range(10))
+
+
+def test_streamed_loader_yields_the_resident_loaders_batches(dev):
+    """A dataset above `max_resident_bytes` stays in pinned host memory; chunks of it are gathered + uploaded by a background thread
+    into a double-buffered device chunk.  Every batch of two epochs (ragged last chunk and last batch included) equals the resident
+    loader's bit for bit - indices, labels, both views and the centre view."""
+    from ssv_amd.utils import data_utils
+    rng = np.random.default_rng(3)
+    imgs, labels = rng.integers(0, 256, size=(150, 40, 40, 3), dtype=np.uint8), rng.integers(0, 10, size=150)
+    tfs = {"train": _cfg((32, 32)), "test": TEST}
+    res = data_utils.GpuTwoViewLoader(imgs, labels, tfs, batch_size=16, shuffle=True, device=dev)
+    stm = data_utils.GpuTwoViewLoader(imgs, labels, tfs, batch_size=16, shuffle=True, device=dev, max_resident_bytes=1000, stream_chunk_batches=3)
+    assert stm.streamed and not res.streamed and stm.images is None and len(stm) == len(res) == 10
+    for epoch in range(2):
+        n = 0
+        for a, b in zip(res, stm):
+            for k in ("index", "label", "aug_1", "aug_2", "img"):
+                assert torch.equal(a[k], b[k]), (epoch, n, k)
+            n += 1
+        assert n == 10
+    ea, eb = list(res.eval_batches()), list(stm.eval_batches())
+    assert len(ea) == len(eb) == 10 and all(torch.equal(x["img"], y["img"]) and torch.equal(x["label"], y["label"]) for x, y in zip(ea, eb))

@@ -82,3 +82,39 @@ def test_lr_schedule_matches_reference(golden):
                 sched.step()
             lrs.append(opt.param_groups[0]["lr"])
     np.testing.assert_allclose(lrs, g["lr_schedule"], rtol=1e-12)
+
+
+def _write_cifar10(root, n_train=50, n_test=20, seed=5):
+    """A CIFAR-10 python archive in miniature: data_batch_1..5 + test_batch, b"data" [n, 3072] uint8 in CHW order, b"labels"."""
+    import pickle
+    base = os.path.join(root, "cifar-10-batches-py")
+    os.makedirs(base)
+    rng = np.random.default_rng(seed)
+    files = {f"data_batch_{i}": n_train // 5 for i in range(1, 6)}
+    files["test_batch"] = n_test
+    truth = {}
+    for name, n in files.items():
+        data = rng.integers(0, 256, size=(n, 3072), dtype=np.uint8)
+        labels = rng.integers(0, 10, size=n).tolist()
+        with open(os.path.join(base, name), "wb") as fh:
+            pickle.dump({b"data": data, b"labels": labels, b"batch_label": name.encode()}, fh)
+        truth[name] = (data, labels)
+    return truth
+
+
+def test_cifar_pickles_are_read_into_nhwc_uint8(tmp_path):
+    """the real-dataset path.  The python archive stores CHW rows; the GPU path wants [N,H,W,3] uint8 (reference
+    utils/data_utils.py:8-11 hands torchvision.datasets.CIFAR10 the same files)."""
+    from ssv_amd.utils import data_utils
+    truth = _write_cifar10(str(tmp_path))
+    x, y = data_utils._load_cifar(str(tmp_path), "cifar10", True)
+    assert x.shape == (50, 32, 32, 3) and x.dtype == np.uint8 and x.flags["C_CONTIGUOUS"] and y.shape == (50,)
+    want = np.concatenate([truth[f"data_batch_{i}"][0] for i in range(1, 6)]).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+    np.testing.assert_array_equal(x, want)
+    np.testing.assert_array_equal(y, np.concatenate([truth[f"data_batch_{i}"][1] for i in range(1, 6)]))
+    xt, yt = data_utils._load_cifar(str(tmp_path), "cifar10", False)
+    assert xt.shape == (20, 32, 32, 3) and yt.tolist() == truth["test_batch"][1]
+    with pytest.raises(FileNotFoundError):
+        data_utils._load_cifar(str(tmp_path / "nowhere"), "cifar10", True)
+    with pytest.raises(AssertionError):
+        data_utils._load("imagenet", str(tmp_path), None)
