@@ -546,9 +546,11 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
           f32x4 v = ra[i];
+          // ReLU and "a padding tap stays zero" in ONE instruction per element: clamp to [0, cap] with cap = +inf for a real pixel and
+          // 0 for a padding tap (v_med3_f32) - the staged transform costs 2 VALU per element instead of 3
+          const float cap = (inb || ((xf_ok >> i) & 1)) ? __builtin_inff() : 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f);
-          if (!inb) { const bool ok = (xf_ok >> i) & 1; v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f; }
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f, cap);
           *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = v;
         }
       } else {
@@ -971,9 +973,9 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
         // same fmaf / fmaxf as bn_apply_k: bit-identical to the materialised activation; padding taps (and, in the LIN mode, rows
         // past M, whose dY rows are zero anyway) must not pick up relu(shift)
         f32x4 v = rbv[i];
+        const float cap = (GATHER == 1 || ((xf_ok >> i) & 1)) ? __builtin_inff() : 0.f;      // ReLU + zero padding tap as one clamp (v_med3_f32)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], xsc[e], xsh[e]), 0.f);
-        if constexpr (GATHER != 1) { const bool ok = (xf_ok >> i) & 1; v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f; }
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(v[e], xsc[e], xsh[e]), 0.f, cap);
         *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = v;
       } else if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
       else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];

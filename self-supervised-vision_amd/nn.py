@@ -177,6 +177,7 @@ _PAD_STEM = os.environ.get("SSV_NO_STEM_PADDING", "0") != "1"
 
 _FUSE_BN_APPLY = os.environ.get("SSV_NO_BN_APPLY_FUSION", "0") != "1"      # diagnostic switch: materialise every activation
 _FUSE_BN_BWD = os.environ.get("SSV_NO_BN_BWD_FUSION", "0") != "1"          # diagnostic switch: BatchNorm backward with its own reduction pass
+_FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
 
 
 class LazyAct:
@@ -646,6 +647,11 @@ class HipConv2d(HipModule):
 
     def can_fuse_input(self):
         """True when this convolution can take a LazyAct (a never-written conv -> BN -> ReLU output) as its input."""
+        # a k x k filter re-stages (and re-transforms) every input element k*k times: with the 256 x 64 tile of narrow layers (cout < 128,
+        # twice the staged A rows per thread) that VALU work costs more than the apply pass it saves (measured: layer1's 3x3 forward at
+        # 99 TFLOP/s fused against 116 on a materialised input, profiles/r02_*_conv_layers_*.csv); wider layers keep the fusion
+        if self.weight.shape[2] > 1 and (not _FUSE_BN_APPLY_3X3 or self.weight.shape[0] < 128):
+            return False
         return _FUSE_BN_APPLY and _FUSE_BN_STATS and ops.can_fuse_conv_input(self.weight.shape[1] * self.groups, self.weight.shape[0], self.groups)
 
     def _run(self, tape, x, bn_stats=False):
