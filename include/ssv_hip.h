@@ -160,6 +160,16 @@ int ssv_bn_relu_bwd_affine(int64_t M, int32_t C, const float* dy, const float* x
 int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, const float* x, const float* gamma,
                              const float* save_mean, const float* save_invstd, const float* psum_g, const float* psum_gx, int64_t groups,
                              float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The image stem's BatchNorm + ReLU + MaxPool2d(3, 2, 1) (networks/resnet.py:147-148 `maxpool(relu(bn1(conv1(x))))`) as one pass each way:
+ * forward reads the raw conv output y [N,H,W,C] once and writes only the pooled map [N,Ho,Wo,C] + its argmax slots (scale / shift from
+ * ssv_bn_stats_finalize); backward forms the gradient w.r.t. the BatchNorm output on the fly (gather over the <= 2x2 windows that chose the
+ * pixel, ReLU gate recomputed) inside the BatchNorm backward's reduction and apply passes - bit-identical to ssv_maxpool3x3s2_bwd followed by
+ * ssv_bn_train_bwd, without the two full-resolution intermediates.  Workspace: ssv_bn_workspace_bytes(N*H*W, C). */
+int ssv_bn_relu_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* y, const float* scale, const float* shift,
+                            float* out, uint8_t* argmax, void* stream);
+int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dpool, const uint8_t* argmax, const float* y,
+                            const float* gamma, const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
+                            float* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* out[c] (+)= sum_m x[m][c]   (bias gradient of nn.Linear); same workspace size as BN */
 int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int accumulate,
                void* ws, size_t ws_bytes, void* stream);

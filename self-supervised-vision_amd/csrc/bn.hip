@@ -565,6 +565,165 @@ extern "C" int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, co
   return SSV_OK;
 }
 
+// ---- the image stem: BatchNorm + ReLU + MaxPool2d(3, 2, 1) as one pass each way (networks/resnet.py:147-148) ----------------
+// forward : pooled = max over the window of relu(y * scale + shift); y is read once, the 112^2 activation is never written
+// backward: g[pixel] = relu'(a) * sum of dpool over the (at most 2 x 2) windows whose argmax is this pixel - formed on the fly
+//           in the BatchNorm backward's reduction AND apply passes (same partition, same order as bn_bwd_reduce_k / _apply_k, so the
+//           result is bit-identical to maxpool_bwd -> bn_train_bwd), instead of materialising dy of the 112^2 map twice.
+namespace {
+__global__ void __launch_bounds__(256)
+bn_relu_maxpool_fwd_k(int N, int H, int W, int C, int Ho, int Wo, const float* __restrict__ y, const float* __restrict__ scale,
+                      const float* __restrict__ shift, float* __restrict__ out, uint8_t* __restrict__ am) {
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const f32x4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * 2 - 1 + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int wi = wo * 2 - 1 + s_;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        f32x4 v = fma4(ld4(y + (((size_t)n * H + hi) * W + wi) * C + 4 * c4), sc, sh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaxf(v[e], 0.f);                                                     // the ReLU of bn_apply_k
+          if (first[e] || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s_; first[e] = false; }   // ties: first, like ATen
+        }
+      }
+    }
+    st4(out + (size_t)i * 4, best);
+    uchar4 a; a.x = (uint8_t)bi[0]; a.y = (uint8_t)bi[1]; a.z = (uint8_t)bi[2]; a.w = (uint8_t)bi[3];
+    reinterpret_cast<uchar4*>(am)[i] = a;
+  }
+}
+
+// gradient w.r.t. the BatchNorm output of pixel (n, hi, wi), ReLU included.  A pixel sits in at most 2 x 2 windows: along each axis the
+// window (c + 1) >> 1 with slot (c + 1) & 1, and for odd c also the window before it with slot 2.  The four candidates are visited in
+// the order of maxpool_bwd_k (slot-row major), so the sum is bit-identical.
+__device__ __forceinline__ f32x4 pool_gate_grad(int n, int hi, int wi, int Ho, int Wo, int C4, int c4, const float* __restrict__ dpool,
+                                                const uint8_t* __restrict__ am, f32x4 a) {
+  const int hA = (hi + 1) >> 1, rA = (hi + 1) & 1, wA = (wi + 1) >> 1, sA = (wi + 1) & 1;
+  // (window, slot) per axis in increasing slot order: [A (slot 0/1)], then [A - 1 (slot 2)] when the coordinate is odd
+  const int hw[2] = {hA, hA - 1}, hs[2] = {rA, 2}, ww[2] = {wA, wA - 1}, wsl[2] = {sA, 2};
+  const bool hv[2] = {hA < Ho, (hi & 1) != 0}, wv[2] = {wA < Wo, (wi & 1) != 0};
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (hv[i] && wv[j]) {
+        const size_t o = (((size_t)n * Ho + hw[i]) * Wo + ww[j]) * C4 + c4;
+        const uchar4 m = reinterpret_cast<const uchar4*>(am)[o];
+        const f32x4 d = ld4(dpool + o * 4);
+        const int slot = hs[i] * 3 + wsl[j];
+        g[0] += m.x == slot ? d[0] : 0.f; g[1] += m.y == slot ? d[1] : 0.f;
+        g[2] += m.z == slot ? d[2] : 0.f; g[3] += m.w == slot ? d[3] : 0.f;
+      }
+    }
+  return masked<true>(g, a);
+}
+
+template <bool APPLY>
+__global__ void __launch_bounds__(256)
+bn_pool_bwd_k(int64_t M, int C, int CT, int RT, int rpb, int H, int W, int Ho, int Wo, const float* __restrict__ dpool, const uint8_t* __restrict__ am,
+              const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+              const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ k1, const float* __restrict__ k2,
+              float* __restrict__ psg, float* __restrict__ psgx, float* __restrict__ dx) {
+  __shared__ f32x4 sm1[APPLY ? 1 : 256], sm2[APPLY ? 1 : 256];
+  const int tid = threadIdx.x;
+  const int ct = tid % CT, rt = tid / CT;
+  const int c4 = blockIdx.y * CT + ct;
+  const bool active = rt < RT && c4 < C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < M ? r0 + rpb : M;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  if (active) {
+    const f32x4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4), sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
+    f32x4 gi = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    if constexpr (APPLY) { gi = ld4(gamma + 4 * c4) * is; a1 = ld4(k1 + 4 * c4); a2 = ld4(k2 + 4 * c4); }
+    // (n, hi, wi) of this thread's current row, advanced by RT pixels per visit without divisions (RT <= W is checked by the host)
+    int64_t r = r0 + rt;
+    int wi = (int)(r % W);
+    int hi = (int)((r / W) % H), n = (int)(r / ((int64_t)W * H));
+    auto body = [&](int64_t rr) {
+      const size_t o = (size_t)rr * C + 4 * c4;
+      const f32x4 xv = ld4(x + o);
+      const f32x4 g = pool_gate_grad(n, hi, wi, Ho, Wo, C / 4, c4, dpool, am, fma4(xv, sc, sh));
+      const f32x4 xh = (xv - mu) * is;
+      if constexpr (APPLY) st4(dx + o, gi * (g - a1 - xh * a2));
+      else { s1 += g; s2 += g * xh; }
+      wi += RT;
+      if (wi >= W) { wi -= W; if (++hi == H) { hi = 0; ++n; } }
+    };
+    for (; r + 3 * RT < r1; r += 4 * RT) { body(r); body(r + RT); body(r + 2 * RT); body(r + 3 * RT); }
+    for (; r < r1; r += RT) body(r);
+  }
+  if constexpr (!APPLY) {
+    sm1[tid] = s1; sm2[tid] = s2;
+    __syncthreads();
+    if (active && rt == 0) {
+      for (int j = 1; j < RT; ++j) { s1 += sm1[j * CT + ct]; s2 += sm2[j * CT + ct]; }
+      st4(psg + (size_t)blockIdx.x * C + 4 * c4, s1);
+      st4(psgx + (size_t)blockIdx.x * C + 4 * c4, s2);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ssv_bn_relu_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* y, const float* scale, const float* shift,
+                                       float* out, uint8_t* argmax, void* stream) {
+  SSV_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ssv_bn_relu_maxpool_fwd: bad shape (C %% 4 == 0 required)");
+  SSV_REQUIRE(y && scale && shift && out && argmax, "ssv_bn_relu_maxpool_fwd: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_FWD, s);
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_k, dim3((unsigned)blocks), dim3(256), 0, s, N, H, W, C, Ho, Wo, y, scale, shift, out, argmax);
+  SSV_CHECK_LAUNCH("ssv_bn_relu_maxpool_fwd");
+  return SSV_OK;
+}
+
+extern "C" int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dpool, const uint8_t* argmax, const float* y,
+                                       const float* gamma, const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
+                                       float* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  const int64_t M = (int64_t)N * H * W;
+  if (int rc = check_mc(M, C, "ssv_bn_relu_maxpool_bwd")) return rc;
+  SSV_REQUIRE(N > 0 && H > 0 && W > 0, "ssv_bn_relu_maxpool_bwd: bad shape");
+  SSV_REQUIRE(bn_plan((int64_t)N * H * W, C).RT <= W, "ssv_bn_relu_maxpool_bwd: the feature map is narrower than the row stride of the kernel (W=%d)", W);
+  SSV_REQUIRE(dpool && argmax && y && gamma && save_mean && save_invstd && scale && shift && dy && ws, "ssv_bn_relu_maxpool_bwd: null pointer");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_relu_maxpool_bwd: workspace too small");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_BWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* psg = (float*)ws;
+  float* psgx = psg + (size_t)p.nblk * C;
+  float* k1 = psgx + (size_t)p.nblk * C;
+  float* k2 = k1 + C;
+  const dim3 grid(p.nblk, p.GY);
+  hipLaunchKernelGGL((bn_pool_bwd_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, H, W, Ho, Wo, dpool, argmax, y, gamma, save_mean, save_invstd,
+                     scale, shift, (const float*)nullptr, (const float*)nullptr, psg, psgx, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
+                     dgamma, dbeta, accumulate, k1, k2);
+  hipLaunchKernelGGL((bn_pool_bwd_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, H, W, Ho, Wo, dpool, argmax, y, gamma, save_mean, save_invstd,
+                     scale, shift, (const float*)k1, (const float*)k2, (float*)nullptr, (float*)nullptr, dy);
+  SSV_CHECK_LAUNCH("ssv_bn_relu_maxpool_bwd");
+  return SSV_OK;
+}
+
 extern "C" int ssv_colsum(int64_t M, int32_t C, const float* x, float* out, int accumulate,
                           void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_mc(M, C, "ssv_colsum")) return rc;

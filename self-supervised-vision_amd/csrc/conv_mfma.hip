@@ -1109,7 +1109,9 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
 #define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
 #define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
-  if (stats || xf) {                                           // C % 32 == 0 checked by the callers
+  if (stats && d->C == 4) {                                    // the padded image stem with the statistics epilogue
+    FWD_TILE(32, true, true, false);
+  } else if (stats || xf) {                                    // C % 32 == 0 checked by the callers
     if (stats && xf) FWD_TILE(32, true, false, true);
     else if (stats)  FWD_TILE(32, true, false, false);
     else             FWD_TILE(32, false, false, true);
@@ -1192,7 +1194,8 @@ extern "C" int ssv_conv2d_fwd_bnrelu_in_stats(const ssv_conv_desc* d, const floa
   SSV_REQUIRE(pmean || in_scale, "ssv_conv2d_fwd_bnrelu_in_stats: neither statistics nor a fused input requested - call ssv_conv2d_fwd");
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)pmean | (uintptr_t)pm2 | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0,
               "ssv_conv2d_fwd_bnrelu_in_stats: pointers must be 16-byte aligned");
-  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0, "ssv_conv2d_fwd_bnrelu_in_stats: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  SSV_REQUIRE((d->C % 32 == 0 || (d->C == 4 && !in_scale)) && d->K % 4 == 0,
+              "ssv_conv2d_fwd_bnrelu_in_stats: needs C %% 32 == 0 (or the 4-channel stem, statistics only) and K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
   SSV_REQUIRE(!in_scale || d->C <= XF_MAXC, "ssv_conv2d_fwd_bnrelu_in_stats: a fused input supports at most %d channels (got %d)", XF_MAXC, d->C);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_FWD, s);

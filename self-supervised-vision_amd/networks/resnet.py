@@ -137,7 +137,7 @@ class ResNet(hnn.HipModule):
         return ops.nchw_to_nhwc(x)
 
     def _run(self, tape, x):
-        x = hnn.maxpool(tape, hnn.batchnorm(tape, self.conv1._run(tape, x, bn_stats=True), self.bn1, relu=True))
+        x = hnn.bn_relu_maxpool(tape, self.conv1._run(tape, x, bn_stats=True), self.bn1)      # one pass each way when the conv left statistics
         for idx in range(1, len(_STAGE_PLANES) + 1):
             for unit in getattr(self, f"layer{idx}"):
                 x = unit._run(tape, x)

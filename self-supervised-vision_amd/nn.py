@@ -240,14 +240,19 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
     return y
 
 
-def stem_conv(tape, x, weight, stride, pad):
+def stem_conv(tape, x, weight, stride, pad, bn_stats=False):
     """The 3-channel image convolution with both operands padded to 4 channels: the kernels then move one filter tap per 16-byte
     load (forward) / take their float4 path (wgrad) instead of gathering scalars.  Exact: the fourth channel is zero on both
-    sides.  No input gradient (images)."""
+    sides.  No input gradient (images).  ``bn_stats``: the epilogue leaves the BatchNorm statistics partials, as in `conv`."""
     k, c, r, s_ = weight.shape
     xp = ops.pad_channels(x, 4)                                                  # [N,H,W,4]
     wp = ops.pad_channels(weight.permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)     # OHWI [K,R,S,4], seen as [K,4,R,S] channels_last
-    y = ops.conv2d_fwd(xp, wp, stride, pad)
+    fused = ops.conv2d_fwd_stats(xp, wp, stride, pad) if (bn_stats and _FUSE_BN_STATS) else None
+    if fused is not None:
+        y = fused[0]
+        y._bn_partials = (fused[1], fused[2])
+    else:
+        y = ops.conv2d_fwd(xp, wp, stride, pad)
     if tape is not None:
         slot = tape.slot
 
@@ -356,6 +361,32 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
                 return (_accum(existing[0], dx), None)
             return (_accum(existing[0], dx), _accum(existing[1], dres))
         tape.record((x, residual), y, bwd)
+    return y
+
+
+_FUSE_STEM_POOL = os.environ.get("SSV_NO_STEM_POOL_FUSION", "0") != "1"    # diagnostic switch
+
+
+def bn_relu_maxpool(tape, x, bn):
+    """maxpool(relu(bn(x))) of the image stem (networks/resnet.py:147-148).  With the statistics partials of x at hand this is one pass
+    each way: the full-resolution activation and its gradient are never written (ssv_bn_relu_maxpool_fwd / _bwd)."""
+    partials = x.__dict__.get("_bn_partials")
+    if partials is None or not _FUSE_STEM_POOL or not _FUSE_BN_APPLY:
+        return maxpool(tape, batchnorm(tape, x, bn, relu=True))
+    x.__dict__.pop("_bn_partials")
+    _bn_order_wait(bn, x)
+    m, c = ops._rows(x)
+    mean, invstd, scale, shift = ops.bn_stats_finalize(m, c, partials, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                       eps=bn.eps, momentum=bn.momentum)
+    _bn_order_record(bn, x)
+    y, am = ops.bn_relu_maxpool_fwd(x, scale, shift)
+    if tape is not None:
+        slot = tape.slot
+
+        def bwd(dy, existing):
+            dx = ops.bn_relu_maxpool_bwd(dy, am, x, bn.weight, mean, invstd, scale, shift, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
+            return (_accum(existing[0], dx),)
+        tape.record((x,), y, bwd)
     return y
 
 
@@ -658,7 +689,7 @@ class HipConv2d(HipModule):
         if self.groups > 1:
             return grouped_conv(tape, x, self.weight, self.groups, self.stride, self.pad)
         if self.weight.shape[1] == 3 and (tape is None or not tape.needs_grad(x)) and _PAD_STEM:
-            return stem_conv(tape, x, self.weight, self.stride, self.pad)
+            return stem_conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats)
         return conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats)
 
     def _apply(self, fn, *a, **k):

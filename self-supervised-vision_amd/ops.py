@@ -79,7 +79,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
     64 output rows.  Returns None when the shape is outside the fused kernel's preconditions (C % 32, K % 4)."""
     _lib._dev(x, w)
     _, wshape = _ohwi(w)
-    if wshape[1] % 32 or wshape[0] % 4:
+    if (wshape[1] % 32 and wshape[1] != 4) or wshape[0] % 4:          # C == 4: the padded image stem
         return None
     y, part = conv2d_fwd_fused(x, w, stride, pad, in_affine=None, want_stats=True)
     return y, part[0], part[1]
@@ -306,6 +306,28 @@ def colsum(x, out, accumulate=True):
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
     call("ssv_colsum", m, c, ptr(x), ptr(out), int(accumulate), ptr(ws), ws.numel(), stream())
     return out
+
+
+def bn_relu_maxpool_fwd(y, scale, shift):
+    """maxpool3x3s2(relu(y * scale + shift)) of a raw conv output [N,H,W,C] in one pass: returns (pooled, argmax slots)."""
+    _lib._dev(y, scale, shift)
+    n, h, w, c = y.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = _empty((n, ho, wo, c), y)
+    am = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=y.device)
+    call("ssv_bn_relu_maxpool_fwd", n, h, w, c, ptr(y), ptr(scale), ptr(shift), ptr(out), ptr(am), stream())
+    return out, am
+
+
+def bn_relu_maxpool_bwd(dpool, am, y, gamma, mean, invstd, scale, shift, dgamma, dbeta, accumulate=True):
+    """Gradient w.r.t. the raw conv output y through maxpool, ReLU and BatchNorm, plus dgamma / dbeta."""
+    _lib._dev(dpool, am, y)
+    n, h, w, c = y.shape
+    dy = torch.empty_like(y)
+    ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(n * h * w, c), y.device)
+    call("ssv_bn_relu_maxpool_bwd", n, h, w, c, ptr(dpool), ptr(am), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+         ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
+    return dy
 
 
 def maxpool_fwd(x):
