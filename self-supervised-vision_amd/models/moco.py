@@ -19,7 +19,15 @@ class MemoryBank:
         self.bank = ops.fill_(torch.empty(((self.size + 15) // 16 * 16, feature_size), dtype=torch.float32, device=device), 0.0)
 
     def add_batch(self, batch):
-        self.ptr = ops.queue_push(self.bank, self.size, self.ptr, batch.detach().contiguous())
+        """Data parallel: the keys of ALL ranks enter every rank's queue, in rank order - the replicas stay identical."""
+        from .. import distributed as hdist
+        keys = batch.detach().contiguous()
+        if hdist.is_on():
+            b, world = keys.shape[0], hdist.world_size()
+            allk = torch.empty((b * world, keys.shape[1]), dtype=keys.dtype, device=keys.device)
+            allk[hdist.rank() * b:(hdist.rank() + 1) * b].copy_(keys)
+            keys = hdist.all_gather_rows(allk, b)
+        self.ptr = ops.queue_push(self.bank, self.size, self.ptr, keys)
 
     def get_vectors(self):
         return self.bank

@@ -210,16 +210,23 @@ class _RelicKLFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, zi, zj, zo, normalize, temperature, alpha):
-        if hdist.world_size() > 1:
-            raise NotImplementedError("ReLIC's invariance term soft-maxes across the batch; its data-parallel form is not built")
-        d = zi.shape[1]
+        # Data parallel: the term soft-maxes the N diagonal logits ACROSS the batch, so the (normalised) embeddings are all-gathered and
+        # every rank evaluates the global-batch term (N x D work - nothing next to the encoder), keeping the gradient rows of its own
+        # samples: the SUM of the per-rank parameter gradients is the gradient of the global loss, like the other losses here.
+        bl, d = zi.shape
+        world, rank = hdist.world_size(), hdist.rank()
         mats, invs = [], []
         for z in (zi, zj, zo):
             zh, inv = ops.l2norm_fwd(z.detach().contiguous(), normalize)
+            if world > 1:
+                zall = torch.empty((bl * world, d), dtype=torch.float32, device=z.device)
+                zall[rank * bl:(rank + 1) * bl].copy_(zh)
+                zh = hdist.all_gather_rows(zall, bl)
             mats.append(zh)
             invs.append(inv)
         loss, *grads = ops.relic_kl(mats[0], mats[1], mats[2], 1.0 / float(temperature), alpha)
-        ctx.saved = tuple(ops.l2norm_bwd(mats[k], invs[k], grads[k], d, normalize) for k in range(3))
+        mine = slice(rank * bl, (rank + 1) * bl)
+        ctx.saved = tuple(ops.l2norm_bwd(mats[k][mine].contiguous(), invs[k], grads[k][mine].contiguous(), d, normalize) for k in range(3))
         return loss
 
     @staticmethod
@@ -244,15 +251,23 @@ class RelicLoss(nn.Module):
 class _MocoFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, query, keys, bank, queue_size, normalize, temperature):
-        if hdist.world_size() > 1:
-            raise NotImplementedError("MoCo's queue under data parallelism (all-gather of the keys) is not built")
+        # Data parallel: every query is scored against its own key and the (replicated) queue - a per-sample loss, so the mean over the
+        # GLOBAL batch is the local mean weighted 1/world with the scalar all-reduced (the convention of the BYOL pair loss); the queue
+        # stays identical on every rank because MemoryBank.add_batch pushes the all-gathered keys in rank order.
         n, d = query.shape
+        world = hdist.world_size()
         qn, inv_q = ops.l2norm_fwd(query.detach().contiguous(), normalize)
         kn, _ = ops.l2norm_fwd(keys.detach().contiguous(), normalize)
         neg = ops.conv2d_fwd(qn.view(n, 1, 1, d), bank).view(n, bank.shape[0])                    # [N, K_pad] products with the queue (MFMA GEMM)
         loss, dq = ops.moco_loss(qn, kn, neg, queue_size, 1.0 / float(temperature))
         ops.conv2d_dgrad(neg.view(n, 1, 1, -1), bank, (n, 1, 1, d), addend=dq.view(n, 1, 1, d), out=dq.view(n, 1, 1, d))   # dq += P . bank
-        ctx.saved = ops.l2norm_bwd(qn, inv_q, dq, d, normalize)
+        dz = ops.l2norm_bwd(qn, inv_q, dq, d, normalize)
+        if world > 1:
+            w = torch.full((), 1.0 / world, dtype=torch.float32, device=query.device)
+            ops.scale_(loss.view(1), w)
+            ops.scale_(dz, w)
+            hdist.all_reduce_sum(loss)
+        ctx.saved = dz
         return loss
 
     @staticmethod

@@ -115,6 +115,34 @@ def _sharded_loss_checks(rank, dev, losses):
         scale = float(a.grad.abs().max())
         np.testing.assert_allclose(li.grad.cpu().numpy(), a.grad[sl].numpy(), rtol=2e-3, atol=2e-4 * scale)
         np.testing.assert_allclose(lj.grad.cpu().numpy(), c.grad[sl].numpy(), rtol=2e-3, atol=2e-4 * scale)
+    # ReLIC (NT-Xent + the batch-wide invariance term) and MoCo (per-sample loss against a replicated queue) over the split batch
+    from oracle import siblings as osib
+    zs = [seeded_randn(50 + k, n, 64) for k in range(3)]
+    ref_in = [z.clone().requires_grad_() for z in zs]
+    ref = osib.relic_loss(*ref_in, normalize=True, temperature=0.5, alpha=0.7)
+    ref.backward()
+    loc = [z[sl].to(dev).requires_grad_() for z in zs]
+    loss = losses.RelicLoss(True, 0.5, 0.7)(*loc)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    for k in range(3):
+        np.testing.assert_allclose(loc[k].grad.cpu().numpy(), ref_in[k].grad[sl].numpy(), rtol=2e-3, atol=2e-6)
+    q, kk, bank = seeded_randn(60, n, 64), seeded_randn(61, n, 64), torch.nn.functional.normalize(seeded_randn(62, 80, 64), dim=1)
+    qr = q.clone().requires_grad_()
+    ref = osib.moco_loss(qr, kk, bank, normalize=True, temperature=0.2)
+    ref.backward()
+    ql = q[sl].to(dev).requires_grad_()
+    loss = losses.MocoLoss(True, 0.2)(ql, kk[sl].to(dev), bank.to(dev).contiguous(), 80)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    np.testing.assert_allclose(ql.grad.cpu().numpy(), qr.grad[sl].numpy(), rtol=2e-3, atol=2e-7)
+    # the queue of every rank receives the keys of ALL ranks, in rank order
+    from ssv_amd.models.moco import MemoryBank
+    mb = MemoryBank(96, 64, dev)
+    mb.add_batch(kk[sl].to(dev))
+    want = torch.nn.functional.normalize(kk, dim=1)
+    np.testing.assert_allclose(mb.get_vectors()[:n].cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+    assert mb.ptr == n % 96
     return None
 
 
