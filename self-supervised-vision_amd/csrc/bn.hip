@@ -27,6 +27,33 @@ BnPlan bn_plan(int64_t M, int C) {
   return p;
 }
 
+// Grid of the pure element-wise passes (bn_apply_k, bn_bwd_apply_k): their result does not depend on the partition, so they get a
+// grid of their own - about SSV_APPLY_WGS workgroups in all, each walking a long run of rows.
+// register cap of the element-wise passes (amdgpu_num_vgpr(n) caps the unified file at 2n on gfx950)
+#ifdef SSV_APPLY_VGPR
+#define SSV_APPLY_ATTR __attribute__((amdgpu_num_vgpr(SSV_APPLY_VGPR)))
+#else
+#define SSV_APPLY_ATTR
+#endif
+#ifndef SSV_APPLY_UNROLL
+#define SSV_APPLY_UNROLL 4
+#endif
+#ifndef SSV_APPLY_WGS
+#define SSV_APPLY_WGS 1024
+#endif
+struct ApplyGrid { int rpb, nblk; };
+ApplyGrid apply_grid(const BnPlan& p, int64_t M) {
+  int64_t blocks = SSV_APPLY_WGS / p.GY;
+  if (blocks < 1) blocks = 1;
+  int64_t rpb = cdiv64(M, blocks);
+  const int64_t min_rows = (int64_t)p.RT * 4;
+  if (rpb < min_rows) rpb = min_rows;
+  ApplyGrid g;
+  g.rpb = (int)rpb;
+  g.nblk = (int)cdiv64(M, rpb);
+  return g;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -139,7 +166,7 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
 // RES: 0 none, 1 add a materialised residual, 2 add a residual that is itself a BatchNorm of a raw conv output
 // (res * rscale + rshift: the projection shortcut's BatchNorm folded into the block's closing kernel)
 template <bool RELU, int RES>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SSV_APPLY_ATTR
 bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ x, const float* __restrict__ scale,
            const float* __restrict__ shift, const float* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
            float* __restrict__ y, uint8_t* __restrict__ mask) {
@@ -164,7 +191,11 @@ bn_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ 
     st4(y + o, v);
   };
   int64_t r = r0 + rt;
+#if SSV_APPLY_UNROLL == 4
   for (; r + 3 * RT < r1; r += 4 * RT) { body(r); body(r + RT); body(r + 2 * RT); body(r + 3 * RT); }
+#else
+  for (; r + RT < r1; r += 2 * RT) { body(r); body(r + RT); }
+#endif
   for (; r < r1; r += RT) body(r);
 }
 
@@ -261,7 +292,7 @@ bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, con
 }
 
 template <int RELU, bool DRES>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SSV_APPLY_ATTR
 bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restrict__ dy, const float* __restrict__ y,
                const uint8_t* __restrict__ mask, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
                const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -285,7 +316,11 @@ bn_bwd_apply_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restric
     if constexpr (DRES) st4(dres + o, g);
   };
   int64_t r = r0 + rt;
+#if SSV_APPLY_UNROLL == 4
   for (; r + 3 * RT < r1; r += 4 * RT) { body(r); body(r + RT); body(r + 2 * RT); body(r + 3 * RT); }
+#else
+  for (; r + RT < r1; r += 2 * RT) { body(r); body(r + RT); }
+#endif
   for (; r < r1; r += RT) body(r);
 }
 
@@ -379,9 +414,13 @@ bn_sums_coarsen_k(int C, int nblk, int factor, const float* __restrict__ p1, con
 
 void launch_apply(const BnPlan& p, int64_t M, int C, const float* x, const float* scale, const float* shift, const float* res,
                   const float* rscale, const float* rshift, int relu, float* y, uint8_t* mask, hipStream_t s) {
-  const dim3 grid(p.nblk, p.GY);
+  const ApplyGrid ag = apply_grid(p, M);
+  const dim3 grid(ag.nblk, p.GY);
   const int mode = res ? (rscale ? 2 : 1) : 0;
-#define APPLY(R_, M_) hipLaunchKernelGGL((bn_apply_k<R_, M_>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, x, scale, shift, res, rscale, rshift, y, mask)
+#ifdef SSV_EXP_SKIP_APPLY
+  return;
+#endif
+#define APPLY(R_, M_) hipLaunchKernelGGL((bn_apply_k<R_, M_>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, ag.rpb, x, scale, shift, res, rscale, rshift, y, mask)
   if (relu) { if (mode == 2) APPLY(true, 2); else if (mode == 1) APPLY(true, 1); else APPLY(true, 0); }
   else      { if (mode == 2) APPLY(false, 2); else if (mode == 1) APPLY(false, 1); else APPLY(false, 0); }
 #undef APPLY
@@ -500,7 +539,12 @@ int launch_bwd(int64_t M, int C, const float* dy, const float* y, const uint8_t*
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
                      dgamma, dbeta, accumulate, k1, k2);
   const float* ck1 = k1; const float* ck2 = k2;
-#define BAPPLY(R_, D_) hipLaunchKernelGGL((bn_bwd_apply_k<R_, D_>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, scale, shift, ck1, ck2, dx, dresidual)
+  const ApplyGrid ag = apply_grid(p, M);
+  const dim3 agrid(ag.nblk, p.GY);
+#ifdef SSV_EXP_SKIP_APPLY
+  return SSV_OK;
+#endif
+#define BAPPLY(R_, D_) hipLaunchKernelGGL((bn_bwd_apply_k<R_, D_>), agrid, dim3(256), 0, s, M, C, p.CT, p.RT, ag.rpb, dy, y, relu_mask, x, gamma, save_mean, save_invstd, scale, shift, ck1, ck2, dx, dresidual)
   if (dresidual) { if (relu_mode == 2) BAPPLY(2, true); else if (relu_mode == 1) BAPPLY(1, true); else BAPPLY(0, true); }
   else           { if (relu_mode == 2) BAPPLY(2, false); else if (relu_mode == 1) BAPPLY(1, false); else BAPPLY(0, false); }
 #undef BAPPLY
@@ -558,8 +602,12 @@ extern "C" int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, co
     psum_g = c1; psum_gx = c2; nblk = ncoarse;
   }
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, nblk, psum_g, psum_gx, dgamma, dbeta, accumulate, k1, k2);
-  const dim3 grid(p.nblk, p.GY);
-  hipLaunchKernelGGL((bn_bwd_apply_k<0, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, g, (const float*)nullptr, (const uint8_t*)nullptr, x, gamma,
+  const ApplyGrid ag = apply_grid(p, M);
+  const dim3 grid(ag.nblk, p.GY);
+#ifdef SSV_EXP_SKIP_APPLY
+  return SSV_OK;
+#endif
+  hipLaunchKernelGGL((bn_bwd_apply_k<0, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, ag.rpb, g, (const float*)nullptr, (const uint8_t*)nullptr, x, gamma,
                      save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, (const float*)k1, (const float*)k2, dx, (float*)nullptr);
   SSV_CHECK_LAUNCH("ssv_bn_bwd_from_partials");
   return SSV_OK;

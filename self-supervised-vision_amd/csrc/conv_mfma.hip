@@ -29,6 +29,13 @@
 #include <string.h>
 #include <type_traits>
 
+#ifndef SSV_EXP_LDS_PAD
+#define SSV_EXP_LDS_PAD 0   // diagnostic builds only: extra LDS floats per forward / data-gradient workgroup (forces a lower occupancy)
+#endif
+#ifndef SSV_CONV_WGPC
+#define SSV_CONV_WGPC 3     // resident workgroups per CU the forward / data-gradient kernels are compiled for
+#endif
+
 namespace {
 
 constexpr int GBK = 16;   // K-step of the generic (scalar gather) path and the granularity of wgrad row chunks
@@ -402,14 +409,14 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // forward
 // =============================================================================================
 template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0>
-__global__ void __launch_bounds__(256, 3)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+__global__ void __launch_bounds__(256, SSV_CONV_WGPC)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;                   // ROWK row stride: 16-lane b128 read groups hit 16 distinct 16-B slots
   constexpr int STAGE = (BM + BN) * LDT;
   static_assert(!XF || (VEC && !C4), "the fused-input variant is the float4 path");
-  __shared__ __attribute__((aligned(16))) float smem[STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[STAGE + SSV_EXP_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
   float* As = smem;
   float* Bs = smem + BM * LDT;
@@ -678,12 +685,12 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
 template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false, int GATE = 0>
-__global__ void __launch_bounds__(256, 3)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+__global__ void __launch_bounds__(256, SSV_CONV_WGPC)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;
   constexpr int A_FLOATS = BM * LDT, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
-  __shared__ __attribute__((aligned(16))) float smem[STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[STAGE + SSV_EXP_LDS_PAD];
   __shared__ unsigned rowpix[BM];
   __shared__ int taps[64 * 3];      // (dho, dwo, tapoff) per valid tap
   __shared__ int ntaps_s;
