@@ -103,6 +103,21 @@ typedef struct ssv_bn_gate {
 int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d);
 int ssv_conv2d_fwd_gated(const ssv_conv_desc* d, const float* x, const float* w, const float* addend, float* y,
                          const ssv_bn_gate* gate, void* stream);
+/* The SECOND half of that backward fused into its consumers (networks/resnet.py:66-75 backwards: conv3 / downsample are 1x1): the
+ * BatchNorm backward's dx = A[c] * g + B[c] * (x - mean[c]) + D[c] is formed by the consuming kernels while they stage it, from the gated
+ * gradient g, the BatchNorm's input x and coef = [A | mean | B | D] ([4][channels], ssv_bn_bwd_coef) - the element-wise apply pass
+ * ssv_bn_bwd_from_partials would run over (g, x) -> dx does not exist.  1x1 / stride-1 / unpadded convolutions only. */
+typedef struct ssv_bn_dyin {
+  const float* x;               /* input of the BatchNorm whose backward this is: same shape as g */
+  const float* coef;            /* [4][channels] from ssv_bn_bwd_coef */
+} ssv_bn_dyin;
+/* y = conv1x1(dx(g, dyin), w) (+ addend), optional gate on y (NULL = none): the data gradient of a 1x1 convolution, run as a forward
+ * convolution with the transposed filter.  d->C = channels of g (% 32 == 0), d->K % 4 == 0 */
+int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend, float* y,
+                        const ssv_bn_gate* gate, void* stream);
+/* dw (+)= x (*) dx(g, dyin); x may be a raw conv output with (in_scale, in_shift) as in ssv_conv2d_wgrad_bnrelu_in.  d->K >= 128 */
+int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* g,
+                          const ssv_bn_dyin* dyin, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* ssv_conv2d_dgrad with the gate.  K % 32 == 0, C % 4 == 0 */
 int64_t ssv_conv2d_dgrad_gate_groups(const ssv_conv_desc* d);
 int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend, float* dx,
@@ -160,6 +175,11 @@ int ssv_bn_relu_bwd_affine(int64_t M, int32_t C, const float* dy, const float* x
 int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, const float* x, const float* gamma,
                              const float* save_mean, const float* save_invstd, const float* psum_g, const float* psum_gx, int64_t groups,
                              float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same merge WITHOUT the apply pass: dgamma / dbeta as above and coef = [A | mean | B | D] ([4][C]) of
+ * dx = A * g + B * (x - mean) + D, for ssv_conv2d_fwd_dyin / ssv_conv2d_wgrad_dyin. */
+int ssv_bn_bwd_coef(int64_t M, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
+                    const float* psum_g, const float* psum_gx, int64_t groups, float* coef, float* dgamma, float* dbeta, int accumulate,
+                    void* ws, size_t ws_bytes, void* stream);
 /* The image stem's BatchNorm + ReLU + MaxPool2d(3, 2, 1) (networks/resnet.py:147-148 `maxpool(relu(bn1(conv1(x))))`) as one pass each way:
  * forward reads the raw conv output y [N,H,W,C] once and writes only the pooled map [N,Ho,Wo,C] + its argmax slots (scale / shift from
  * ssv_bn_stats_finalize); backward forms the gradient w.r.t. the BatchNorm output on the fly (gather over the <= 2x2 windows that chose the

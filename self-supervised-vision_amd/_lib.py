@@ -26,6 +26,10 @@ class BnGate(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx")]
 
 
+class BnDyin(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "coef")]
+
+
 class AugCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("brightness", "contrast", "saturation", "hue", "p_jitter", "p_gray", "p_flip",
                                           "scale_min", "scale_max", "ratio_min", "ratio_max")]
@@ -60,6 +64,9 @@ SIGNATURES = {
     "ssv_conv2d_dgrad_gate_groups": (_i64, [_cd]),
     "ssv_conv2d_dgrad_gated": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
     "ssv_bn_bwd_from_partials": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_bn_bwd_coef": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_conv2d_fwd_dyin": (C.c_int, [_cd, _vp, C.POINTER(BnDyin), _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
+    "ssv_conv2d_wgrad_dyin": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnDyin), _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_bn_workspace_bytes": (_sz, [_i64, _i32]),

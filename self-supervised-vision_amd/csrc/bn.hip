@@ -267,7 +267,9 @@ bn_bwd_reduce_k(int64_t M, int C, int CT, int RT, int rpb, const float* __restri
 
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, const float* __restrict__ psgx,
-                  float* dgamma, float* dbeta, int accumulate, float* __restrict__ k1, float* __restrict__ k2) {
+                  float* dgamma, float* dbeta, int accumulate, float* __restrict__ k1, float* __restrict__ k2,
+                  const float* __restrict__ gamma = nullptr, const float* __restrict__ mean = nullptr, const float* __restrict__ invstd = nullptr,
+                  float* __restrict__ coef = nullptr) {
   __shared__ double s1[FIN_G][FIN_C], s2[FIN_G][FIN_C];
   const int cl = threadIdx.x % FIN_C, grp = threadIdx.x / FIN_C;
   const int c = blockIdx.x * FIN_C + cl;
@@ -284,8 +286,14 @@ bn_bwd_finalize_k(int64_t M, int C, int nblk, const float* __restrict__ psg, con
   if (grp == 0 && ok) {
     sg = 0.0; sgx = 0.0;
     for (int g = 0; g < FIN_G; ++g) { sg += s1[g][cl]; sgx += s2[g][cl]; }
-    k1[c] = (float)(sg / (double)M);
-    k2[c] = (float)(sgx / (double)M);
+    if (k1) { k1[c] = (float)(sg / (double)M); k2[c] = (float)(sgx / (double)M); }
+    if (coef) {      // dx = A * g + B * (x - mean) + D  (ssv_bn_dyin: the consumer convolutions form dx while they stage it)
+      const double gi = (double)gamma[c] * (double)invstd[c];
+      coef[c] = (float)gi;
+      coef[C + c] = mean[c];
+      coef[2 * C + c] = (float)(-gi * (double)invstd[c] * (sgx / (double)M));
+      coef[3 * C + c] = (float)(-gi * (sg / (double)M));
+    }
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
   }
@@ -610,6 +618,34 @@ extern "C" int ssv_bn_bwd_from_partials(int64_t M, int32_t C, const float* g, co
   hipLaunchKernelGGL((bn_bwd_apply_k<0, false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, ag.rpb, g, (const float*)nullptr, (const uint8_t*)nullptr, x, gamma,
                      save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, (const float*)k1, (const float*)k2, dx, (float*)nullptr);
   SSV_CHECK_LAUNCH("ssv_bn_bwd_from_partials");
+  return SSV_OK;
+}
+
+// The same merge without the apply pass: the coefficients of dx = A * g + B * (x - mean) + D per channel, for consumers that form dx while
+// they stage it (ssv_conv2d_fwd_dyin, ssv_conv2d_wgrad_dyin).  coef: [4][C] floats = A | mean | B | D.
+extern "C" int ssv_bn_bwd_coef(int64_t M, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
+                               const float* psum_g, const float* psum_gx, int64_t groups, float* coef, float* dgamma, float* dbeta, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_mc(M, C, "ssv_bn_bwd_coef")) return rc;
+  SSV_REQUIRE(gamma && save_mean && save_invstd && psum_g && psum_gx && groups > 0 && groups < (1ll << 31) && coef && ws, "ssv_bn_bwd_coef: bad arguments");
+  SSV_REQUIRE((((uintptr_t)coef | (uintptr_t)psum_g | (uintptr_t)psum_gx) & 15) == 0, "ssv_bn_bwd_coef: pointers must be 16-byte aligned");
+  if (ws_bytes < ssv_bn_workspace_bytes(M, C)) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_bn_bwd_coef: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_BN_BWD, s);
+  const BnPlan p = bn_plan(M, C);
+  float* k2 = (float*)ws + C;
+  int nblk = (int)groups;
+  if (nblk > 2048) {                                          // two-level merge, as in ssv_bn_bwd_from_partials
+    const int cap = p.nblk;
+    const int factor = cdiv(nblk, 32) > cap ? cdiv(nblk, cap) : 32, ncoarse = cdiv(nblk, factor);
+    float* c1 = k2 + C;
+    float* c2 = c1 + (size_t)ncoarse * C;
+    hipLaunchKernelGGL(bn_sums_coarsen_k, dim3(cdiv(C, 256), ncoarse), dim3(256), 0, s, C, nblk, factor, psum_g, psum_gx, c1, c2);
+    psum_g = c1; psum_gx = c2; nblk = ncoarse;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, nblk, psum_g, psum_gx, dgamma, dbeta, accumulate,
+                     (float*)nullptr, (float*)nullptr, gamma, save_mean, save_invstd, coef);
+  SSV_CHECK_LAUNCH("ssv_bn_bwd_coef");
   return SSV_OK;
 }
 

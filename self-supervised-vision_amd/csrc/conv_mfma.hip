@@ -61,6 +61,8 @@ struct ConvKP {
   const float* xf_scale;  // XF variants: per-input-channel affine of the fused BatchNorm + ReLU applied to the staged input
   const float* xf_shift;
   ssv_bn_gate gate;       // GATE variants (this launch computes the gradient w.r.t. a BatchNorm + ReLU output): see epilogue_vec
+  const float* dyin_x;    // DYF variants: the staged operand is the BatchNorm backward's dx = A[k] * g + B[k] * (x - mean[k]) + D[k], formed
+  const float* dyin_coef; //   on load from the gated gradient g (the operand pointer) and the BatchNorm's input x; coef = A | mean | B | D
 };
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
@@ -191,13 +193,18 @@ __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[
 
 // K loop over staged tiles: ONE LDS stage, two barriers per tile (small LDS footprint -> 3 workgroups per CU hide each other's
 // barriers).  load_tile() issues the next tile's global loads into registers, store_tile(0) writes those registers to LDS.
-template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int NLD, class LoadTile, class StoreTile>
+// xform_tile(): register-to-register transform of the prefetched tile (fused BatchNorm input / BatchNorm-backward operand), run right before
+// the tile is stored to LDS.  (Measured: issuing it under the last substep's MFMAs instead is SLOWER, 254.3 -> 256.0 ms per step - its
+// s_waitcnt for the prefetched loads then stalls that wave's MFMA stream one substep early.)
+struct NoXform { __device__ __forceinline__ void operator()() const {} };
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int NLD, class LoadTile, class StoreTile, class Xform = NoXform>
 __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs, int wr0, int wc0, int lane,
-                                       f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile) {
+                                       f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile, Xform&& xform_tile = NoXform()) {
   if (nkt <= 0) return;
   constexpr int NS = BK / 8;
   constexpr int NM = 4 * TM * TN;            // MFMAs per substep
   load_tile();
+  xform_tile();
   store_tile(0);
   __syncthreads();
   {
@@ -219,7 +226,7 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
       STAMP(t_mma);
       __syncthreads();
       STAMP(t_b1);
-      if (more) { store_tile(0); STAMP(t_st); __syncthreads(); STAMP(t_b2); }
+      if (more) { xform_tile(); store_tile(0); STAMP(t_st); __syncthreads(); STAMP(t_b2); }
     }
 #else
     // Branch-free body (one scheduling region per tile): the next tile's NLD buffer loads are issued one per MFMA of
@@ -242,7 +249,7 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
         mma_frags<TM, TN>(fr, acc);
       }
       __syncthreads();
-      if (kt + 1 < nkt) { store_tile(0); __syncthreads(); }
+      if (kt + 1 < nkt) { xform_tile(); store_tile(0); __syncthreads(); }
     }
 #endif
 #ifdef SSV_STAMP
@@ -408,14 +415,18 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0>
-__global__ void __launch_bounds__(256, SSV_CONV_WGPC)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+// DYF (1x1 / stride 1 / no padding only - the data gradient of a 1x1 convolution run as a forward convolution): the A operand is the
+// second half of the BatchNorm backward, dx = A[k] * g + B[k] * (x - mean[k]) + D[k], formed while it is staged - the element-wise apply
+// pass over (g, x) -> dx of that BatchNorm disappears (it ran AT the HBM roofline and overlapped with nothing: 23 ms of a 257 ms step).
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, bool DYF = false>
+__global__ void __launch_bounds__(256, DYF ? 2 : SSV_CONV_WGPC)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;                   // ROWK row stride: 16-lane b128 read groups hit 16 distinct 16-B slots
   constexpr int STAGE = (BM + BN) * LDT;
   static_assert(!XF || (VEC && !C4), "the fused-input variant is the float4 path");
+  static_assert(!DYF || (VEC && !C4 && !XF), "the BatchNorm-backward operand is the float4 path");
   __shared__ __attribute__((aligned(16))) float smem[STAGE + SSV_EXP_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
   float* As = smem;
@@ -515,6 +526,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;     // 1x1 / no padding: every tap of a valid row is in bounds
     int lr = 0, ls = 0, lc0 = 0;   // loader position (tap r, s, first channel)
     f32x4 ra[AP], rb[BP];
+    f32x4 ra2[DYF ? AP : 1], co[DYF ? 4 : 1];
+    const rsrc_t rx2 = make_rsrc(DYF ? p.dyin_x : x, (unsigned)p.N * p.H * p.W * p.C * 4u);
+    const rsrc_t rco = make_rsrc(DYF ? p.dyin_coef : x, DYF ? (unsigned)p.C * 16u : 16u);
     int xf_ok = 0, xf_c = 0;       // XF: which of the staged rows hold real pixels (bit i), first channel of this thread's float4
     if constexpr (XF) {
       for (int c = tid; c < p.C; c += 256) { xfs[c] = p.xf_scale[c]; xfs[XF_MAXC + c] = p.xf_shift[c]; }
@@ -528,7 +542,12 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       for (int i = 0; i < AP; ++i) {
         const bool ok = inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W));
         ra[i] = bload4(rx, ok ? aoff[i] + toff_x : OOB_OFF, 0);
+        if constexpr (DYF) ra2[i] = bload4(rx2, ok ? aoff[i] + toff_x : OOB_OFF, 0);
         if constexpr (XF) xf_ok |= (int)ok << i;
+      }
+      if constexpr (DYF) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) co[j] = bload4(rco, (j * p.C + chunk) * 4, lc0 * 4);
       }
 #pragma unroll
       for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
@@ -544,7 +563,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       lr = w2 ? 0 : lr;
       lc0 += w2 ? BK : 0;
     };
-    auto store_tile = [&](int buf) {
+    auto xform_tile = [&]() {
       if constexpr (XF) {
         // the staged values are the producer's raw conv output: apply its BatchNorm + ReLU here (same fmaf / fmaxf as bn_apply_k,
         // so the operand is bit-identical to the materialised activation); padding taps stay exactly zero.  A row past M keeps
@@ -552,22 +571,28 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         const f32x4 sc = *reinterpret_cast<const f32x4*>(&xfs[xf_c]), sh = *reinterpret_cast<const f32x4*>(&xfs[XF_MAXC + xf_c]);
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-          f32x4 v = ra[i];
           // ReLU and "a padding tap stays zero" in ONE instruction per element: clamp to [0, cap] with cap = +inf for a real pixel and
           // 0 for a padding tap (v_med3_f32) - the staged transform costs 2 VALU per element instead of 3
           const float cap = (inb || ((xf_ok >> i) & 1)) ? __builtin_inff() : 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f, cap);
-          *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = v;
+          for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(ra[i][e], sc[e], sh[e]), 0.f, cap);
         }
-      } else {
+      } else if constexpr (DYF) {
+        // a row past M holds D - mean * B instead of zero: harmless, its output row is never stored nor counted
 #pragma unroll
-        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = ra[i];
+        for (int i = 0; i < AP; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_fmaf(ra[i][e], co[0][e], __builtin_fmaf(ra2[i][e] - co[1][e], co[2][e], co[3][e]));
+        }
       }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
       for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (DYF ? AP + 4 : 0)>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
     static_assert(BK == GBK, "generic path is BK=16");
@@ -852,13 +877,15 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 //           (ho, wo) kept incrementally per staged row - no division in the loop)
 // XF: x is the producer's RAW conv output; the X operand is relu(x * xf_scale[c] + xf_shift[c]) (the activation the forward never
 //     materialised), formed on the way into LDS.  A thread's four channels are loop constants, so are its scale / shift registers.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false>
+// DYF (LIN gather only): the dY operand is formed on load from (g, x of the BatchNorm behind this convolution, coefficients) - see conv_fwd_k.
+template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false>
 __global__ void __launch_bounds__(256)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int STAGE = BK * (BM + BN);
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);            // the vectorised epilogue's staging area (one 32-row slab per wave)
   static_assert(!XF || VECB, "the fused-input variant is the float4 path");
+  static_assert(!DYF || (VECB && GATHER == 1), "the BatchNorm-backward operand: 1x1 / stride 1 layers");
   __shared__ __attribute__((aligned(16))) float smem[STAGE > EP_FLOATS ? STAGE : EP_FLOATS];
   float* As = smem;               // [BK][BM]
   float* Bs = smem + BK * BM;     // [BK][BN]
@@ -899,6 +926,13 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   f32x4 rbv[VECB ? BP : 1];
   float rbs[VECB ? 1 : BP];
   int avoff[AP], bvoff[BP];
+  f32x4 ra2[DYF ? AP : 1], dco[DYF ? 4 : 1];
+  const rsrc_t rdx = make_rsrc(DYF ? p.dyin_x : dy, (unsigned)p.M * p.K * 4u);
+  int a_ok = 0;
+  if constexpr (DYF) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dco[j] = acok ? *reinterpret_cast<const f32x4*>(p.dyin_coef + (size_t)j * p.K + i0 + acol) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   int xf_ok = 0;
   f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};
   if constexpr (XF) { if (jok) { xsc = *reinterpret_cast<const f32x4*>(p.xf_scale + cj); xsh = *reinterpret_cast<const f32x4*>(p.xf_shift + cj); } }
@@ -924,6 +958,11 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
     const int soff_a = mcur * p.K * 4;
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[i] = bload4(rdy, avoff[i], soff_a);
+    if constexpr (DYF) {
+      a_ok = 0;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) { ra2[i] = bload4(rdx, avoff[i], soff_a); a_ok |= (int)(mcur + arow + ARP * i < p.M) << i; }
+    }
     if constexpr (GATHER == 1) {
       const int soff_b = mcur * p.C * 4;
 #pragma unroll
@@ -971,24 +1010,36 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
     }
     mcur += BK;
   };
+  auto xform_tile = [&]() {
+    if constexpr (DYF) {         // rows past M must contribute nothing (g and x read as zeros there, the affine form would not)
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const bool ok = (a_ok >> i) & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[i][e] = ok ? __builtin_fmaf(ra[i][e], dco[0][e], __builtin_fmaf(ra2[i][e] - dco[1][e], dco[2][e], dco[3][e])) : 0.f;
+      }
+    }
+    if constexpr (XF) {
+      // same fmaf / fmaxf as bn_apply_k: bit-identical to the materialised activation; padding taps (and, in the LIN mode, rows
+      // past M, whose dY rows are zero anyway) must not pick up relu(shift)
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const float cap = (GATHER == 1 || ((xf_ok >> i) & 1)) ? __builtin_inff() : 0.f;      // ReLU + zero padding tap as one clamp (v_med3_f32)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rbv[i][e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(rbv[i][e], xsc[e], xsh[e]), 0.f, cap);
+      }
+    }
+  };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      if constexpr (XF) {
-        // same fmaf / fmaxf as bn_apply_k: bit-identical to the materialised activation; padding taps (and, in the LIN mode, rows
-        // past M, whose dY rows are zero anyway) must not pick up relu(shift)
-        f32x4 v = rbv[i];
-        const float cap = (GATHER == 1 || ((xf_ok >> i) & 1)) ? __builtin_inff() : 0.f;      // ReLU + zero padding tap as one clamp (v_med3_f32)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(v[e], xsc[e], xsh[e]), 0.f, cap);
-        *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = v;
-      } else if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
+      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
       else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
-  k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
 
   float* out = partial + (size_t)split * p.K * p.RSC;
   if ((p.RSC & 3) == 0) {      // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
@@ -1063,6 +1114,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dS = make_fastdiv((uint32_t)d->S);
   p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr; p.xf_scale = nullptr; p.xf_shift = nullptr;
   memset(&p.gate, 0, sizeof(p.gate));
+  p.dyin_x = nullptr; p.dyin_coef = nullptr;
   return p;
 }
 
@@ -1180,6 +1232,36 @@ extern "C" int ssv_conv2d_fwd_gated(const ssv_conv_desc* d, const float* x, cons
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   launch_fwd(d, x, w, nullptr, addend, y, nullptr, nullptr, nullptr, nullptr, s, gate);
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_gated");
+  return SSV_OK;
+}
+
+// 1x1 / stride-1 forward convolution whose input operand is the BatchNorm backward's dx, formed on load (the data gradient of a 1x1
+// convolution runs here with the transposed filter); optional gate on the output as in ssv_conv2d_fwd_gated.
+extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend, float* y,
+                                   const ssv_bn_gate* gate, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_dyin")) return rc;
+  if (gate) { if (int rc = check_gate(gate, "ssv_conv2d_fwd_dyin")) return rc; }
+  SSV_REQUIRE(g && w && y && dyin && dyin->x && dyin->coef, "ssv_conv2d_fwd_dyin: null pointer");
+  SSV_REQUIRE((((uintptr_t)g | (uintptr_t)w | (uintptr_t)y | (uintptr_t)addend | (uintptr_t)dyin->x | (uintptr_t)dyin->coef) & 15) == 0,
+              "ssv_conv2d_fwd_dyin: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->C % 32 == 0 && d->K % 4 == 0,
+              "ssv_conv2d_fwd_dyin: a 1x1 / stride-1 / unpadded convolution with C %% 32 == 0 and K %% 4 == 0 (got %dx%d s%d p%d C=%d K=%d)",
+              d->R, d->S, d->stride, d->pad, d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.dyin_x = dyin->x; p.dyin_coef = dyin->coef;
+  if (gate) p.gate = *gate;
+  const bool wide = d->K >= 128;
+  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+  const int gm = gate ? (gate->mask ? 2 : 1) : 0;
+#define FWDD(BM_, BN_, WM_, WN_, G_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, true>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+#define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
+  if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
+#undef FWDD_TILE
+#undef FWDD
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_dyin");
   return SSV_OK;
 }
 
@@ -1319,8 +1401,28 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
   return ssv_conv2d_wgrad_bnrelu_in(d, x, nullptr, nullptr, dy, dw, accumulate, ws, ws_bytes, stream);
 }
 
+namespace {
+int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy, const ssv_bn_dyin* dyin,
+               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+}
 extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy,
                                           float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return wgrad_impl(d, x, in_scale, in_shift, dy, nullptr, dw, accumulate, ws, ws_bytes, stream);
+}
+
+// Weight gradient of a 1x1 / stride-1 convolution whose dY operand is the BatchNorm backward's dx, formed on load from (g, dyin).
+extern "C" int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* g,
+                                     const ssv_bn_dyin* dyin, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(dyin && dyin->x && dyin->coef, "ssv_conv2d_wgrad_dyin: null operand description");
+  SSV_REQUIRE((((uintptr_t)dyin->x | (uintptr_t)dyin->coef) & 15) == 0, "ssv_conv2d_wgrad_dyin: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K >= 128 && d->C % 4 == 0,
+              "ssv_conv2d_wgrad_dyin: a 1x1 / stride-1 / unpadded convolution with K >= 128 and C %% 4 == 0");
+  return wgrad_impl(d, x, in_scale, in_shift, g, dyin, dw, accumulate, ws, ws_bytes, stream);
+}
+
+namespace {
+int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy, const ssv_bn_dyin* dyin,
+               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_desc(d, "ssv_conv2d_wgrad")) return rc;
   SSV_REQUIRE(x && dy && dw && ws, "ssv_conv2d_wgrad: null pointer");
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0, "ssv_conv2d_wgrad: pointers must be 16-byte aligned");
@@ -1335,6 +1437,7 @@ extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x
   ProfScope ps(SSV_PROF_CONV_WGRAD, s);
   ConvKP p = make_kp(d);
   p.xf_scale = in_scale; p.xf_shift = in_shift;
+  if (dyin) { p.dyin_x = dyin->x; p.dyin_coef = dyin->coef; }
   const bool vecb = d->C % 4 == 0;
   const int tiles = wp.it * wp.jt;
   const dim3 grid((unsigned)(tiles * wp.nsplit));
@@ -1344,10 +1447,15 @@ extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x
   const int gather = (d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1) ? 1 : (s1ok ? 2 : 0);
 #define WG_LAUNCH(BM_, BN_, WM_, WN_, B_, V_, G_, X_) \
   hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, B_, V_, G_, X_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define WG_DYIN(BM_, BN_, WM_, WN_, X_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, X_, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
 #define WG_GATHER(BM_, BN_, WM_, WN_, X_) \
   do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 1, X_); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 2, X_); \
        else WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 0, X_); } while (0)
-  if (!vecb) {
+  if (dyin) {                                      // preconditions checked by ssv_conv2d_wgrad_dyin: LIN gather, 128-row tiles, float4 columns
+    if (wp.bn == 64) { if (xf) WG_DYIN(128, 64, 2, 2, true); else WG_DYIN(128, 64, 2, 2, false); }
+    else             { if (xf) WG_DYIN(128, 128, 2, 2, true); else WG_DYIN(128, 128, 2, 2, false); }
+  } else if (!vecb) {
     if (wp.bm == 128) WG_LAUNCH(128, 128, 2, 2, GBK, false, 0, false);
     else              WG_LAUNCH(64, 128, 1, 4, GBK, false, 0, false);
   } else if (wp.bn == 64) {                       // RSC <= 64 (and C % 4 == 0): 64-wide column tile
@@ -1359,6 +1467,7 @@ extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x
     if (xf) WG_GATHER(64, 128, 1, 4, true); else WG_GATHER(64, 128, 1, 4, false);
   }
 #undef WG_GATHER
+#undef WG_DYIN
 #undef WG_LAUNCH
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(partial)");
   const int64_t n = (int64_t)d->K * p.RSC;
@@ -1366,6 +1475,7 @@ extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(reduce)");
   return SSV_OK;
 }
+}  // namespace
 
 #ifdef SSV_STAMP
 extern "C" int ssv_debug_stamps(unsigned long long* out_host, int reset) {

@@ -177,6 +177,11 @@ _PAD_STEM = os.environ.get("SSV_NO_STEM_PADDING", "0") != "1"
 
 _FUSE_BN_APPLY = os.environ.get("SSV_NO_BN_APPLY_FUSION", "0") != "1"      # diagnostic switch: materialise every activation
 _FUSE_BN_BWD = os.environ.get("SSV_NO_BN_BWD_FUSION", "0") != "1"          # diagnostic switch: BatchNorm backward with its own reduction pass
+_FUSE_BN_DY = os.environ.get("SSV_NO_BN_DY_FUSION", "0") != "1"            # diagnostic switch: BatchNorm backward always writes dx
+# ... for feature maps of at least this many pixels.  Forming dx on load costs the consumers a second operand stream and ~3 VALU per element
+# between their barriers; it pays where the removed pass is long (56x56 / 28x28 maps: 257.3 -> 254.6 ms per step at bs 512) and not on the
+# small deep maps (all layers: 256.9 ms) - measured with SSV_BN_DY_MIN_HW = 0 / 784 / 3136 / off, three runs each.
+_BN_DY_MIN_HW = int(os.environ.get("SSV_BN_DY_MIN_HW", "784"))
 _FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
 
 
@@ -220,6 +225,8 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
             y._bn_partials = (fused[1], fused[2])
         else:
             y = ops.conv2d_fwd(x, weight, stride, pad, bias=bias)
+    if tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW:
+        y._lazy_dy_ok = True       # a BatchNorm behind this output may hand its backward over as an ops.LazyGrad (formed by wgrad / dgrad)
     if tape is not None:
         need_dx = lazy is not None or tape.needs_grad(x)
 
@@ -327,6 +334,9 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
 
                 def bwd_lazy(dact, existing):
                     part = dact.__dict__.pop("_gate_partials", None)      # consumed here: the buffer may be reused for another gradient
+                    if part is not None and existing[0] is None and tape.last[0] and getattr(x, "_lazy_dy_ok", False):
+                        coef = ops.bn_bwd_coef(x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
+                        return (ops.LazyGrad(dact, x, coef),)      # dx is formed by the producing convolution's wgrad / dgrad
                     if part is not None:          # the consumer's data gradient already gated dact and reduced it
                         dx = ops.bn_bwd_from_partials(dact, x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
                     elif relu:
@@ -351,7 +361,11 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
 
         def bwd(dy, existing):
             part = dy.__dict__.pop("_gate_partials", None)        # consumed here: dy's buffer goes on as the residual gradient
-            if part is not None:                  # dy arrives relu-gated with its partial sums: no reduction pass, and dresidual IS dy
+            if part is not None and existing[0] is None and tape.last[0] and getattr(x, "_lazy_dy_ok", False):
+                # the second half of the backward is formed by the producing convolution's wgrad / dgrad while they stage it
+                dx = ops.LazyGrad(dy, x, ops.bn_bwd_coef(x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot)))
+                dres = dy if residual is not None else None
+            elif part is not None:                # dy arrives relu-gated with its partial sums: no reduction pass, and dresidual IS dy
                 dx = ops.bn_bwd_from_partials(dy, x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
                 dres = dy if residual is not None else None
             else:

@@ -146,6 +146,32 @@ class BnGateCtx:
         self.x, self.mean, self.invstd, self.mask, self.scale, self.shift = x, mean, invstd, mask, scale, shift
 
 
+class LazyGrad:
+    """The gradient w.r.t. a convolution output x that sits behind a BatchNorm, NOT written to HBM: dx = A[c] * g + B[c] * (x - mean[c])
+    + D[c] with g the (relu-gated) gradient w.r.t. the BatchNorm's output and coef = [A | mean | B | D] from `bn_bwd_coef`.  The producing
+    convolution's weight and data gradient form it while they stage their dY operand (ssv_conv2d_wgrad_dyin / ssv_conv2d_fwd_dyin), so the
+    element-wise pass of the BatchNorm backward does not run (1x1 / stride-1 convolutions: conv3 and the stride-1 projection shortcut of
+    networks/resnet.py:66-75, the widest tensors of a residual unit)."""
+    __slots__ = ("g", "x", "coef")
+
+    def __init__(self, g, x, coef):
+        self.g, self.x, self.coef = g, x, coef
+
+    @property
+    def shape(self):
+        return self.g.shape
+
+
+def can_lazy_dy(w_shape, stride, pad):
+    """Can the weight and data gradient of this convolution take their dY operand as a LazyGrad?"""
+    k, c, r, s_ = w_shape
+    return r == 1 and s_ == 1 and stride == 1 and pad == 0 and k >= 128 and k % 32 == 0 and c % 4 == 0
+
+
+def _dyin_struct(lg, n0, n1):
+    return _lib.BnDyin(ptr(lg.x[n0:n1]), ptr(lg.coef))
+
+
 def _gate_struct(gate, groups, channels, like):
     part = _empty((2, groups, channels), like)
     st = _lib.BnGate(ptr(gate.x), ptr(gate.scale), ptr(gate.shift), ptr(gate.mask), ptr(gate.mean), ptr(gate.invstd), ptr(part[0]), ptr(part[1]))
@@ -164,9 +190,14 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     ``gate`` (BnGateCtx): dx is the gradient w.r.t. a BatchNorm + ReLU output and this call is its LAST contribution - the epilogue
     stores the relu-gated gradient and the partial sums of the BatchNorm backward; they come back as ``dx._gate_partials``
     (psum_g, psum_gx, groups).  Silently ungated when the shape is outside the gated kernels' preconditions."""
+    lazy = dy if isinstance(dy, LazyGrad) else None
+    if lazy is not None:
+        dy = lazy.g
     _lib._dev(dy, w, addend)
     w, wshape = _ohwi(w)
     k, c, r, s_ = wshape
+    if lazy is not None and not can_lazy_dy(wshape, stride, pad):
+        raise _lib.SsvError("conv2d_dgrad: a LazyGrad reached a convolution that cannot form it (the producer must check ops.can_lazy_dy)")
     dx = out if out is not None else _empty(tuple(x_shape), dy)
     dx.__dict__.pop("_gate_partials", None)            # an accumulated-into buffer never keeps the partial sums of its old content
     if gate is not None and (k % 32 or c % 4 or tuple(gate.x.shape) != tuple(dx.shape)):
@@ -185,7 +216,15 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
             d = conv_desc(dyc.shape, (c, k, r, s_), 1, r - 1 - pad)
             if (d.Ho, d.Wo) != (x_shape[1], x_shape[2]):
                 raise _lib.SsvError("conv2d_dgrad: input shape does not match the stride-1 geometry")
-            if gate is not None:
+            if lazy is not None:
+                st = None
+                if gate is not None:
+                    groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))
+                    st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
+                    parts.append(part)
+                dyin = _dyin_struct(lazy, n0, n1)
+                call("ssv_conv2d_fwd_dyin", C.byref(d), ptr(dyc), C.byref(dyin), ptr(wt), ptr(adc), ptr(dxc), None if st is None else C.byref(st), stream())
+            elif gate is not None:
                 groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))
                 st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
                 call("ssv_conv2d_fwd_gated", C.byref(d), ptr(dyc), ptr(wt), ptr(adc), ptr(dxc), C.byref(st), stream())
@@ -210,14 +249,23 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
 def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None):
     """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI).  ``in_affine = (scale, shift)``: x is a raw conv output and
     the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation)."""
+    lazy = dy if isinstance(dy, LazyGrad) else None
+    if lazy is not None:
+        dy = lazy.g
     _lib._dev(x, dy, dw)
     _, wshape = _ohwi(w_like)
+    if lazy is not None and not can_lazy_dy(wshape, stride, pad):
+        raise _lib.SsvError("conv2d_wgrad: a LazyGrad reached a convolution that cannot form it (the producer must check ops.can_lazy_dy)")
     lib = _lib.load()
     sc, sh = in_affine if in_affine is not None else (None, None)
     for i, (n0, n1) in enumerate(_batch_chunks(x.shape[0], (x[0].numel(), dy[0].numel()))):
         xc, dyc = x[n0:n1], dy[n0:n1]
         d = conv_desc(xc.shape, wshape, stride, pad)
         ws = workspace.get(lib.ssv_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
+        if lazy is not None:
+            dyin = _dyin_struct(lazy, n0, n1)
+            call("ssv_conv2d_wgrad_dyin", C.byref(d), ptr(xc), ptr(sc), ptr(sh), ptr(dyc), C.byref(dyin), ptr(dw), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
+            continue
         call("ssv_conv2d_wgrad_bnrelu_in", C.byref(d), ptr(xc), ptr(sc), ptr(sh), ptr(dyc), ptr(dw), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
     return dw
 
@@ -288,6 +336,17 @@ def bn_bwd_from_partials(g, x, gamma, mean, invstd, partials, dgamma, dbeta, acc
     call("ssv_bn_bwd_from_partials", m, c, ptr(g), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(partials[0]), ptr(partials[1]), int(partials[2]),
          ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
     return dx
+
+
+def bn_bwd_coef(x, gamma, mean, invstd, partials, dgamma, dbeta, accumulate=True):
+    """The merge of `bn_bwd_from_partials` without its element-wise pass: dgamma / dbeta and the [4, C] coefficients of a LazyGrad."""
+    _lib._dev(x, gamma)
+    m, c = _rows(x)
+    coef = torch.empty((4, c), dtype=torch.float32, device=x.device)
+    ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
+    call("ssv_bn_bwd_coef", m, c, ptr(gamma), ptr(mean), ptr(invstd), ptr(partials[0]), ptr(partials[1]), int(partials[2]),
+         ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
+    return coef
 
 
 def bn_train_bwd(dy, y, x, gamma, mean, invstd, relu, dgamma, dbeta, want_dres=False, accumulate=True, relu_mask=None):

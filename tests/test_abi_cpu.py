@@ -30,7 +30,9 @@ class AugCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("brightness", "contrast", "saturation", "hue", "p_jitter", "p_gray", "p_flip", "scale_min", "scale_max", "ratio_min", "ratio_max")]
 class BnGate(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx")]
-PTR = {"p_conv": C.POINTER(ConvDesc), "p_aug": C.POINTER(AugCfg), "p_gate": C.POINTER(BnGate), "p_f32": C.POINTER(C.c_float),
+class BnDyin(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "coef")]
+PTR = {"p_conv": C.POINTER(ConvDesc), "p_aug": C.POINTER(AugCfg), "p_gate": C.POINTER(BnGate), "p_dyin": C.POINTER(BnDyin), "p_f32": C.POINTER(C.c_float),
        "p_f64": C.POINTER(C.c_double), "p_i64": C.POINTER(C.c_int64)}
 host = (C.c_float * 4096)()                      # a HOST buffer: fine for argument checks, never dereferenced by host code
 hp = C.cast(host, C.c_void_p).value
@@ -52,6 +54,8 @@ def build(kind, mode):
         return C.pointer(d)
     if kind == "p_gate":
         return C.POINTER(BnGate)() if mode == "null" else C.pointer(BnGate())          # all-NULL members: an incomplete gate
+    if kind == "p_dyin":
+        return C.POINTER(BnDyin)() if mode == "null" else C.pointer(BnDyin())          # all-NULL members: an incomplete operand description
     if kind == "p_aug":
         return C.POINTER(AugCfg)() if mode == "null" else C.pointer(AugCfg())
     return PTR[kind]() if mode == "null" else C.cast(hp, PTR[kind])
@@ -79,7 +83,7 @@ _KIND = {C.c_void_p: "void_p", C.c_int32: "i32", C.c_int64: "i64", C.c_float: "f
 
 def _signatures():
     from ssv_amd import _lib
-    ptrs = {C.POINTER(_lib.ConvDesc): "p_conv", C.POINTER(_lib.AugCfg): "p_aug", C.POINTER(_lib.BnGate): "p_gate", C.POINTER(C.c_float): "p_f32",
+    ptrs = {C.POINTER(_lib.ConvDesc): "p_conv", C.POINTER(_lib.AugCfg): "p_aug", C.POINTER(_lib.BnGate): "p_gate", C.POINTER(_lib.BnDyin): "p_dyin", C.POINTER(C.c_float): "p_f32",
             C.POINTER(C.c_double): "p_f64", C.POINTER(C.c_int64): "p_i64"}
     kind = lambda t: _KIND.get(t) or ptrs[t]
     return {name: (kind(res), [kind(a) for a in args]) for name, (res, args) in _lib.SIGNATURES.items()}
@@ -115,7 +119,7 @@ def _check(result):
         # status-returning entry points: never SSV_OK on NULL pointers, and never anything but a declared status
         if not all(g in (0, -1, -2, -3) for g in got):
             bad.append((name, "undeclared status", got))
-        if got[0] == 0 and any(a in ("void_p", "p_conv", "p_gate", "p_aug", "p_f32", "p_f64", "p_i64") for a in sigs[name][1]):
+        if got[0] == 0 and any(a in ("void_p", "p_conv", "p_gate", "p_dyin", "p_aug", "p_f32", "p_f64", "p_i64") for a in sigs[name][1]):
             bad.append((name, "accepted NULL pointers", got))
         if "p_conv" in sigs[name][1] and got[1] != -1:
             bad.append((name, "accepted an inconsistent conv descriptor", got))

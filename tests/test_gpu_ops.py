@@ -471,3 +471,62 @@ def test_batches_beyond_the_per_launch_limit_are_split_on_the_host(dev, monkeypa
     for a, b in zip(whole[6], split[6]):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-4)
     close(split[7], whole[7], rtol=1e-5, what="wgrad over chunks")
+
+
+@pytest.mark.parametrize("n,h,cin,k,xf,gate_kind", [(3, 7, 64, 256, False, None), (2, 9, 64, 256, True, "affine"), (3, 7, 256, 512, False, "mask"),
+                                                   (5, 5, 128, 512, True, None), (2, 6, 512, 2048, False, "affine")])
+def test_batchnorm_backward_formed_by_the_consumers_of_dx(dev, n, h, cin, k, xf, gate_kind):
+    """ops.LazyGrad: conv3 / projection-shortcut gradients (networks/resnet.py:66-75 backwards) take the BatchNorm backward's dx =
+    gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) as (g, x, coefficients) and form it while they stage it; the result must be
+    the weight / data gradient computed from the materialised dx (ssv_bn_bwd_from_partials), ragged row counts, fused inputs and gated
+    outputs included."""
+    from ssv_amd import ops
+    m = n * h * h
+    g = seeded_randn(901, n, h, h, k).to(dev)
+    x = (seeded_randn(902, n, h, h, k) * 1.7 + 0.6).to(dev)                     # the BatchNorm's input (conv output), mean far from 0
+    gamma = (torch.rand(k, generator=torch.Generator().manual_seed(5)) + 0.5).to(dev)
+    xf64 = x.double().reshape(m, k)
+    mean64, var64 = xf64.mean(0), xf64.var(0, unbiased=False)
+    mean, invstd = mean64.float(), (1.0 / torch.sqrt(var64 + 1e-5)).float()
+    xhat = (xf64 - mean64) / torch.sqrt(var64 + 1e-5)
+    g64 = g.double().reshape(m, k)
+    groups = -(-m // 64)
+    pg = torch.zeros(groups, k, dtype=torch.float64, device=dev)
+    pgx = torch.zeros_like(pg)
+    for i in range(groups):
+        pg[i] = g64[64 * i:64 * i + 64].sum(0)
+        pgx[i] = (g64[64 * i:64 * i + 64] * xhat[64 * i:64 * i + 64]).sum(0)
+    part = (pg.float().contiguous(), pgx.float().contiguous(), groups)
+    dga, dba, dgb, dbb = (torch.zeros(k, device=dev) for _ in range(4))
+    dx = ops.bn_bwd_from_partials(g, x, gamma, mean, invstd, part, dga, dba, accumulate=False)
+    coef = ops.bn_bwd_coef(x, gamma, mean, invstd, part, dgb, dbb, accumulate=False)
+    assert torch.equal(dga, dgb) and torch.equal(dba, dbb)
+    want = gamma.double() * invstd.double() * (g64 - g64.mean(0) - xhat * (g64 * xhat).mean(0))
+    close(dx.reshape(m, k), want.float(), rtol=1e-4, what="materialised dx")
+    lazy = ops.LazyGrad(g, x, coef)
+    # the convolution behind the BatchNorm: 1x1, cin -> k
+    w = (seeded_randn(903, k, cin, 1, 1) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    xin = seeded_randn(904, n, h, h, cin).to(dev)
+    aff = None
+    if xf:
+        aff = ((torch.rand(cin, generator=torch.Generator().manual_seed(6)) + 0.5).to(dev), seeded_randn(905, cin).to(dev) * 0.3)
+    dw1, dw2 = torch.zeros_like(w), torch.zeros_like(w)
+    ops.conv2d_wgrad(xin, dx, w, dw1, 1, 0, accumulate=False, in_affine=aff)
+    ops.conv2d_wgrad(xin, lazy, w, dw2, 1, 0, accumulate=False, in_affine=aff)
+    close(dw2, dw1, rtol=2e-5, what="weight gradient from the lazy dx")
+    addend = seeded_randn(906, n, h, h, cin).to(dev)
+    gate = None
+    if gate_kind is not None:
+        gx = seeded_randn(907, n, h, h, cin).to(dev)
+        gm, gi = gx.reshape(-1, cin).mean(0), 1.0 / torch.sqrt(gx.reshape(-1, cin).var(0, unbiased=False) + 1e-5)
+        if gate_kind == "affine":
+            gate = ops.BnGateCtx(gx, gm, gi, scale=gi.clone(), shift=(-gm * gi))
+        else:
+            mask = torch.randint(0, 16, (m * cin // 4,), dtype=torch.uint8, generator=torch.Generator().manual_seed(8)).to(dev)
+            gate = ops.BnGateCtx(gx, gm, gi, mask=mask)
+    d1 = ops.conv2d_dgrad(dx, w, xin.shape, 1, 0, addend=addend.clone(), gate=gate)
+    d2 = ops.conv2d_dgrad(lazy, w, xin.shape, 1, 0, addend=addend.clone(), gate=gate)
+    close(d2, d1, rtol=2e-5, what="data gradient from the lazy dx")
+    if gate is not None:
+        for a, b in zip(d1._gate_partials[:2], d2._gate_partials[:2]):
+            close(b.sum(0), a.sum(0), rtol=1e-4, what="gate partial sums")
