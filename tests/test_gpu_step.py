@@ -493,3 +493,37 @@ def test_fused_stem_batchnorm_relu_maxpool_is_bitwise_the_three_kernel_form(dev,
     assert f[0] == u[0] and torch.equal(f[1], u[1]) and torch.equal(f[2], u[2])
     assert torch.equal(f[3], u[3]), f"gradients differ: max {float((f[3] - u[3]).abs().max()):.3e}"
     assert torch.equal(f[4], u[4])
+
+
+@pytest.mark.parametrize("arch,size,b", [("resnet50", 64, 6), ("resnet50", 96, 3)])
+def test_batchnorm_backward_formed_by_its_consumers_matches_the_materialised_form(dev, arch, size, b):
+    """ops.LazyGrad through a whole ResNet-50: behind conv3 and the stride-1 projection shortcut the BatchNorm backward hands (g, x,
+    coefficients) to the convolution's weight / data gradient instead of writing dx.  Same inputs, same weights: the forward is
+    bit-identical and every parameter gradient agrees with the materialised form to rounding level - the two differ only in how
+    dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) is associated (fused multiply-adds on the staged operand)."""
+    from ssv_amd import nn as hnn
+    a1, a2 = seeded_randn(1800, b, 3, size, size), seeded_randn(1801, b, 3, size, size)
+    outs = []
+    prev_hw, hnn._BN_DY_MIN_HW = hnn._BN_DY_MIN_HW, 0            # small inputs: every eligible layer, not only the >= 28x28 maps
+    try:
+        for fuse in (True, False):
+            prev, hnn._FUSE_BN_DY = hnn._FUSE_BN_DY, fuse
+            try:
+                m = _Step(dev, arch, False)
+                loss, z1, z2 = m.step(a1, a2)
+                torch.cuda.synchronize()
+                outs.append((loss, z1.cpu(), m, m.grads.cpu().clone()))
+            finally:
+                hnn._FUSE_BN_DY = prev
+    finally:
+        hnn._BN_DY_MIN_HW = prev_hw
+    (lf, zf, m, gf), (lu, zu, _, gu) = outs
+    assert lf == lu and torch.equal(zf, zu)
+    worst = 0.0
+    for p, off in zip(m.params(), m.optim.arena.offsets):
+        a, r = gf[off:off + p.numel()].double(), gu[off:off + p.numel()].double()
+        if float(r.norm()) < 1e-5:
+            assert float(a.abs().max()) < 1e-5
+            continue
+        worst = max(worst, float((a - r).norm() / r.norm()))
+    assert 0.0 < worst < 2e-5, f"worst per-tensor gradient difference {worst:.2e} (0 = the fused path did not run)"
