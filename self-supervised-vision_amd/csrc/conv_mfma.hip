@@ -32,6 +32,11 @@
 #ifndef SSV_EXP_LDS_PAD
 #define SSV_EXP_LDS_PAD 0   // diagnostic builds only: extra LDS floats per forward / data-gradient workgroup (forces a lower occupancy)
 #endif
+#ifdef SSV_CONV_VGPR          // diagnostic builds only: register cap of the forward / data-gradient kernels (amdgpu_num_vgpr(n) caps the unified file at 2n)
+#define SSV_CONV_ATTR __attribute__((amdgpu_num_vgpr(SSV_CONV_VGPR)))
+#else
+#define SSV_CONV_ATTR
+#endif
 #ifndef SSV_CONV_WGPC
 #define SSV_CONV_WGPC 3     // resident workgroups per CU the forward / data-gradient kernels are compiled for
 #endif
@@ -419,7 +424,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // second half of the BatchNorm backward, dx = A[k] * g + B[k] * (x - mean[k]) + D[k], formed while it is staged - the element-wise apply
 // pass over (g, x) -> dx of that BatchNorm disappears (it ran AT the HBM roofline and overlapped with nothing: 23 ms of a 257 ms step).
 template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, bool DYF = false>
-__global__ void __launch_bounds__(256, DYF ? 2 : SSV_CONV_WGPC)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+__global__ void __launch_bounds__(256, DYF ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -710,7 +715,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
 template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false, int GATE = 0>
-__global__ void __launch_bounds__(256, SSV_CONV_WGPC)      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+__global__ void __launch_bounds__(256, SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;
