@@ -118,6 +118,13 @@ int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const ssv_bn_dyi
 /* dw (+)= x (*) dx(g, dyin); x may be a raw conv output with (in_scale, in_shift) as in ssv_conv2d_wgrad_bnrelu_in.  d->K >= 128 */
 int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* g,
                           const ssv_bn_dyin* dyin, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The closing activation of a residual unit, a = relu(bn3(x) + shortcut) (networks/resnet.py:73-74), formed by its first consumer - the 1x1
+ * conv1 of the next unit - while it stages it, and written out by that kernel (a_out [N,H,W,C]; mask_out: its ReLU byte mask as in
+ * ssv_bn_apply, or NULL): a = relu(x * scale + shift + res) or, with rscale / rshift, + res * rscale + rshift (the projection shortcut's raw
+ * output and its BatchNorm affine).  Bit-identical to ssv_bn_apply followed by ssv_conv2d_fwd_stats.  1x1 / stride 1 / unpadded, C % 32 == 0. */
+int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x, const float* res, const float* scale, const float* shift,
+                               const float* rscale, const float* rshift, const float* w, float* y, float* pmean, float* pm2,
+                               float* a_out, uint8_t* mask_out, void* stream);
 /* ssv_conv2d_dgrad with the gate.  K % 32 == 0, C % 4 == 0 */
 int64_t ssv_conv2d_dgrad_gate_groups(const ssv_conv_desc* d);
 int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend, float* dx,

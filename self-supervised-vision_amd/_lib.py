@@ -52,6 +52,7 @@ SIGNATURES = {
     "ssv_conv2d_fwd_stats_groups": (_i64, [_cd]),
     "ssv_conv2d_fwd_stats": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_conv2d_fwd_bnrelu_in_stats": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_fwd_sumin_stats": (C.c_int, [_cd] + [_vp] * 13),
     "ssv_conv2d_wgrad_bnrelu_in": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_bn_stats_finalize": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_bn_apply": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),

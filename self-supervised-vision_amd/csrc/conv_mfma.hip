@@ -68,6 +68,10 @@ struct ConvKP {
   ssv_bn_gate gate;       // GATE variants (this launch computes the gradient w.r.t. a BatchNorm + ReLU output): see epilogue_vec
   const float* dyin_x;    // DYF variants: the staged operand is the BatchNorm backward's dx = A[k] * g + B[k] * (x - mean[k]) + D[k], formed
   const float* dyin_coef; //   on load from the gated gradient g (the operand pointer) and the BatchNorm's input x; coef = A | mean | B | D
+  // SUM variants (OPM 2): the staged operand is the closing activation of a residual unit, a = relu(x * scale + shift + res * rscale + rshift),
+  // formed on load from the unit's last conv output x (the operand pointer) and its shortcut; the column-tile-0 workgroups also WRITE it
+  const float* sum_res; const float* sum_scale; const float* sum_shift; const float* sum_rscale; const float* sum_rshift;
+  float* sum_out; uint8_t* sum_mask;
 };
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
@@ -423,15 +427,22 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // DYF (1x1 / stride 1 / no padding only - the data gradient of a 1x1 convolution run as a forward convolution): the A operand is the
 // second half of the BatchNorm backward, dx = A[k] * g + B[k] * (x - mean[k]) + D[k], formed while it is staged - the element-wise apply
 // pass over (g, x) -> dx of that BatchNorm disappears (it ran AT the HBM roofline and overlapped with nothing: 23 ms of a 257 ms step).
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, bool DYF = false>
-__global__ void __launch_bounds__(256, DYF ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+//
+// OPM 2 (SUM; same geometry - the first convolution of the NEXT residual unit): the A operand is the closing activation of the previous unit,
+// a = relu(bn3(x) + shortcut) (networks/resnet.py:73-74), formed while it is staged from the unit's last conv output and its shortcut
+// (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
+// residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
+// element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0>
+__global__ void __launch_bounds__(256, OPM ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;                   // ROWK row stride: 16-lane b128 read groups hit 16 distinct 16-B slots
   constexpr int STAGE = (BM + BN) * LDT;
   static_assert(!XF || (VEC && !C4), "the fused-input variant is the float4 path");
-  static_assert(!DYF || (VEC && !C4 && !XF), "the BatchNorm-backward operand is the float4 path");
+  constexpr bool DYF = OPM == 1, SUM = OPM == 2;
+  static_assert(OPM == 0 || (VEC && !C4 && !XF), "the formed-on-load operands are the float4 path");
   __shared__ __attribute__((aligned(16))) float smem[STAGE + SSV_EXP_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
   float* As = smem;
@@ -531,9 +542,15 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;     // 1x1 / no padding: every tap of a valid row is in bounds
     int lr = 0, ls = 0, lc0 = 0;   // loader position (tap r, s, first channel)
     f32x4 ra[AP], rb[BP];
-    f32x4 ra2[DYF ? AP : 1], co[DYF ? 4 : 1];
-    const rsrc_t rx2 = make_rsrc(DYF ? p.dyin_x : x, (unsigned)p.N * p.H * p.W * p.C * 4u);
+    f32x4 ra2[OPM ? AP : 1], co[OPM ? 4 : 1];
+    const rsrc_t rx2 = make_rsrc(DYF ? p.dyin_x : (SUM ? p.sum_res : x), (unsigned)p.N * p.H * p.W * p.C * 4u);
     const rsrc_t rco = make_rsrc(DYF ? p.dyin_coef : x, DYF ? (unsigned)p.C * 16u : 16u);
+    const rsrc_t rs0 = make_rsrc(SUM ? p.sum_scale : x, (unsigned)p.C * 4u), rs1 = make_rsrc(SUM ? p.sum_shift : x, (unsigned)p.C * 4u);
+    const bool raff = SUM && p.sum_rscale != nullptr;           // uniform: the shortcut carries its own BatchNorm affine
+    const rsrc_t rs2 = make_rsrc(raff ? p.sum_rscale : x, (unsigned)p.C * 4u), rs3 = make_rsrc(raff ? p.sum_rshift : x, (unsigned)p.C * 4u);
+    const rsrc_t rso = make_rsrc(SUM ? p.sum_out : y, (unsigned)p.N * p.H * p.W * p.C * 4u);
+    const rsrc_t rsm = make_rsrc(SUM && p.sum_mask ? reinterpret_cast<float*>(p.sum_mask) : y, (unsigned)p.N * p.H * p.W * (p.C / 4));
+    int st_off = 0;                // SUM: uniform byte offset of the tile being transformed (the loader has moved on by then)
     int xf_ok = 0, xf_c = 0;       // XF: which of the staged rows hold real pixels (bit i), first channel of this thread's float4
     if constexpr (XF) {
       for (int c = tid; c < p.C; c += 256) { xfs[c] = p.xf_scale[c]; xfs[XF_MAXC + c] = p.xf_shift[c]; }
@@ -547,12 +564,18 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       for (int i = 0; i < AP; ++i) {
         const bool ok = inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W));
         ra[i] = bload4(rx, ok ? aoff[i] + toff_x : OOB_OFF, 0);
-        if constexpr (DYF) ra2[i] = bload4(rx2, ok ? aoff[i] + toff_x : OOB_OFF, 0);
+        if constexpr (OPM != 0) ra2[i] = bload4(rx2, ok ? aoff[i] + toff_x : OOB_OFF, 0);
         if constexpr (XF) xf_ok |= (int)ok << i;
       }
       if constexpr (DYF) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) co[j] = bload4(rco, (j * p.C + chunk) * 4, lc0 * 4);
+      }
+      if constexpr (SUM) {
+        st_off = toff_x;
+        co[0] = bload4(rs0, chunk * 4, lc0 * 4); co[1] = bload4(rs1, chunk * 4, lc0 * 4);
+        if (raff) { co[2] = bload4(rs2, chunk * 4, lc0 * 4); co[3] = bload4(rs3, chunk * 4, lc0 * 4); }
+        else { co[2] = f32x4{1.f, 1.f, 1.f, 1.f}; co[3] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
 #pragma unroll
       for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
@@ -589,6 +612,27 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
           for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_fmaf(ra[i][e], co[0][e], __builtin_fmaf(ra2[i][e] - co[1][e], co[2][e], co[3][e]));
         }
+      } else if constexpr (SUM) {
+        // the arithmetic of bn_apply_k (fma(x, scale, shift) + [fma(res, rscale, rshift) | res], mask bit = v > 0, fmaxf): bit-identical to the
+        // materialised activation.  A row past M stages relu(shift + rshift) - harmless, see above - and its stores are dropped (out of range).
+        const bool wr = nt == 0;                               // uniform: every element of a is staged by exactly one workgroup of column tile 0
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          f32x4 v;
+          unsigned bits = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = __builtin_fmaf(ra[i][e], co[0][e], co[1][e]) + __builtin_fmaf(ra2[i][e], co[2][e], co[3][e]);
+            bits |= (v[e] > 0.f ? 1u : 0u) << e;
+            v[e] = fmaxf(v[e], 0.f);
+          }
+          ra[i] = v;
+          if (wr) {
+            const int off = aoff[i] == OOB_OFF ? OOB_OFF : aoff[i] + st_off;
+            bstore4(rso, off, v);
+            if (p.sum_mask) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rsm, off == OOB_OFF ? OOB_OFF : off >> 4, 0, 0);
+          }
+        }
       }
     };
     auto store_tile = [&](int buf) {
@@ -597,7 +641,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
       for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (DYF ? AP + 4 : 0)>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
+    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
     static_assert(BK == GBK, "generic path is BK=16");
@@ -1120,6 +1164,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr; p.xf_scale = nullptr; p.xf_shift = nullptr;
   memset(&p.gate, 0, sizeof(p.gate));
   p.dyin_x = nullptr; p.dyin_coef = nullptr;
+  p.sum_res = p.sum_scale = p.sum_shift = p.sum_rscale = p.sum_rshift = nullptr; p.sum_out = nullptr; p.sum_mask = nullptr;
   return p;
 }
 
@@ -1261,12 +1306,38 @@ extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const
   const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
   const int gm = gate ? (gate->mask ? 2 : 1) : 0;
 #define FWDD(BM_, BN_, WM_, WN_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, true>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
 #define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
   if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
 #undef FWDD_TILE
 #undef FWDD
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_dyin");
+  return SSV_OK;
+}
+
+// 1x1 / stride-1 forward convolution (with the statistics epilogue) whose input is the closing activation of the previous residual unit,
+// formed on load AND written out: a = relu(x * scale + shift + (res | res * rscale + rshift)), relu mask optional.
+extern "C" int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x, const float* res, const float* scale, const float* shift,
+                                          const float* rscale, const float* rshift, const float* w, float* y, float* pmean, float* pm2,
+                                          float* a_out, uint8_t* mask_out, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_sumin_stats")) return rc;
+  SSV_REQUIRE(x && res && scale && shift && w && y && pmean && pm2 && a_out, "ssv_conv2d_fwd_sumin_stats: null pointer");
+  SSV_REQUIRE((rscale == nullptr) == (rshift == nullptr), "ssv_conv2d_fwd_sumin_stats: rscale / rshift must both be given or both NULL");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)res | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)rscale | (uintptr_t)rshift | (uintptr_t)w | (uintptr_t)y |
+                (uintptr_t)pmean | (uintptr_t)pm2 | (uintptr_t)a_out) & 15) == 0, "ssv_conv2d_fwd_sumin_stats: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->C % 32 == 0 && d->K % 4 == 0,
+              "ssv_conv2d_fwd_sumin_stats: a 1x1 / stride-1 / unpadded convolution with C %% 32 == 0 and K %% 4 == 0 (got %dx%d s%d p%d C=%d K=%d)",
+              d->R, d->S, d->stride, d->pad, d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.aux_out = pmean; p.aux_out2 = pm2;
+  p.sum_res = res; p.sum_scale = scale; p.sum_shift = shift; p.sum_rscale = rscale; p.sum_rshift = rshift; p.sum_out = a_out; p.sum_mask = mask_out;
+  const bool wide = d->K >= 128;
+  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  else      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_sumin_stats");
   return SSV_OK;
 }
 

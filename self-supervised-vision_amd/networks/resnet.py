@@ -55,17 +55,20 @@ class _ResidualUnit(hnn.HipModule):
         """conv -> BN -> ReLU -> conv chains never write the activation between the convolutions: the BatchNorm in the middle only
         finalises its statistics (hnn.batchnorm(lazy=True)) and the next convolution applies scale / shift / ReLU while it stages its
         input.  The projection shortcut's BatchNorm is folded into the unit's closing kernel the same way."""
+        # The unit's input may be the previous unit's closing activation that nobody has written yet (hnn.LazySum): conv1 forms and writes it
+        # when it is a 1x1 / stride-1 convolution, so it runs BEFORE the projection shortcut (which then reads the tensor).
+        h1 = self.conv1._run(tape, x, bn_stats=True)
         shortcut = x
         if self.downsample is not None:                      # conv1x1 -> BN: no ReLU, its only consumer is the closing BatchNorm below
             fold = getattr(self, f"conv{self.depth}").has_stats_epilogue()
             shortcut = hnn.batchnorm(tape, self.downsample[0]._run(tape, x, bn_stats=True), self.downsample[1], lazy=fold)
         h = x
         for i in range(1, self.depth + 1):
-            h = getattr(self, f"conv{i}")._run(tape, h, bn_stats=True)      # every conv here is followed by its BatchNorm
+            h = h1 if i == 1 else getattr(self, f"conv{i}")._run(tape, h, bn_stats=True)      # every conv here is followed by its BatchNorm
             closing = i == self.depth
             nxt = None if closing else getattr(self, f"conv{i + 1}")
             fuse = nxt is not None and nxt.can_fuse_input()
-            h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None, lazy=fuse)
+            h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None, lazy=fuse, defer=closing)
         return h
 
 

@@ -182,6 +182,11 @@ _FUSE_BN_DY = os.environ.get("SSV_NO_BN_DY_FUSION", "0") != "1"            # dia
 # between their barriers; it pays where the removed pass is long (56x56 / 28x28 maps: 257.3 -> 254.6 ms per step at bs 512) and not on the
 # small deep maps (all layers: 256.9 ms) - measured with SSV_BN_DY_MIN_HW = 0 / 784 / 3136 / off, three runs each.
 _BN_DY_MIN_HW = int(os.environ.get("SSV_BN_DY_MIN_HW", "784"))
+_FUSE_CLOSING = os.environ.get("SSV_NO_CLOSING_FUSION", "0") != "1"        # diagnostic switch: the closing activation of a unit gets its own pass
+# ... on feature maps of [lo, hi] pixels.  Measured at bs 512 (three runs each, profiles/r02_experiments_step_time.txt exp12): off 252.8 ms, every
+# stage 250.3, the 56x56 / 28x28 stages only 249.8, the 14x14 / 7x7 stages only 252.4 - as for the BatchNorm-backward operand, the pass is
+# worth removing where it is long.
+_CLOSING_HW = tuple(int(v) for v in os.environ.get("SSV_CLOSING_HW", "784,1000000000").split(","))
 _FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
 
 
@@ -204,6 +209,38 @@ class LazyAct:
         return ops.bn_apply(self.raw, self.scale, self.shift, relu=self.relu)[0]
 
 
+class LazySum:
+    """a = relu(raw * scale + shift + shortcut): the closing activation of a residual unit (networks/resnet.py:73-74), NOT YET written.  Its
+    first consumer decides: the 1x1 conv1 of the next unit forms it while it stages its input and writes it out of the same kernel
+    (ops.conv2d_fwd_sumin - the element-wise pass disappears); anything else (`tensor()`) runs that pass.  Either way the tensor exists
+    afterwards (`t`): the next residual add, the weight gradient and the backward's ReLU mask need it.  On the tape the object stands where
+    the tensor would: gradients are keyed by it."""
+    __slots__ = ("raw", "scale", "shift", "mean", "invstd", "res", "res_affine", "want_mask", "t", "mask", "_bn_gate")
+
+    def __init__(self, raw, scale, shift, mean, invstd, res, res_affine, want_mask):
+        self.raw, self.scale, self.shift, self.mean, self.invstd = raw, scale, shift, mean, invstd
+        self.res, self.res_affine, self.want_mask = res, res_affine, want_mask
+        self.t, self.mask, self._bn_gate = None, None, None
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def set(self, t, mask):
+        self.t, self.mask = t, mask
+        if mask is not None:
+            self._bn_gate = ops.BnGateCtx(self.raw, self.mean, self.invstd, mask=mask)
+
+    def tensor(self):
+        if self.t is None:
+            self.set(*ops.bn_apply(self.raw, self.scale, self.shift, relu=True, residual=self.res, res_affine=self.res_affine, want_mask=self.want_mask))
+        return self.t
+
+
+def _tensor(x):
+    return x.tensor() if isinstance(x, LazySum) else x
+
+
 def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
     """``bn_stats``: the caller normalises the output next - let the conv epilogue produce the statistics partials (kept on the
     output tensor as ``_bn_partials`` for `batchnorm`), which saves BatchNorm's own pass over the conv output.
@@ -213,18 +250,29 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
     if lazy is not None and not (lazy.relu and bias is None and ops.can_fuse_conv_input(weight.shape[1], weight.shape[0])):
         raise SsvError("a lazy activation reached a convolution that cannot fuse it (the producer must check ops.can_fuse_conv_input)")
     affine = None if lazy is None else (lazy.scale, lazy.shift)
-    src = x if lazy is None else lazy.raw
-    if lazy is not None:
+    y = None
+    if isinstance(x, LazySum):
+        if (x.t is None and want and _FUSE_CLOSING and ops.can_form_closing_sum(weight.shape, stride, pad)
+                and _CLOSING_HW[0] <= x.shape[1] * x.shape[2] <= _CLOSING_HW[1]):
+            y, part, a, mask = ops.conv2d_fwd_sumin(x.raw, x.res, x.scale, x.shift, x.res_affine, weight, want_mask=x.want_mask)
+            x.set(a, mask)
+            y._bn_partials = part
+        src = x.tensor()
+    else:
+        src = x if lazy is None else lazy.raw
+    if y is not None:
+        pass
+    elif lazy is not None:
         y, part = ops.conv2d_fwd_fused(src, weight, stride, pad, in_affine=affine, want_stats=want)
         if part is not None:
             y._bn_partials = part
     else:
-        fused = ops.conv2d_fwd_stats(x, weight, stride, pad) if want else None
+        fused = ops.conv2d_fwd_stats(src, weight, stride, pad) if want else None
         if fused is not None:
             y = fused[0]
             y._bn_partials = (fused[1], fused[2])
         else:
-            y = ops.conv2d_fwd(x, weight, stride, pad, bias=bias)
+            y = ops.conv2d_fwd(src, weight, stride, pad, bias=bias)
     if tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW:
         y._lazy_dy_ok = True       # a BatchNorm behind this output may hand its backward over as an ops.LazyGrad (formed by wgrad / dgrad)
     if tape is not None:
@@ -307,8 +355,11 @@ def _bn_order_record(bn, x):
         bn._order_event.record(torch.cuda.current_stream(x.device))
 
 
-def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
+def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False, defer=False):
     """BatchNorm (batch statistics) [+ residual] [+ ReLU] of a conv output.
+
+    ``defer=True`` (the closing BatchNorm + shortcut + ReLU of a residual unit): only the statistics are finalised here; the result is a
+    LazySum whose first consumer either forms and writes it (conv1 of the next unit) or runs the element-wise pass.
 
     ``lazy=True`` (the caller guarantees that the only consumer is a convolution that can fuse its input, or - without ReLU - the
     closing BatchNorm of a residual unit): nothing but the statistics is computed; the result is a LazyAct.  ``residual`` may be such a
@@ -318,8 +369,11 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
     res_lazy = residual if isinstance(residual, LazyAct) else None
     if res_lazy is not None and (partials is None or res_lazy.relu):
         raise SsvError("a lazy residual needs the statistics partials of this BatchNorm's input and must not carry a ReLU")
+    res_t = None if res_lazy is not None else _tensor(residual)          # a LazySum shortcut is needed as a tensor here
+    defer = defer and relu and residual is not None and partials is not None and _FUSE_CLOSING and _FUSE_BN_APPLY
+    hold = None
     _bn_order_wait(bn, x)
-    if lazy or res_lazy is not None:
+    if lazy or res_lazy is not None or defer:
         m, c = ops._rows(x)
         mean, invstd, scale, shift = ops.bn_stats_finalize(m, c, partials, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                                            eps=bn.eps, momentum=bn.momentum)
@@ -346,10 +400,16 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
                     return (_accum(existing[0], dx),)
                 tape.record((x,), out, bwd_lazy)
             return out
-        y, mask = ops.bn_apply(x, scale, shift, relu=relu, residual=res_lazy.raw, res_affine=(res_lazy.scale, res_lazy.shift), want_mask=tape is not None)
+        r_raw = res_t if res_lazy is None else res_lazy.raw
+        r_aff = None if res_lazy is None else (res_lazy.scale, res_lazy.shift)
+        if defer:
+            y = hold = LazySum(x, scale, shift, mean, invstd, r_raw, r_aff, want_mask=tape is not None)
+            mask = None
+        else:
+            y, mask = ops.bn_apply(x, scale, shift, relu=relu, residual=r_raw, res_affine=r_aff, want_mask=tape is not None)
     else:
         y, mean, invstd, mask = ops.bn_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                                 relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
+                                                 relu=relu, residual=res_t, eps=bn.eps, momentum=bn.momentum,
                                                  want_mask=True, skip_mask=tape is None,   # 1 byte per 4 elements for the backward
                                                  partials=partials)
         _bn_order_record(bn, x)
@@ -360,6 +420,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
             y._bn_gate = ops.BnGateCtx(x, mean, invstd, mask=mask)
 
         def bwd(dy, existing):
+            y_, mask_ = (y, mask) if hold is None else (hold.t, hold.mask)      # a deferred output was written by its first consumer
             part = dy.__dict__.pop("_gate_partials", None)        # consumed here: dy's buffer goes on as the residual gradient
             if part is not None and existing[0] is None and tape.last[0] and getattr(x, "_lazy_dy_ok", False):
                 # the second half of the backward is formed by the producing convolution's wgrad / dgrad while they stage it
@@ -369,8 +430,8 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False):
                 dx = ops.bn_bwd_from_partials(dy, x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
                 dres = dy if residual is not None else None
             else:
-                dx, dres = ops.bn_train_bwd(dy, y, x, bn.weight, mean, invstd, relu, grad_of(bn.weight, slot), grad_of(bn.bias, slot),
-                                            want_dres=residual is not None, accumulate=True, relu_mask=mask)
+                dx, dres = ops.bn_train_bwd(dy, y_, x, bn.weight, mean, invstd, relu, grad_of(bn.weight, slot), grad_of(bn.bias, slot),
+                                            want_dres=residual is not None, accumulate=True, relu_mask=mask_)
             if residual is None:
                 return (_accum(existing[0], dx), None)
             return (_accum(existing[0], dx), _accum(existing[1], dres))
@@ -412,7 +473,7 @@ def maxpool(tape, x):
 
 
 def global_avgpool(tape, x):
-    y = ops.gap_fwd(x)
+    y = ops.gap_fwd(_tensor(x))
     if tape is not None:
         tape.record((x,), y, lambda dy, ex: (_accum(ex[0], ops.gap_bwd(dy, x.shape)),))
     return y

@@ -109,6 +109,38 @@ def conv2d_fwd_fused(x, w, stride=1, pad=0, in_affine=None, want_stats=True):
     return y, (None if part is None else (part[0], part[1]))
 
 
+def can_form_closing_sum(w_shape, stride, pad, groups=1):
+    """Can this convolution form (and write) the closing activation of the previous residual unit while it stages its input?"""
+    k, c, r, s_ = w_shape
+    return groups == 1 and r == 1 and s_ == 1 and stride == 1 and pad == 0 and c % 32 == 0 and k % 4 == 0
+
+
+def conv2d_fwd_sumin(x, res, scale, shift, res_affine, w, want_mask=True):
+    """y = conv1x1(a, w) with a = relu(x * scale + shift + res) (``res_affine = (rscale, rshift)``: + res * rscale + rshift) formed while it is
+    staged AND written out by the same kernel; the epilogue leaves the BatchNorm statistics partials of y.
+    Returns (y, (pmean, pm2), a, mask | None) - a / mask bit-identical to `bn_apply(x, scale, shift, relu=True, residual=res, ...)`."""
+    _lib._dev(x, res, w)
+    w, wshape = _ohwi(w)
+    d = conv_desc(x.shape, wshape, 1, 0)
+    y = _empty((d.N, d.Ho, d.Wo, d.K), x)
+    a = torch.empty_like(x)
+    m, c = _rows(x)
+    mask = torch.empty((m * c // 4,), dtype=torch.uint8, device=x.device) if want_mask else None
+    lib = _lib.load()
+    groups = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(d)))
+    part = _empty((2, groups, d.K), x)
+    rs, rh = res_affine if res_affine is not None else (None, None)
+    per = d.H * d.W * d.C
+    g0 = 0
+    for n0, n1 in _batch_chunks(d.N, (per, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo):
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, 1, 0)
+        gc = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(dc)))
+        call("ssv_conv2d_fwd_sumin_stats", C.byref(dc), ptr(x[n0:n1]), ptr(res[n0:n1]), ptr(scale), ptr(shift), ptr(rs), ptr(rh), ptr(w), ptr(y[n0:n1]),
+             ptr(part[0][g0:g0 + gc]), ptr(part[1][g0:g0 + gc]), ptr(a[n0:n1]), None if mask is None else ptr(mask[n0 * per // 4:n1 * per // 4]), stream())
+        g0 += gc
+    return y, (part[0], part[1]), a, mask
+
+
 def can_fuse_conv_input(cin, cout, groups=1):
     """Preconditions of the fused-input convolution kernels (forward and weight gradient)."""
     return groups == 1 and cin % 32 == 0 and cin <= 1024 and cout % 4 == 0

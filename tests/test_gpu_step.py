@@ -527,3 +527,34 @@ def test_batchnorm_backward_formed_by_its_consumers_matches_the_materialised_for
             continue
         worst = max(worst, float((a - r).norm() / r.norm()))
     assert 0.0 < worst < 2e-5, f"worst per-tensor gradient difference {worst:.2e} (0 = the fused path did not run)"
+
+
+@pytest.mark.parametrize("arch,rbc,size,b", [("resnet50", False, 64, 6), ("resnet50", False, 96, 3), ("resnet18", True, 32, 12)])
+def test_closing_activation_formed_by_the_next_conv1_is_bitwise_the_element_wise_pass(dev, arch, rbc, size, b):
+    """hnn.LazySum: the closing relu(bn3(x) + shortcut) of a bottleneck unit is formed AND written by conv1 of the next unit while it stages
+    its input (identity and projection shortcuts, the stage-entry units whose conv1 now runs before the projection shortcut); ResNet-18's
+    3x3 conv1 cannot, so its units fall back to the element-wise pass.  Same fmaf / add / fmaxf on the same floats: loss and embeddings are
+    bit-identical; the gradients agree to rounding (at the stage entries the gate + partial sums of the unit-input gradient move from the
+    stride-2 data-gradient kernel's epilogue to the forward kernel's: same ReLU bits, sums grouped differently)."""
+    from ssv_amd import nn as hnn
+    a1, a2 = seeded_randn(1900, b, 3, size, size), seeded_randn(1901, b, 3, size, size)
+    outs = []
+    for fuse in (True, False):
+        prev, hnn._FUSE_CLOSING = hnn._FUSE_CLOSING, fuse
+        try:
+            m = _Step(dev, arch, rbc)
+            loss, z1, z2 = m.step(a1, a2)
+            torch.cuda.synchronize()
+            outs.append((loss, z1.cpu(), z2.cpu(), m, m.grads.cpu().clone()))
+        finally:
+            hnn._FUSE_CLOSING = prev
+    (lf, zf, z2f, m, gf), (lu, zu, z2u, _, gu) = outs
+    assert lf == lu and torch.equal(zf, zu) and torch.equal(z2f, z2u)
+    worst = 0.0
+    for p, off in zip(m.params(), m.optim.arena.offsets):
+        a, r = gf[off:off + p.numel()].double(), gu[off:off + p.numel()].double()
+        if float(r.norm()) < 1e-5:
+            assert float(a.abs().max()) < 1e-5
+            continue
+        worst = max(worst, float((a - r).norm() / r.norm()))
+    assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"
