@@ -696,8 +696,9 @@ class _Bridge(torch.autograd.Function):
         xin = module._prepare_input(x.detach())
         tape = Tape(xin, x.requires_grad) if record else None
         y = module._run(tape, xin)
-        ctx.tape, ctx.y, ctx.module = tape, y, module
-        return y.view_as(y)        # fresh tensor object for autograd; same storage
+        ctx.tape, ctx.y, ctx.module = tape, y, module            # the tape keys the output by this object (it may be a LazySum)
+        yt = _tensor(y)                                          # a module boundary is a consumer like any other: the tensor must exist
+        return yt.view_as(yt)      # fresh tensor object for autograd; same storage
 
     @staticmethod
     def backward(ctx, dy):
