@@ -115,7 +115,7 @@ typedef struct ssv_bn_dyin {
  * convolution with the transposed filter.  d->C = channels of g (% 32 == 0), d->K % 4 == 0 */
 int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend, float* y,
                         const ssv_bn_gate* gate, void* stream);
-/* dw (+)= x (*) dx(g, dyin); x may be a raw conv output with (in_scale, in_shift) as in ssv_conv2d_wgrad_bnrelu_in.  d->K >= 128 */
+/* dw (+)= x (*) dx(g, dyin); x may be a raw conv output with (in_scale, in_shift) as in ssv_conv2d_wgrad_bnrelu_in.  d->K % 4 == 0 */
 int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* g,
                           const ssv_bn_dyin* dyin, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* The closing activation of a residual unit, a = relu(bn3(x) + shortcut) (networks/resnet.py:73-74), formed by its first consumer - the 1x1

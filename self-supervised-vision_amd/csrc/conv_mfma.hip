@@ -1491,8 +1491,8 @@ extern "C" int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, con
                                      const ssv_bn_dyin* dyin, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   SSV_REQUIRE(dyin && dyin->x && dyin->coef, "ssv_conv2d_wgrad_dyin: null operand description");
   SSV_REQUIRE((((uintptr_t)dyin->x | (uintptr_t)dyin->coef) & 15) == 0, "ssv_conv2d_wgrad_dyin: pointers must be 16-byte aligned");
-  SSV_REQUIRE(d && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K >= 128 && d->C % 4 == 0,
-              "ssv_conv2d_wgrad_dyin: a 1x1 / stride-1 / unpadded convolution with K >= 128 and C %% 4 == 0");
+  SSV_REQUIRE(d && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K % 4 == 0 && d->C % 4 == 0,
+              "ssv_conv2d_wgrad_dyin: a 1x1 / stride-1 / unpadded convolution with K %% 4 == 0 and C %% 4 == 0");
   return wgrad_impl(d, x, in_scale, in_shift, g, dyin, dw, accumulate, ws, ws_bytes, stream);
 }
 
@@ -1528,9 +1528,14 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
 #define WG_GATHER(BM_, BN_, WM_, WN_, X_) \
   do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 1, X_); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 2, X_); \
        else WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 0, X_); } while (0)
-  if (dyin) {                                      // preconditions checked by ssv_conv2d_wgrad_dyin: LIN gather, 128-row tiles, float4 columns
-    if (wp.bn == 64) { if (xf) WG_DYIN(128, 64, 2, 2, true); else WG_DYIN(128, 64, 2, 2, false); }
-    else             { if (xf) WG_DYIN(128, 128, 2, 2, true); else WG_DYIN(128, 128, 2, 2, false); }
+  if (dyin) {                                      // preconditions checked by ssv_conv2d_wgrad_dyin: LIN gather, float4 columns
+    if (wp.bm == 128) {
+      if (wp.bn == 64) { if (xf) WG_DYIN(128, 64, 2, 2, true); else WG_DYIN(128, 64, 2, 2, false); }
+      else             { if (xf) WG_DYIN(128, 128, 2, 2, true); else WG_DYIN(128, 128, 2, 2, false); }
+    } else {
+      if (wp.bn == 64) { if (xf) WG_DYIN(64, 64, 2, 2, true); else WG_DYIN(64, 64, 2, 2, false); }
+      else             { if (xf) WG_DYIN(64, 128, 1, 4, true); else WG_DYIN(64, 128, 1, 4, false); }
+    }
   } else if (!vecb) {
     if (wp.bm == 128) WG_LAUNCH(128, 128, 2, 2, GBK, false, 0, false);
     else              WG_LAUNCH(64, 128, 1, 4, GBK, false, 0, false);

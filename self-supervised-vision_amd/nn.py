@@ -182,6 +182,7 @@ _FUSE_BN_DY = os.environ.get("SSV_NO_BN_DY_FUSION", "0") != "1"            # dia
 # between their barriers; it pays where the removed pass is long (56x56 / 28x28 maps: 257.3 -> 254.6 ms per step at bs 512) and not on the
 # small deep maps (all layers: 256.9 ms) - measured with SSV_BN_DY_MIN_HW = 0 / 784 / 3136 / off, three runs each.
 _BN_DY_MIN_HW = int(os.environ.get("SSV_BN_DY_MIN_HW", "784"))
+_BN_DY_MIN_K = int(os.environ.get("SSV_BN_DY_MIN_K", "0"))                 # diagnostic: only convolutions with at least this many output channels
 _FUSE_CLOSING = os.environ.get("SSV_NO_CLOSING_FUSION", "0") != "1"        # diagnostic switch: the closing activation of a unit gets its own pass
 # ... on feature maps of [lo, hi] pixels.  Measured at bs 512 (three runs each, profiles/r02_experiments_step_time.txt exp12): off 252.8 ms, every
 # stage 250.3, the 56x56 / 28x28 stages only 249.8, the 14x14 / 7x7 stages only 252.4 - as for the BatchNorm-backward operand, the pass is
@@ -273,7 +274,8 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
             y._bn_partials = (fused[1], fused[2])
         else:
             y = ops.conv2d_fwd(src, weight, stride, pad, bias=bias)
-    if tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW:
+    if (tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW
+            and weight.shape[0] >= _BN_DY_MIN_K):
         y._lazy_dy_ok = True       # a BatchNorm behind this output may hand its backward over as an ops.LazyGrad (formed by wgrad / dgrad)
     if tape is not None:
         need_dx = lazy is not None or tape.needs_grad(x)

@@ -197,7 +197,7 @@ class LazyGrad:
 def can_lazy_dy(w_shape, stride, pad):
     """Can the weight and data gradient of this convolution take their dY operand as a LazyGrad?"""
     k, c, r, s_ = w_shape
-    return r == 1 and s_ == 1 and stride == 1 and pad == 0 and k >= 128 and k % 32 == 0 and c % 4 == 0
+    return r == 1 and s_ == 1 and stride == 1 and pad == 0 and k % 32 == 0 and c % 4 == 0
 
 
 def _dyin_struct(lg, n0, n1):

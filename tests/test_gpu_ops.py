@@ -474,7 +474,8 @@ def test_batches_beyond_the_per_launch_limit_are_split_on_the_host(dev, monkeypa
 
 
 @pytest.mark.parametrize("n,h,cin,k,xf,gate_kind", [(3, 7, 64, 256, False, None), (2, 9, 64, 256, True, "affine"), (3, 7, 256, 512, False, "mask"),
-                                                   (5, 5, 128, 512, True, None), (2, 6, 512, 2048, False, "affine")])
+                                                   (5, 5, 128, 512, True, None), (2, 6, 512, 2048, False, "affine"),
+                                                   (3, 7, 256, 64, False, "mask"), (2, 9, 64, 64, False, None)])
 def test_batchnorm_backward_formed_by_the_consumers_of_dx(dev, n, h, cin, k, xf, gate_kind):
     """ops.LazyGrad: conv3 / projection-shortcut gradients (networks/resnet.py:66-75 backwards) take the BatchNorm backward's dx =
     gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) as (g, x, coefficients) and form it while they stage it; the result must be
