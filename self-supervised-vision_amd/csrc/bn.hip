@@ -29,6 +29,9 @@ BnPlan bn_plan(int64_t M, int C) {
 
 // Grid of the pure element-wise passes (bn_apply_k, bn_bwd_apply_k): their result does not depend on the partition, so they get a
 // grid of their own - about SSV_APPLY_WGS workgroups in all, each walking a long run of rows.
+// SSV_APPLY_* / SSV_EXP_SKIP_APPLY: compile-time switches of DIAGNOSTIC builds only (tools/probe/build_variant.sh; the shipped Makefile defines
+// none): grid size, rows in flight and register cap of the element-wise passes, and the timing-only what-if that skips them
+// (profiles/r02_experiments_step_time.txt).
 // register cap of the element-wise passes (amdgpu_num_vgpr(n) caps the unified file at 2n on gfx950)
 #ifdef SSV_APPLY_VGPR
 #define SSV_APPLY_ATTR __attribute__((amdgpu_num_vgpr(SSV_APPLY_VGPR)))

@@ -29,6 +29,8 @@
 #include <string.h>
 #include <type_traits>
 
+// Compile-time switches of DIAGNOSTIC builds only (tools/probe/build_variant.sh builds a side library with them; the shipped Makefile defines
+// none, and nothing here reads the environment): the what-ifs and A/Bs they served are tabulated in profiles/r02_experiments_step_time.txt.
 #ifndef SSV_EXP_LDS_PAD
 #define SSV_EXP_LDS_PAD 0   // diagnostic builds only: extra LDS floats per forward / data-gradient workgroup (forces a lower occupancy)
 #endif
