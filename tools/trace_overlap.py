@@ -38,6 +38,7 @@ active = set()
 last = ev[0][0]
 depth_time = defaultdict(int)
 alone = defaultdict(int)
+alone_by_name = defaultdict(int)
 beside = defaultdict(lambda: defaultdict(int))
 for t, kind, i in ev:
     dt = t - last
@@ -49,6 +50,7 @@ for t, kind, i in ev:
             others = {cls(ks[o][3]) for o in active if ks[o][2] != ks[j][2]}
             if not others:
                 alone[c] += dt
+                alone_by_name[re.sub(r"[<(].*", "", ks[j][3].replace("void ", "").replace("(anonymous namespace)::", ""))[:60]] += dt
             else:
                 for oc in others:
                     beside[c][oc] += dt
@@ -68,3 +70,6 @@ for s, e, q, n in ks:
 for c, (tot, n) in sorted(dur.items()):
     print(f"{c:13} {n:6} launches, {tot / 1e6:8.1f} ms kernel time, avg {tot / n / 1e3:7.1f} us | alone {alone[c] / 1e6:7.1f} ms | beside: " +
           ", ".join(f"{oc} {v / 1e6:.1f}" for oc, v in sorted(beside[c].items())))
+print("kernels that ran with no kernel of another queue beside them (top 15):")
+for n, v in sorted(alone_by_name.items(), key=lambda kv: -kv[1])[:15]:
+    print(f"  {v / 1e6:8.1f} ms  {n}")
