@@ -98,6 +98,13 @@ typedef struct ssv_bn_gate {
   const float* invstd;
   float* psum_g;
   float* psum_gx;
+  /* optional second reduction target (all four or none; byte-mask gate, forward-kernel entry points only): g is also the gradient w.r.t. the
+   * output of the projection shortcut's BatchNorm (networks/resnet.py:72-74, no ReLU there) whose input is x2 - psum_gx2 receives
+   * sum g * xhat2 (its sum g is psum_g), so that BatchNorm's backward needs no reduction pass either */
+  const float* x2;
+  const float* mean2;
+  const float* invstd2;
+  float* psum_gx2;
 } ssv_bn_gate;
 /* ssv_conv2d_fwd with the gate (stride-1 data gradients run on the forward kernel with the transposed filter).  C % 32 == 0, K % 4 == 0 */
 int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d);

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
 
 
 class BnGate(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx")]
+    _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx", "x2", "mean2", "invstd2", "psum_gx2")]
 
 
 class BnDyin(C.Structure):

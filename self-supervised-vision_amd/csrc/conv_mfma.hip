@@ -291,6 +291,9 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // STATS: also reduce, per output column, the rows this wave stores (a group of TM*32 consecutive output rows) to (mean, centred sum
 // of squares) - shifted sums around the group's first row, then a shuffle over the lanes that share a column - and write them as
 // one partial of the BatchNorm that follows (layout of bn_stats_finalize_k with rows-per-block = TM*32).
+// GATE 3 = GATE 2 plus a SECOND reduction target: the gated gradient g of a unit's closing activation is also the gradient w.r.t. the output
+// of the projection shortcut's BatchNorm (no ReLU there), so sum g * xhat2 against that BatchNorm's input (bn.x2 / mean2 / invstd2 ->
+// bn.psum_gx2; its sum g is psum_g) comes out of the same epilogue and the shortcut's backward needs no reduction pass either.
 // GATE (1: the ReLU bit recomputed as x * scale + shift > 0, 2: the ReLU bit from the forward's byte mask): the tile is the gradient
 // w.r.t. the OUTPUT of a BatchNorm (+ residual) + ReLU whose input x is bn.x.  The value stored is g = relu'(.) * (acc + addend), and
 // the wave leaves, per column, the two sums the BatchNorm backward needs over its rows - sum g and sum g * xhat - as one partial
@@ -308,7 +311,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
                                              float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0,
                                              const ssv_bn_gate* bn = nullptr, long long group = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
-  constexpr int HB = GATE == 1 ? 2 : (NP < 4 ? NP : 4);   // rows per batch: the loads of a batch are in flight together (register budget of 3 workgroups per CU)
+  constexpr bool GMASK = GATE >= 2, GX2 = GATE == 3;
+  constexpr int HB = (GATE == 1 || GX2) ? 2 : (NP < 4 ? NP : 4);   // rows per batch: the loads of a batch are in flight together (register budget of 3 workgroups per CU)
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
@@ -318,10 +322,12 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 st_p = {0.f, 0.f, 0.f, 0.f}, st_s1 = {0.f, 0.f, 0.f, 0.f}, st_s2 = {0.f, 0.f, 0.f, 0.f};
   f32x4 g_mu = {0.f, 0.f, 0.f, 0.f}, g_is = {0.f, 0.f, 0.f, 0.f}, g_sc = {0.f, 0.f, 0.f, 0.f}, g_sh = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g_mu2 = {0.f, 0.f, 0.f, 0.f}, g_is2 = {0.f, 0.f, 0.f, 0.f}, st_s3 = {0.f, 0.f, 0.f, 0.f};
   if constexpr (GATE != 0) {
     if (cok) {
       g_mu = *reinterpret_cast<const f32x4*>(bn->mean + gcol); g_is = *reinterpret_cast<const f32x4*>(bn->invstd + gcol);
       if constexpr (GATE == 1) { g_sc = *reinterpret_cast<const f32x4*>(bn->scale + gcol); g_sh = *reinterpret_cast<const f32x4*>(bn->shift + gcol); }
+      if constexpr (GX2) { g_mu2 = *reinterpret_cast<const f32x4*>(bn->mean2 + gcol); g_is2 = *reinterpret_cast<const f32x4*>(bn->invstd2 + gcol); }
     }
   }
   if (bias && cok) b4 = *reinterpret_cast<const f32x4*>(bias + gcol);
@@ -330,7 +336,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   {
     const rsrc_t r_add = make_rsrc(ADD ? addend : out, bytes);
     const rsrc_t r_gx = make_rsrc(GATE != 0 ? bn->x : out, bytes);
-    const rsrc_t r_gm = make_rsrc(GATE == 2 ? reinterpret_cast<const float*>(bn->mask) : out, bytes / 16);
+    const rsrc_t r_gm = make_rsrc(GMASK ? reinterpret_cast<const float*>(bn->mask) : out, bytes / 16);
+    const rsrc_t r_gx2 = make_rsrc(GX2 ? bn->x2 : out, bytes);
     const rsrc_t r_gate = make_rsrc(EPI == 2 ? gate : out, bytes);
     const rsrc_t r_act = make_rsrc(EPI == 1 ? out_act : out, bytes);
 #pragma unroll
@@ -344,7 +351,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
       for (int q0 = 0; q0 < NP; q0 += HB) {
         __builtin_amdgcn_sched_barrier(0);       // one batch of rows in flight at a time (register budget of 3 workgroups per CU)
         int voff[HB];
-        f32x4 av[HB], xv[HB], gv[HB];
+        f32x4 av[HB], xv[HB], gv[HB], xv2[GX2 ? HB : 1];
         unsigned mb[HB];
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
@@ -353,7 +360,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
           if (ADD) av[i] = bload4(r_add, voff[i], 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == 2) gv[i] = bload4(r_gate, voff[i], 0);
           if constexpr (GATE != 0) xv[i] = bload4(r_gx, voff[i], 0);
-          if constexpr (GATE == 2) mb[i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[i] == OOB_OFF ? OOB_OFF : voff[i] >> 4, 0, 0);
+          if constexpr (GMASK) mb[i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[i] == OOB_OFF ? OOB_OFF : voff[i] >> 4, 0, 0);
+          if constexpr (GX2) xv2[i] = bload4(r_gx2, voff[i], 0);
         }
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
@@ -385,6 +393,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
             if constexpr (GATE == 1) { gvv[0] = ok ? v[0] : 0.f; gvv[1] = ok ? v[1] : 0.f; gvv[2] = ok ? v[2] : 0.f; gvv[3] = ok ? v[3] : 0.f; }
             st_s1 += gvv;
             st_s2 += gvv * ((xv[i] - g_mu) * g_is);
+            if constexpr (GX2) st_s3 += gvv * ((xv2[i] - g_mu2) * g_is2);      // an out-of-range row has gvv == 0 (mask byte 0)
           }
           bstore4(r_out, voff[i], v);
           if constexpr (EPI == 1) {
@@ -414,11 +423,15 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 #pragma unroll
     for (int o = C4; o < 64; o <<= 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { st_s1[e] += __shfl_xor(st_s1[e], o, 64); st_s2[e] += __shfl_xor(st_s2[e], o, 64); }
+      for (int e = 0; e < 4; ++e) {
+        st_s1[e] += __shfl_xor(st_s1[e], o, 64); st_s2[e] += __shfl_xor(st_s2[e], o, 64);
+        if constexpr (GX2) st_s3[e] += __shfl_xor(st_s3[e], o, 64);
+      }
     }
     if (r_in == 0 && cok) {       // every wave writes its partial, zeros included: the finalize kernel reads all of them
       *reinterpret_cast<f32x4*>(bn->psum_g + group * ncols + gcol) = st_s1;
       *reinterpret_cast<f32x4*>(bn->psum_gx + group * ncols + gcol) = st_s2;
+      if constexpr (GX2) *reinterpret_cast<f32x4*>(bn->psum_gx2 + group * ncols + gcol) = st_s3;
     }
   }
 }
@@ -436,7 +449,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
 template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0>
-__global__ void __launch_bounds__(256, OPM ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+__global__ void __launch_bounds__(256, (OPM || GATE == 3) ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -1211,8 +1224,9 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
     const unsigned gg = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
 #define FWDG(BM_, BN_, WM_, WN_, G_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(gg), dim3(256), 0, s, p, x, w, bias, addend, y)
-    if (gate->mask) { if (wide) FWDG(128, 128, 2, 2, 2); else FWDG(256, 64, 4, 1, 2); }
-    else            { if (wide) FWDG(128, 128, 2, 2, 1); else FWDG(256, 64, 4, 1, 1); }
+    if (gate->x2)        { if (wide) FWDG(128, 128, 2, 2, 3); else FWDG(256, 64, 4, 1, 3); }
+    else if (gate->mask) { if (wide) FWDG(128, 128, 2, 2, 2); else FWDG(256, 64, 4, 1, 2); }
+    else                 { if (wide) FWDG(128, 128, 2, 2, 1); else FWDG(256, 64, 4, 1, 1); }
 #undef FWDG
     return SSV_OK;
   }
@@ -1262,6 +1276,10 @@ int check_gate(const ssv_bn_gate* g, const char* who) {
               "%s: a gate carries either the byte mask or scale + shift", who);
   SSV_REQUIRE((((uintptr_t)g->x | (uintptr_t)g->mean | (uintptr_t)g->invstd | (uintptr_t)g->psum_g | (uintptr_t)g->psum_gx | (uintptr_t)g->scale | (uintptr_t)g->shift) & 15) == 0,
               "%s: gate pointers must be 16-byte aligned", who);
+  if (g->x2 || g->mean2 || g->invstd2 || g->psum_gx2) {
+    SSV_REQUIRE(g->x2 && g->mean2 && g->invstd2 && g->psum_gx2 && g->mask, "%s: the second reduction target needs x2, mean2, invstd2, psum_gx2 and the byte-mask gate", who);
+    SSV_REQUIRE((((uintptr_t)g->x2 | (uintptr_t)g->mean2 | (uintptr_t)g->invstd2 | (uintptr_t)g->psum_gx2) & 15) == 0, "%s: gate pointers must be 16-byte aligned", who);
+  }
   return SSV_OK;
 }
 }  // namespace
@@ -1306,11 +1324,11 @@ extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const
   if (gate) p.gate = *gate;
   const bool wide = d->K >= 128;
   const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-  const int gm = gate ? (gate->mask ? 2 : 1) : 0;
+  const int gm = gate ? (gate->x2 ? 3 : (gate->mask ? 2 : 1)) : 0;
 #define FWDD(BM_, BN_, WM_, WN_, G_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
 #define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
-  if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
+  if (gm == 3) FWDD_TILE(3); else if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
 #undef FWDD_TILE
 #undef FWDD
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_dyin");
@@ -1446,6 +1464,7 @@ extern "C" int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, c
                                       const ssv_bn_gate* gate, void* stream) {
   if (int rc = check_desc(d, "ssv_conv2d_dgrad_gated")) return rc;
   if (int rc = check_gate(gate, "ssv_conv2d_dgrad_gated")) return rc;
+  SSV_REQUIRE(gate->x2 == nullptr, "ssv_conv2d_dgrad_gated: the second reduction target is a forward-kernel feature (stride-1 data gradients)");
   SSV_REQUIRE(dy && w && dx, "ssv_conv2d_dgrad_gated: null pointer");
   SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)addend) & 15) == 0, "ssv_conv2d_dgrad_gated: pointers must be 16-byte aligned");
   SSV_REQUIRE(d->K % 32 == 0 && d->C % 4 == 0 && d->stride <= 8, "ssv_conv2d_dgrad_gated: needs K %% 32 == 0, C %% 4 == 0, stride <= 8 (got K=%d C=%d)", d->K, d->C);

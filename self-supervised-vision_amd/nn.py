@@ -188,6 +188,7 @@ _FUSE_CLOSING = os.environ.get("SSV_NO_CLOSING_FUSION", "0") != "1"        # dia
 # stage 250.3, the 56x56 / 28x28 stages only 249.8, the 14x14 / 7x7 stages only 252.4 - as for the BatchNorm-backward operand, the pass is
 # worth removing where it is long.
 _CLOSING_HW = tuple(int(v) for v in os.environ.get("SSV_CLOSING_HW", "784,1000000000").split(","))
+_FUSE_SHORTCUT_GATE = os.environ.get("SSV_NO_SHORTCUT_GATE", "0") != "1"   # diagnostic switch: the projection shortcut's BatchNorm backward reduces in its own pass
 _FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
 
 
@@ -216,11 +217,11 @@ class LazySum:
     (ops.conv2d_fwd_sumin - the element-wise pass disappears); anything else (`tensor()`) runs that pass.  Either way the tensor exists
     afterwards (`t`): the next residual add, the weight gradient and the backward's ReLU mask need it.  On the tape the object stands where
     the tensor would: gradients are keyed by it."""
-    __slots__ = ("raw", "scale", "shift", "mean", "invstd", "res", "res_affine", "want_mask", "t", "mask", "_bn_gate")
+    __slots__ = ("raw", "scale", "shift", "mean", "invstd", "res", "res_affine", "want_mask", "second", "t", "mask", "_bn_gate")
 
-    def __init__(self, raw, scale, shift, mean, invstd, res, res_affine, want_mask):
+    def __init__(self, raw, scale, shift, mean, invstd, res, res_affine, want_mask, second=None):
         self.raw, self.scale, self.shift, self.mean, self.invstd = raw, scale, shift, mean, invstd
-        self.res, self.res_affine, self.want_mask = res, res_affine, want_mask
+        self.res, self.res_affine, self.want_mask, self.second = res, res_affine, want_mask, second
         self.t, self.mask, self._bn_gate = None, None, None
 
     @property
@@ -230,7 +231,7 @@ class LazySum:
     def set(self, t, mask):
         self.t, self.mask = t, mask
         if mask is not None:
-            self._bn_gate = ops.BnGateCtx(self.raw, self.mean, self.invstd, mask=mask)
+            self._bn_gate = ops.BnGateCtx(self.raw, self.mean, self.invstd, mask=mask, second=self.second)
 
     def tensor(self):
         if self.t is None:
@@ -373,7 +374,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False, defer=False):
         raise SsvError("a lazy residual needs the statistics partials of this BatchNorm's input and must not carry a ReLU")
     res_t = None if res_lazy is not None else _tensor(residual)          # a LazySum shortcut is needed as a tensor here
     defer = defer and relu and residual is not None and partials is not None and _FUSE_CLOSING and _FUSE_BN_APPLY
-    hold = None
+    hold = second = None
     _bn_order_wait(bn, x)
     if lazy or res_lazy is not None or defer:
         m, c = ops._rows(x)
@@ -404,8 +405,10 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False, defer=False):
             return out
         r_raw = res_t if res_lazy is None else res_lazy.raw
         r_aff = None if res_lazy is None else (res_lazy.scale, res_lazy.shift)
+        # the gated gradient of this output is also the gradient w.r.t. the projection shortcut's BatchNorm output: let the gate reduce against it too
+        second = (res_lazy.raw, res_lazy.mean, res_lazy.invstd) if (res_lazy is not None and _FUSE_SHORTCUT_GATE and _FUSE_BN_BWD) else None
         if defer:
-            y = hold = LazySum(x, scale, shift, mean, invstd, r_raw, r_aff, want_mask=tape is not None)
+            y = hold = LazySum(x, scale, shift, mean, invstd, r_raw, r_aff, want_mask=tape is not None, second=second)
             mask = None
         else:
             y, mask = ops.bn_apply(x, scale, shift, relu=relu, residual=r_raw, res_affine=r_aff, want_mask=tape is not None)
@@ -419,11 +422,14 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False, defer=False):
         slot = tape.slot
 
         if relu and mask is not None:
-            y._bn_gate = ops.BnGateCtx(x, mean, invstd, mask=mask)
+            y._bn_gate = ops.BnGateCtx(x, mean, invstd, mask=mask, second=second)
 
         def bwd(dy, existing):
             y_, mask_ = (y, mask) if hold is None else (hold.t, hold.mask)      # a deferred output was written by its first consumer
             part = dy.__dict__.pop("_gate_partials", None)        # consumed here: dy's buffer goes on as the residual gradient
+            part_res = dy.__dict__.pop("_gate_partials_res", None)
+            if part is not None and part_res is not None and residual is not None and existing[1] is None:
+                dy._gate_partials = part_res      # dy IS the gradient w.r.t. the projection shortcut's BatchNorm output: its backward finds its sums
             if part is not None and existing[0] is None and tape.last[0] and getattr(x, "_lazy_dy_ok", False):
                 # the second half of the backward is formed by the producing convolution's wgrad / dgrad while they stage it
                 dx = ops.LazyGrad(dy, x, ops.bn_bwd_coef(x, bn.weight, mean, invstd, part, grad_of(bn.weight, slot), grad_of(bn.bias, slot)))

@@ -172,10 +172,13 @@ def _transposed_filter(w, wshape):
 class BnGateCtx:
     """What a convolution's data gradient needs to run the first half of the BatchNorm backward in its epilogue (include/ssv_hip.h,
     ssv_bn_gate): the BatchNorm's input x, its saved statistics, and the ReLU bit - byte mask or the forward's (scale, shift)."""
-    __slots__ = ("x", "mean", "invstd", "mask", "scale", "shift")
+    __slots__ = ("x", "mean", "invstd", "mask", "scale", "shift", "x2", "mean2", "invstd2")
 
-    def __init__(self, x, mean, invstd, mask=None, scale=None, shift=None):
+    def __init__(self, x, mean, invstd, mask=None, scale=None, shift=None, second=None):
+        """``second = (x2, mean2, invstd2)``: the gated gradient is also the gradient w.r.t. the output of the projection shortcut's BatchNorm
+        (input x2): the epilogue then reduces sum g * xhat2 as well (mask gates on stride-1 data gradients only; dropped otherwise)."""
         self.x, self.mean, self.invstd, self.mask, self.scale, self.shift = x, mean, invstd, mask, scale, shift
+        self.x2, self.mean2, self.invstd2 = second if second is not None else (None, None, None)
 
 
 class LazyGrad:
@@ -204,15 +207,16 @@ def _dyin_struct(lg, n0, n1):
     return _lib.BnDyin(ptr(lg.x[n0:n1]), ptr(lg.coef))
 
 
-def _gate_struct(gate, groups, channels, like):
-    part = _empty((2, groups, channels), like)
-    st = _lib.BnGate(ptr(gate.x), ptr(gate.scale), ptr(gate.shift), ptr(gate.mask), ptr(gate.mean), ptr(gate.invstd), ptr(part[0]), ptr(part[1]))
+def _gate_struct(gate, groups, channels, like, second=False):
+    part = _empty((3 if second else 2, groups, channels), like)
+    st = _lib.BnGate(ptr(gate.x), ptr(gate.scale), ptr(gate.shift), ptr(gate.mask), ptr(gate.mean), ptr(gate.invstd), ptr(part[0]), ptr(part[1]),
+                     ptr(gate.x2) if second else None, ptr(gate.mean2) if second else None, ptr(gate.invstd2) if second else None, ptr(part[2]) if second else None)
     return st, part
 
 
 def _gate_sub(gate, n0, n1):
     return BnGateCtx(gate.x[n0:n1], gate.mean, gate.invstd, mask=None if gate.mask is None else gate.mask[n0 * gate.x[0].numel() // 4:n1 * gate.x[0].numel() // 4],
-                     scale=gate.scale, shift=gate.shift)
+                     scale=gate.scale, shift=gate.shift, second=None if gate.x2 is None else (gate.x2[n0:n1], gate.mean2, gate.invstd2))
 
 
 def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=None):
@@ -232,6 +236,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
         raise _lib.SsvError("conv2d_dgrad: a LazyGrad reached a convolution that cannot form it (the producer must check ops.can_lazy_dy)")
     dx = out if out is not None else _empty(tuple(x_shape), dy)
     dx.__dict__.pop("_gate_partials", None)            # an accumulated-into buffer never keeps the partial sums of its old content
+    dx.__dict__.pop("_gate_partials_res", None)
     if gate is not None and (k % 32 or c % 4 or tuple(gate.x.shape) != tuple(dx.shape)):
         gate = None
     lib = _lib.load()
@@ -241,6 +246,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     if gate is not None and not as_fwd and stride > 8:
         gate = None
     wt = _transposed_filter(w, wshape) if as_fwd else None
+    second = gate is not None and as_fwd and gate.x2 is not None and gate.mask is not None and tuple(gate.x2.shape) == tuple(dx.shape)
     parts = []
     for n0, n1 in chunks:
         dyc, dxc, adc = dy[n0:n1], dx[n0:n1], _sub(addend, n0, n1)
@@ -252,13 +258,13 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
                 st = None
                 if gate is not None:
                     groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))
-                    st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
+                    st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy, second)
                     parts.append(part)
                 dyin = _dyin_struct(lazy, n0, n1)
                 call("ssv_conv2d_fwd_dyin", C.byref(d), ptr(dyc), C.byref(dyin), ptr(wt), ptr(adc), ptr(dxc), None if st is None else C.byref(st), stream())
             elif gate is not None:
                 groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))
-                st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
+                st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy, second)
                 call("ssv_conv2d_fwd_gated", C.byref(d), ptr(dyc), ptr(wt), ptr(adc), ptr(dxc), C.byref(st), stream())
                 parts.append(part)
             else:
@@ -275,6 +281,8 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     if parts:
         part = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)      # partial SUMS: any grouping of the rows adds up the same
         dx._gate_partials = (part[0], part[1], part.shape[1])
+        if part.shape[0] == 3:                 # the same g against the projection shortcut's BatchNorm input
+            dx._gate_partials_res = (part[0], part[2], part.shape[1])
     return dx
 
 

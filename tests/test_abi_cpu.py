@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
 class AugCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("brightness", "contrast", "saturation", "hue", "p_jitter", "p_gray", "p_flip", "scale_min", "scale_max", "ratio_min", "ratio_max")]
 class BnGate(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx")]
+    _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mask", "mean", "invstd", "psum_g", "psum_gx", "x2", "mean2", "invstd2", "psum_gx2")]
 class BnDyin(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "coef")]
 PTR = {"p_conv": C.POINTER(ConvDesc), "p_aug": C.POINTER(AugCfg), "p_gate": C.POINTER(BnGate), "p_dyin": C.POINTER(BnDyin), "p_f32": C.POINTER(C.c_float),

@@ -531,3 +531,41 @@ def test_batchnorm_backward_formed_by_the_consumers_of_dx(dev, n, h, cin, k, xf,
     if gate is not None:
         for a, b in zip(d1._gate_partials[:2], d2._gate_partials[:2]):
             close(b.sum(0), a.sum(0), rtol=1e-4, what="gate partial sums")
+
+
+@pytest.mark.parametrize("n,h,k,c,lazy_dy", [(3, 7, 64, 256, False), (2, 9, 128, 512, True), (5, 5, 64, 64, False)])
+def test_gate_epilogue_also_reduces_against_the_projection_shortcut_input(dev, n, h, k, c, lazy_dy):
+    """ssv_bn_gate's second target: the gated gradient g of a unit's closing activation is also the gradient w.r.t. the projection shortcut's
+    BatchNorm output, so the stride-1 data gradient that produces g leaves sum g * xhat2 against THAT BatchNorm's input next to the usual
+    (sum g, sum g * xhat) - with a plain and with a formed-on-load (LazyGrad) dY operand."""
+    from ssv_amd import ops
+    m = n * h * h
+    w = (seeded_randn(951, k, c, 1, 1) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)      # conv1 of the next unit: c -> k
+    dy = seeded_randn(952, n, h, h, k).to(dev)
+    x1 = (seeded_randn(953, n, h, h, c) * 1.3 + 0.4).to(dev)          # input of the closing BatchNorm
+    x2 = (seeded_randn(954, n, h, h, c) * 0.7 - 0.2).to(dev)          # input of the projection shortcut's BatchNorm
+    stats = lambda t: (t.reshape(m, c).mean(0), 1.0 / torch.sqrt(t.reshape(m, c).var(0, unbiased=False) + 1e-5))
+    (m1, i1), (m2, i2) = stats(x1), stats(x2)
+    mask = torch.randint(0, 16, (m * c // 4,), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).to(dev)
+    addend = seeded_randn(955, n, h, h, c).to(dev)
+    gate = ops.BnGateCtx(x1, m1, i1, mask=mask, second=(x2, m2, i2))
+    src = dy
+    if lazy_dy:
+        xb = seeded_randn(956, n, h, h, k).to(dev)
+        coef = torch.stack([torch.rand(k, generator=torch.Generator().manual_seed(3)) + 0.5, torch.zeros(k), torch.zeros(k), torch.zeros(k)]).to(dev).contiguous()
+        src = ops.LazyGrad(dy, xb, coef)                              # dx = A * g (B = D = 0): the plain product scaled per channel
+        dy_eff = dy * coef[0]
+    else:
+        dy_eff = dy
+    g = ops.conv2d_dgrad(src, w, (n, h, h, c), 1, 0, addend=addend.clone(), gate=gate)
+    bits = torch.stack([(mask >> e) & 1 for e in range(4)], dim=1).reshape(m, c).bool()
+    want = torch.where(bits, (dy_eff.reshape(m, k).double() @ w.reshape(k, c).double() + addend.reshape(m, c).double()), torch.zeros((), dtype=torch.float64, device=dev))
+    close(g.reshape(m, c), want.float(), rtol=1e-4, what="gated gradient")
+    pg, pgx, _ = g._gate_partials
+    pg2, pgx2, _ = g._gate_partials_res
+    assert pg2.data_ptr() == pg.data_ptr()
+    xh1 = (x1.reshape(m, c).double() - m1.double()) * i1.double()
+    xh2 = (x2.reshape(m, c).double() - m2.double()) * i2.double()
+    close(pg.sum(0), want.sum(0).float(), rtol=1e-4, what="sum g")
+    close(pgx.sum(0), (want * xh1).sum(0).float(), rtol=1e-4, what="sum g * xhat")
+    close(pgx2.sum(0), (want * xh2).sum(0).float(), rtol=1e-4, what="sum g * xhat2")

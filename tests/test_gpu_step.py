@@ -558,3 +558,36 @@ def test_closing_activation_formed_by_the_next_conv1_is_bitwise_the_element_wise
             continue
         worst = max(worst, float((a - r).norm() / r.norm()))
     assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"
+
+
+@pytest.mark.parametrize("arch,size,b", [("resnet50", 64, 6), ("resnet50", 96, 3)])
+def test_projection_shortcut_backward_without_its_reduction_pass_matches_the_two_pass_form(dev, arch, size, b):
+    """The gate epilogue that produces the gated gradient of a unit's closing activation also reduces it against the projection shortcut's
+    BatchNorm input (ssv_bn_gate.x2), so that BatchNorm's backward skips its reduction pass (and, behind the stride-1 shortcut of the first
+    stage, its element-wise pass too).  Forward untouched; every gradient tensor agrees with the two-pass form to rounding."""
+    from ssv_amd import nn as hnn
+    a1, a2 = seeded_randn(2000, b, 3, size, size), seeded_randn(2001, b, 3, size, size)
+    outs = []
+    prev_hw, hnn._BN_DY_MIN_HW = hnn._BN_DY_MIN_HW, 0
+    try:
+        for fuse in (True, False):
+            prev, hnn._FUSE_SHORTCUT_GATE = hnn._FUSE_SHORTCUT_GATE, fuse
+            try:
+                m = _Step(dev, arch, False)
+                loss, z1, z2 = m.step(a1, a2)
+                torch.cuda.synchronize()
+                outs.append((loss, z1.cpu(), m, m.grads.cpu().clone()))
+            finally:
+                hnn._FUSE_SHORTCUT_GATE = prev
+    finally:
+        hnn._BN_DY_MIN_HW = prev_hw
+    (lf, zf, m, gf), (lu, zu, _, gu) = outs
+    assert lf == lu and torch.equal(zf, zu)
+    worst = 0.0
+    for p, off in zip(m.params(), m.optim.arena.offsets):
+        a, r = gf[off:off + p.numel()].double(), gu[off:off + p.numel()].double()
+        if float(r.norm()) < 1e-5:
+            assert float(a.abs().max()) < 1e-5
+            continue
+        worst = max(worst, float((a - r).norm() / r.norm()))
+    assert 0.0 < worst < 2e-5, f"worst per-tensor gradient difference {worst:.2e} (0 = the fused path did not run)"
