@@ -82,16 +82,28 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     dw = torch.zeros_like(w)
     aff = (torch.rand(Cx, device=dev) + 0.5, torch.randn(Cx, device=dev) * 0.1)
     stats_ok = Cx % 32 == 0 and K % 4 == 0
-    if kind == "lazy" and ops.can_fuse_conv_input(Cx, K):
+    # what the training step hands these layers (nn.py): dY formed on load behind 1x1 / stride-1 convolutions on maps of >= 28x28, and the
+    # closing activation of the previous unit formed and written by conv1 on such maps (every conv1 but the first one, whose input is the pool's)
+    big = Ho * Ho >= 784
+    dyl = ops.LazyGrad(dy, torch.randn_like(y), torch.randn(4, K, device=dev).contiguous()) if (big and C != 3 and ops.can_lazy_dy(w.shape, s, p)) else None
+    sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= 784 and ops.can_form_closing_sum(w.shape, s, p)
+    if sum_in:
+        fv = "stats+sum_in"
+        res = torch.randn_like(x)
+        t_f = timeit(lambda: ops.conv2d_fwd_sumin(x, res, aff[0], aff[1], None, w, want_mask=True))
+        wv = "plain" + ("+dy_in" if dyl is not None else "")
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True))
+        del res
+    elif kind == "lazy" and ops.can_fuse_conv_input(Cx, K):
         fv = "stats+bn_in"
         t_f = timeit(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True))
-        wv = "bn_in"
-        t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, s, p, accumulate=True, in_affine=aff))
+        wv = "bn_in" + ("+dy_in" if dyl is not None else "")
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True, in_affine=aff))
     else:
         fv = "stats" if stats_ok else ("c4" if Cx == 4 else "plain")
         t_f = timeit((lambda: ops.conv2d_fwd_stats(x, w, s, p)) if stats_ok else (lambda: ops.conv2d_fwd(x, w, s, p)))
-        wv = "plain"
-        t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, s, p, accumulate=True))
+        wv = "plain" + ("+dy_in" if dyl is not None else "")
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True))
     if C == 3:
         dv, t_d, dwgs = "-", float("nan"), 0
     else:
@@ -103,8 +115,8 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         else:
             gate = ops.BnGateCtx(gx, mean, invstd, mask=torch.randint(0, 16, (x.numel() // 4,), device=dev, dtype=torch.uint8))
         addend = torch.randn_like(x) if kind == "plain" else None
-        dv = ("fwd-kernel" if s == 1 else "dgrad-kernel") + "+gate" + ("+addend" if addend is not None else "")
-        t_d = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, s, p, addend=addend, gate=gate))
+        dv = ("fwd-kernel" if s == 1 else "dgrad-kernel") + "+gate" + ("+addend" if addend is not None else "") + ("+dy_in" if dyl is not None else "")
+        t_d = timeit(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate))
         dwgs = grid_fwd(B * H * H, C) if s == 1 else s * s * grid_fwd(B * (-(-H // s)) ** 2, C)
     tf = lambda t: flop / (t * 1e-3) / 1e12
     wgs = grid_fwd(m, K)
