@@ -462,15 +462,38 @@ def test_batches_beyond_the_per_launch_limit_are_split_on_the_host(dev, monkeypa
         dw = torch.zeros_like(w)
         ops.conv2d_wgrad(x, dy, w, dw, 1, 1, accumulate=True, in_affine=aff)
         return y, part[0], part[1], y2, dx.clone(), dx2.clone(), sums, dw
+    # the operands formed on load (1x1 / stride 1): closing activation formed and written by the convolution, BatchNorm-backward dY with a
+    # gate that also reduces against a second BatchNorm input
+    w1 = (seeded_randn(15, k, c, 1, 1) * 0.1).contiguous(memory_format=torch.channels_last).to(dev)
+    res = seeded_randn(16, n, h, h, c).to(dev)
+    xb = seeded_randn(17, n, h, h, k).to(dev)
+    coef = (torch.rand(4, k, device=dev) + 0.25).contiguous()
+    gx2 = seeded_randn(18, n, h, h, c).to(dev)
+
+    def run_formed():
+        y, part, a, am = ops.conv2d_fwd_sumin(x, res, aff[0], aff[1], (aff[0] * 0.5, aff[1] + 0.1), w1, want_mask=True)
+        lazy = ops.LazyGrad(dy, xb, coef)
+        dx = ops.conv2d_dgrad(lazy, w1, x.shape, 1, 0, addend=gx.clone(), gate=ops.BnGateCtx(gx, mean, invstd, mask=mask, second=(gx2, mean * 0.5, invstd)))
+        sums = (dx._gate_partials[0].sum(0), dx._gate_partials[1].sum(0), dx._gate_partials_res[1].sum(0))
+        dw = torch.zeros_like(w1)
+        ops.conv2d_wgrad(x, lazy, w1, dw, 1, 0, accumulate=True)
+        return y, part[0], part[1], a, am, dx.clone(), sums, dw
     whole = run()
+    whole_f = run_formed()
     monkeypatch.setattr(ops, "_MAX_ELEMS", 8 * h * h * k + 1)          # 8 samples per launch -> 3 chunks of 8 (8*64 rows: multiple of 64)
     assert len(ops._batch_chunks(n, (h * h * c, h * h * k), rows_per_sample=h * h)) == 3
     split = run()
+    split_f = run_formed()
     for i in (0, 1, 2, 3, 4, 5):
         assert torch.equal(whole[i], split[i]), i
     for a, b in zip(whole[6], split[6]):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-4)
     close(split[7], whole[7], rtol=1e-5, what="wgrad over chunks")
+    for i in (0, 1, 2, 3, 4, 5):
+        assert torch.equal(whole_f[i], split_f[i]), f"formed operands, output {i}"
+    for a, b in zip(whole_f[6], split_f[6]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    close(split_f[7], whole_f[7], rtol=1e-5, what="wgrad from the lazy dY over chunks")
 
 
 @pytest.mark.parametrize("n,h,cin,k,xf,gate_kind", [(3, 7, 64, 256, False, None), (2, 9, 64, 256, True, "affine"), (3, 7, 256, 512, False, "mask"),
