@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 # rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh); newest kernel state first
 PMC_FILES = {"simclr": ("r02_simclr_b%d_pmc_hbm_traffic.json", "r01_n_pmc_hbm_traffic_b%d.json"),
              "dino": ("r02_dino_b%d_pmc_hbm_traffic.json", "r01_l_pmc_hbm_traffic_dino_b%d.json")}
+CONV_LAYER_FILES = ("r03_conv_layers_b%d.csv",)     # tools/bench_conv.py: per-layer operand-stream bytes of the variants the step launches
 PMC_MFMA_FILES = {"simclr": ("r02_simclr_b%d_pmc_mfma.json",), "dino": ("r02_dino_b%d_pmc_mfma.json",)}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
@@ -120,7 +121,7 @@ def build(device, algo, steps_per_epoch=1000, lr_scale=1.0):
     torch.manual_seed(420)                                     # identical weights on every rank
     t._build("vit" if algo == "dino" else "resnet50")
     t.scheduler, t.warmup_epochs = train_utils.get_scheduler({**t.config["scheduler"], "epochs": 1000}, optimizer=t.optim)   # lr seeded to lr/10
-    hdist.attach_grad_sync(t.optim)
+    hdist.attach_grad_sync(t.optim, t._sync_modules())
     state = {"i": 0}
 
     def step(batch):
@@ -169,17 +170,39 @@ def _cpu_model():
     return "unknown"
 
 
-GATE_LR_SCALE = 0.01        # the parity gate trains at config lr / 100: every step is then a well-posed comparison
+GATE_LR_SCALE = 0.01        # the parity gate trains at config lr / 100 (the gate's own statement, DESIGN 2: ResNet-50 at batch 32 is ill-conditioned at ANY
+                            # learning rate - the fp32 CPU oracle is 1e-3 .. 1e-2 from its own fp64 twin after one update - so steps >= 1 are held to the
+                            # fp64 envelope of the CPU path, not to a fixed 1e-4)
+
+
+def _twin64(make):
+    """An fp64 copy of an oracle trainer with the SAME (fp32-drawn) weights."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        m64 = make()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    src = make()
+    def copy(dst, s_):
+        for k in dst:
+            if isinstance(dst[k], dict):
+                copy(dst[k], s_[k])
+            elif dst[k].dtype.is_floating_point:
+                dst[k].data = s_[k].detach().double()
+    for attr in ("encoder", "proj_head", "online", "target"):
+        if hasattr(m64, attr):
+            copy(getattr(m64, attr), getattr(src, attr))
+    return m64
 
 
 def cpu_baseline(views, steps, algo="simclr", lr_scale=GATE_LR_SCALE):
     """The oracle (CPU restatement of the reference step, pinned to reference fixtures) on this box's host cores, on the SAME augmented
-    views the GPU path is given: (v1, v2) fp32 [B,3,S,S] CPU tensors.  1 warm-up + `steps` timed steps; every step's loss
-    and the step-0 embeddings are returned for the parity gate."""
+    views the GPU path is given: (v1, v2) fp32 [B,3,S,S] CPU tensors.  1 warm-up + `steps` timed fp32 steps; then, untimed, an
+    fp64 twin of the oracle (same initial weights) runs the same steps: the centre the parity gate measures both fp32 paths against."""
     import oracle
     host = os.cpu_count() or 1
-    # SURVEY 8d asks for all host cores; measured on the 256-thread GPU boxes (2 x EPYC 9575F) the ATen / oneDNN step is pathological
-    # there: 320 s for ONE batch-32 step at 256 threads against 4 s at 32 (profiles/r02_e_bench_default.log).  32 threads is what the
+    # SURVEY 8d asks for all host cores; on the 256-thread GPU boxes (2 x EPYC 9575F) the ATen / oneDNN step is pathological at 256 threads
+    # (round 2 measured ~320 s for ONE batch-32 step there against 3.5 s at 32 threads; that log was not kept).  32 threads is what the
     # baseline uses; host_cpus and the CPU model are reported next to it.
     torch.set_num_threads(min(host, 32))
     v1, v2 = views
@@ -187,37 +210,30 @@ def cpu_baseline(views, steps, algo="simclr", lr_scale=GATE_LR_SCALE):
     base = BENCH_CFG[algo]["optimizer"]
     lr = 1e-12 + base["lr"] * lr_scale / 10                    # get_scheduler's warm-up seeding (utils/train_utils.py:31-33), as the trainer
     if algo == "byol":
-        m = oracle.BYOLOracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"], max_steps=1000 * 1000)
+        make = lambda: oracle.BYOLOracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"], max_steps=1000 * 1000)
     elif algo == "barlow":
-        m = oracle.BarlowOracle("resnet50", False, 4096, lr=lr, weight_decay=base["weight_decay"], normalize=True)
+        make = lambda: oracle.BarlowOracle("resnet50", False, 4096, lr=lr, weight_decay=base["weight_decay"], normalize=True)
     else:
-        m = oracle.SimCLROracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"])
-    run = (lambda s: m.train_step(v1, v2, step=s)) if algo == "byol" else (lambda s: m.train_step(v1, v2, **({"return_z": True} if s == 0 and algo != "byol" else {})))
-    z64 = None
-    if algo == "simclr":                                       # fp64 evaluation of the step-0 embeddings: the centre the gate measures distances to
-        torch.set_default_dtype(torch.float64)
-        try:
-            m64 = oracle.SimCLROracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"])
-        finally:
-            torch.set_default_dtype(torch.float32)
-        for dst, src in ((m64.encoder, m.encoder), (m64.proj_head, m.proj_head)):
-            for k in dst:
-                if dst[k].dtype.is_floating_point:
-                    dst[k].data = src[k].detach().double()
-        with torch.no_grad():
-            z64 = m64.embed(v1.double())
-        del m64
+        make = lambda: oracle.SimCLROracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"])
+    m = make()
+    step_of = lambda mm, a, b_: (lambda s: mm.train_step(a, b_, step=s)) if algo == "byol" else (lambda s: mm.train_step(a, b_, **({"return_z": True} if s == 0 else {})))
+    run = step_of(m, v1, v2)
     first = run(0)                                             # warm-up step = step 0 of the gate
-    note = ""
     losses = [first["loss"]]
     t0 = time.perf_counter()
     for s in range(1, steps + 1):
         losses.append(run(s)["loss"])
     dt = (time.perf_counter() - t0) / steps
+    del m
+    m64 = _twin64(make)
+    run64 = step_of(m64, v1.double(), v2.double())
+    first64 = run64(0)
+    losses64 = [first64["loss"]] + [run64(s)["loss"] for s in range(1, steps + 1)]
+    del m64
     out = {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cpus": host, "cpu_model": _cpu_model(), "kind": "port",
            "sample": f"{steps} timed steps (1 warm-up) of the same {algo} ResNet-50 {size}x{size} step at batch {batch} on the GPU path's own augmented views, "
-                     f"torch fp32 CPU, lr = config / {round(1 / lr_scale)}" + note}
-    return out, losses, first.get("z_1"), z64
+                     f"torch fp32 CPU, lr = config / {round(1 / lr_scale)}"}
+    return out, losses, losses64, first.get("z_1"), first64.get("z_1")
 
 
 def cpu_baseline_dino(batch=2, steps=6):
@@ -257,14 +273,28 @@ def parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, bat
     torch.cuda.synchronize()
     del hip_step, t
     torch.cuda.empty_cache()
-    base, cpu_losses, z_cpu, z64 = cpu_baseline((v1.cpu().contiguous(), v2.cpu().contiguous()), steps, algo)
+    base, cpu_losses, f64_losses, z_cpu, z64 = cpu_baseline((v1.cpu().contiguous(), v2.cpu().contiguous()), steps, algo)
     rel = [abs(h - c) / abs(c) for h, c in zip(hip_losses, cpu_losses)]
+    d_hip = [abs(h - f) / abs(f) for h, f in zip(hip_losses, f64_losses)]
+    d_cpu = [abs(c - f) / abs(f) for c, f in zip(cpu_losses, f64_losses)]
+    sci = lambda xs: [float(f"{x:.2e}") for x in xs]
     gate = {"workload": f"{algo} ResNet-50 {v1.shape[-1]}x{v1.shape[-1]}, batch {b}, the bench's own augmented views, lr = config / {round(1 / GATE_LR_SCALE)}, {steps + 1} steps on that batch",
-            "loss_hip": [round(x, 7) for x in hip_losses], "loss_cpu": [round(x, 7) for x in cpu_losses], "loss_rel_err": [float(f"{x:.2e}") for x in rel],
-            "bar": {"loss_rel_step0": 1e-4, "z_abs_step0": "1e-4, or no further from an fp64 evaluation than 3x the fp32 CPU path is"},
-            "later_steps": "informational: ResNet-50 on a batch of 32 is a chaotic trajectory for ANY fp32 evaluation (a ReLU of the head flips for a 1e-4 "
-                           "forward difference and moves every gradient by ~1e-2); the per-step 1e-4 bar is enforced where it is well posed, tests/test_gpu_trajectories.py"}
+            "loss_hip": [round(x, 7) for x in hip_losses], "loss_cpu": [round(x, 7) for x in cpu_losses], "loss_cpu_fp64": [round(x, 7) for x in f64_losses],
+            "loss_rel_err": sci(rel), "loss_rel_err_hip_vs_fp64": sci(d_hip), "loss_rel_err_cpu32_vs_fp64": sci(d_cpu),
+            "bar": {"loss_step0": "1e-4 relative to the fp32 CPU oracle (north-star)",
+                    "loss_every_step": "no further from the fp64 twin of the oracle than 3x the furthest the fp32 CPU oracle gets from it on this trajectory, + 1e-4: "
+                                       "after one update two fp32 evaluations of this network at batch 32 are 1e-3 .. 1e-2 apart (the CPU oracle against "
+                                       "its own fp64 twin: loss_rel_err_cpu32_vs_fp64), so a fixed 1e-4 is not a well-posed bar beyond step 0 "
+                                       "(DEVIATION from the north-star's wording; DESIGN 2, tests/test_gpu_r50_parity.py)",
+                    "z_abs_step0": "1e-4, or no further from the fp64 evaluation than 3x the fp32 CPU path is (DEVIATION: the CPU path itself is "
+                                   "3-4e-4 from fp64 on this network)"}}
     ok = rel[0] <= 1e-4
+    # steps >= 1: the distance of ONE fp32 evaluation to fp64 at one step is a draw of a chaotic quantity (it can be 5e-4 on one step and 9e-3 on
+    # the next); the yardstick is the size class the CPU path shows over the whole trajectory
+    worst = max(d_cpu)
+    steps_ok = [bool(dh <= (3 * d_cpu[0] + 1e-4 if i == 0 else 3 * worst + 1e-4)) for i, dh in enumerate(d_hip)]
+    gate["steps_pass"] = steps_ok
+    ok = ok and all(steps_ok)
     if z_cpu is not None and "z_1" in captured:
         dz = float((captured["z_1"] - z_cpu).abs().max())
         gate["z_max_abs_err_step0"] = float(f"{dz:.2e}")
@@ -294,8 +324,8 @@ def main():
     from ssv_amd import _lib, distributed as hdist
     rank, world = hdist.init_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s): launch with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -343,10 +373,29 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    dist_info = None
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        import torch.distributed as dist
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(v.item()) for v in every]
+        dt = max(per_rank)                                         # MAX over ranks: the step is as slow as its slowest rank
+        # what the exchange costs: extra steps (after the timed region) with an event pair around every collective, on the stream it runs on
+        hdist.comm_timing(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        comm = torch.tensor([hdist.comm_timing(False) / 2], device=device, dtype=torch.float64)
+        dist.all_reduce(comm, op=dist.ReduceOp.MAX)
+        sync = getattr(train_step.trainer.optim, "grad_sync", None)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_gpu": 1,
+                     "ms_per_step_min_over_ranks": round(min(per_rank) / args.steps * 1e3, 3), "ms_per_step_max_over_ranks": round(max(per_rank) / args.steps * 1e3, 3),
+                     "comm_ms_per_step": round(float(comm.item()), 3),
+                     "comm_note": "device time between HIP events around every collective (embedding / LSE all-gathers, per-bucket gradient all-reduces on the "
+                                  "exchange stream), max over ranks, 2 extra steps; the bucketed all-reduces overlap the backward pass, so this is not additive to ms_per_step",
+                     "gradient_buckets": None if sync is None else [[n, (hi - lo) * 4] for n, lo, hi in sync.buckets]}
+        assert dist_info["world_size"] == args.gpus
     ms_per_step = dt / args.steps * 1e3
     images_per_s = b * world * args.steps / dt
 
@@ -402,12 +451,35 @@ def main():
             mfma = dict(mfma["summary"], source=os.path.relpath(mpath, ROOT))
         except (OSError, KeyError, ValueError, StopIteration):
             mfma = None
+        # operand streams of the conv family in the variants the step launches (the fused BatchNorm operands - shortcut, BatchNorm input, gate
+        # operands, the written activation - are streams of these kernels now): per view from tools/bench_conv.py's per-layer model, x 2 views
+        family_gb, family_src = None, None
+        if args.algo == "simclr":
+            try:
+                import csv
+                cpath = next(pth for pth in (os.path.join(ROOT, "profiles", f % b) for f in CONV_LAYER_FILES) if os.path.exists(pth))
+                with open(cpath) as fh:
+                    tot = [r for r in csv.DictReader(fh) if r["layer"].startswith("TOTAL")]
+                family_gb, family_src = round(2 * sum(float(r["fwd_GB"]) for r in tot), 1), os.path.relpath(cpath, ROOT)
+            except (OSError, KeyError, ValueError, StopIteration):
+                pass
+        whole_traffic = None
+        try:
+            whole_traffic = round(sum(v["fetch"] + v["write"] for v in pmc.values()), 1)
+        except (NameError, KeyError, TypeError):
+            pass
         attn_ms = prof.get("attn", (0.0, 0))[0] / args.prof_steps
         roof = {"bound": "mfma", "kernel": ("implicit-GEMM family running the Linear layers" if args.algo == "dino" else "conv implicit-GEMM family") +
                                            " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, %s)" % (os.path.relpath(pmc_path, ROOT) if traffic is not None else "no PMC pass for this workload"),
-                "algorithmic_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
+                "algorithmic_gb_per_step": family_gb if family_gb is not None else (None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1)),
+                "algorithmic_gb_note": ("every operand stream of the family's kernels moved once, fused BatchNorm operands included (%s)" % family_src) if family_gb is not None
+                                       else "conv operands only (x, w, y once per product): the fused BatchNorm streams these kernels also carry are NOT in this figure",
+                "conv_operands_only_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
+                # whole step: PMC traffic of ALL kernels against SURVEY 8(d)'s streaming model (1.067 GB / sample: 12 fp32 accesses per conv-output element)
+                "whole_step_traffic_gb": whole_traffic,
+                "whole_step_algorithmic_gb": round(1.067 * b, 1) if args.algo == "simclr" else None,
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
                 "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
@@ -431,8 +503,12 @@ def main():
                    "input": f"uint8 [B,{s},{s},3] source resident in HBM -> fused GPU two-view augmentation each step",
                    "per_gpu_batch": b, "global_batch": b * world, "image": [3, s, s], "params": nparams,
                    "parallelism": f"dp{world}" if world > 1 else "single", "view_streams": 2 if hnn.view_streams() else 1, "last_loss": loss,
-                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1)},
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
+                   # every SSV_* variable in the environment: the product's diagnostic switches - {} = the shipped kernel selection
+                   "diagnostic_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("SSV_")},
+                   "library": os.path.relpath(_lib.LIB_PATH, ROOT)},
         "roofline": roof,
+        "distributed": dist_info,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.algo == "dino":

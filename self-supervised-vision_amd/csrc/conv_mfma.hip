@@ -42,6 +42,18 @@
 #ifndef SSV_CONV_WGPC
 #define SSV_CONV_WGPC 3     // resident workgroups per CU the forward / data-gradient kernels are compiled for
 #endif
+#ifndef SSV_OPM_WGPC
+#define SSV_OPM_WGPC 2      // ... and the formed-on-load (OPM) / two-target gate (GATE 3) variants, whose second operand stream costs registers
+#endif
+#ifndef SSV_NARROW_DEEP
+#define SSV_NARROW_DEEP 0   // 1: layers with fewer than 128 output channels run a 128 x 64 tile with K-step 64 (256-byte row pieces) instead of 256 x 64 / K-step 32
+#endif
+#ifndef SSV_OPM_BK
+#define SSV_OPM_BK 32       // K-step of the formed-on-load variants on the 128 x 128 tile (16: half the staging registers per stream)
+#endif
+#ifndef SSV_GATE_HB
+#define SSV_GATE_HB 0       // > 0: rows per load batch of the gated epilogues (default: 2 for GATE 1 / 3, 4 otherwise)
+#endif
 
 namespace {
 
@@ -312,7 +324,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
                                              const ssv_bn_gate* bn = nullptr, long long group = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
   constexpr bool GMASK = GATE >= 2, GX2 = GATE == 3;
-  constexpr int HB = (GATE == 1 || GX2) ? 2 : (NP < 4 ? NP : 4);   // rows per batch: the loads of a batch are in flight together (register budget of 3 workgroups per CU)
+  constexpr int HB0 = (GATE != 0 && SSV_GATE_HB > 0) ? SSV_GATE_HB : ((GATE == 1 || GX2) ? 2 : 4);
+  constexpr int HB = NP < HB0 ? NP : HB0;   // rows per batch: the loads of a batch are in flight together (register budget of 3 workgroups per CU)
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
@@ -449,7 +462,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
 template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0>
-__global__ void __launch_bounds__(256, (OPM || GATE == 3) ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+__global__ void __launch_bounds__(256, (OPM || GATE == 3) ? SSV_OPM_WGPC : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -458,7 +471,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   static_assert(!XF || (VEC && !C4), "the fused-input variant is the float4 path");
   constexpr bool DYF = OPM == 1, SUM = OPM == 2;
   static_assert(OPM == 0 || (VEC && !C4 && !XF), "the formed-on-load operands are the float4 path");
-  __shared__ __attribute__((aligned(16))) float smem[STAGE + SSV_EXP_LDS_PAD];
+  constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);     // the vectorised epilogue's staging area (one 32-row slab per wave)
+  constexpr int SMEM = (VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM + SSV_EXP_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
   float* As = smem;
   float* Bs = smem + BM * LDT;
@@ -720,9 +735,8 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   }
 
   // ---- epilogue: acc reg j of lane l is (row (j&3)+8*(j>>2)+4*(l>>5), col l&31) of its 32x32 tile ----
-  constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
-  static_assert(!(EPI || STATS) || (VEC && EP_FLOATS <= STAGE), "the fused-activation / statistics forward needs the vectorised epilogue");
-  if constexpr (VEC && EP_FLOATS <= STAGE) {
+  static_assert(!(EPI || STATS) || (VEC && EP_FLOATS <= SMEM), "the fused-activation / statistics forward needs the vectorised epilogue");
+  if constexpr (VEC && EP_FLOATS <= SMEM) {
     if ((p.K & 3) == 0) {             // 16-byte stores need K % 4 == 0 (uniform): whole rows segments through LDS
       const int rbase = m0 + wr0;
       if constexpr (STATS) {
@@ -746,7 +760,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       return;
     }
   }
-  static_assert(GATE == 0 || (VEC && EP_FLOATS <= STAGE), "the gated epilogue is the vectorised one");
+  static_assert(GATE == 0 || (VEC && EP_FLOATS <= SMEM), "the gated epilogue is the vectorised one");
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -1212,6 +1226,9 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
 // K-step 32 when the contraction's channel count allows it, else 16; tile by output width.
 namespace {
 
+// narrow layers (fewer than 128 output channels) on the 128 x 64 tile with K-step 64: SSV_NARROW_DEEP builds, channel counts that allow it
+inline bool narrow_deep(const ssv_conv_desc* d) { return SSV_NARROW_DEEP && d->K < 128 && d->C % 64 == 0; }
+
 // forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
 int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
                float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s, const ssv_bn_gate* gate = nullptr) {
@@ -1219,21 +1236,24 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
   const bool wide = d->K >= 128;
+  const bool deep = narrow_deep(d) && !xf;                     // 128 x 64 tile, K-step 64 (SSV_NARROW_DEEP builds)
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, deep ? 128 : 256) * cdiv(d->K, 64));
   if (gate) {                                                  // C % 32 == 0 checked by the caller
     p.gate = *gate;
-    const unsigned gg = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-#define FWDG(BM_, BN_, WM_, WN_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(gg), dim3(256), 0, s, p, x, w, bias, addend, y)
-    if (gate->x2)        { if (wide) FWDG(128, 128, 2, 2, 3); else FWDG(256, 64, 4, 1, 3); }
-    else if (gate->mask) { if (wide) FWDG(128, 128, 2, 2, 2); else FWDG(256, 64, 4, 1, 2); }
-    else                 { if (wide) FWDG(128, 128, 2, 2, 1); else FWDG(256, 64, 4, 1, 1); }
+#define FWDG(BM_, BN_, WM_, WN_, BK_, G_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, false, false, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWDG_TILE(G_) do { if (wide) FWDG(128, 128, 2, 2, 32, G_); else if (deep) { if constexpr (SSV_NARROW_DEEP) FWDG(128, 64, 2, 2, 64, G_); } \
+                           else FWDG(256, 64, 4, 1, 32, G_); } while (0)
+    if (gate->x2) FWDG_TILE(3); else if (gate->mask) FWDG_TILE(2); else FWDG_TILE(1);
+#undef FWDG_TILE
 #undef FWDG
     return SSV_OK;
   }
-  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
 #define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
+#define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); \
+                                          else if (deep && !(C4_) && !(XF_) && BK_ == 32) { if constexpr (SSV_NARROW_DEEP && !(C4_) && !(XF_) && BK_ == 32) FWD(128, 64, 2, 2, 64, ST_, false, false); } \
+                                          else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
   if (stats && d->C == 4) {                                    // the padded image stem with the statistics epilogue
     FWD_TILE(32, true, true, false);
   } else if (stats || xf) {                                    // C % 32 == 0 checked by the callers
@@ -1287,7 +1307,7 @@ int check_gate(const ssv_bn_gate* g, const char* who) {
 extern "C" int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d) {
   if (!d || d->K <= 0) return 0;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  const int bm = d->K >= 128 ? 128 : 256;
+  const int bm = (d->K >= 128 || narrow_deep(d)) ? 128 : 256;
   return cdiv64(M, bm) * (bm / 64);
 }
 
@@ -1322,12 +1342,13 @@ extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const
   ConvKP p = make_kp(d);
   p.dyin_x = dyin->x; p.dyin_coef = dyin->coef;
   if (gate) p.gate = *gate;
-  const bool wide = d->K >= 128;
-  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+  const bool wide = d->K >= 128, deep = narrow_deep(d);
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, deep ? 128 : 256) * cdiv(d->K, 64));
   const int gm = gate ? (gate->x2 ? 3 : (gate->mask ? 2 : 1)) : 0;
-#define FWDD(BM_, BN_, WM_, WN_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
-#define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
+#define FWDD(BM_, BN_, WM_, WN_, BK_, G_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+#define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, SSV_OPM_BK, G_); else if (deep) { if constexpr (SSV_NARROW_DEEP) FWDD(128, 64, 2, 2, 64, G_); } \
+                           else FWDD(256, 64, 4, 1, 32, G_); } while (0)
   if (gm == 3) FWDD_TILE(3); else if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
 #undef FWDD_TILE
 #undef FWDD
@@ -1353,9 +1374,10 @@ extern "C" int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x
   ConvKP p = make_kp(d);
   p.aux_out = pmean; p.aux_out2 = pm2;
   p.sum_res = res; p.sum_scale = scale; p.sum_shift = shift; p.sum_rscale = rscale; p.sum_rshift = rshift; p.sum_out = a_out; p.sum_mask = mask_out;
-  const bool wide = d->K >= 128;
-  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  const bool wide = d->K >= 128, deep = narrow_deep(d);
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, deep ? 128 : 256) * cdiv(d->K, 64));
+  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, SSV_OPM_BK, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  else if (deep) { if constexpr (SSV_NARROW_DEEP) hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, 64, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y); }
   else      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_sumin_stats");
   return SSV_OK;

@@ -28,12 +28,16 @@ extern "C" int ssv_device_cus(void) {
 // The ONLY process-wide mutable state of the library besides the thread-local error string, and off by default: when disabled an
 // entry point pays one relaxed atomic load.  When enabled, the record list is guarded by a mutex, and the begin / end pair of one
 // launch is matched through a thread-local slot, so concurrent callers (one host thread per stream) do not corrupt each other.
-struct ProfRec { int cls; hipEvent_t a, b; };
+struct ProfRec { int cls; hipEvent_t a, b; bool closed; };
 static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_recs;          // records of the current collection window (under g_prof_mu)
 static std::vector<ProfRec> g_free;          // recycled event pairs (under g_prof_mu)
-static thread_local int g_open = -1;         // index of this thread's record between begin and end
+static uint64_t g_gen = 0;                   // collection window number (under g_prof_mu): bumped whenever g_recs is recycled
+// this thread's record between begin and end: its index AND the window it belongs to - a collect / reset from another thread in
+// between recycles the list, and a stale index must not close somebody else's record
+static thread_local int g_open = -1;
+static thread_local uint64_t g_open_gen = 0;
 
 void ssv_prof_begin(int cls, hipStream_t s) {
   if (!g_prof_on.load(std::memory_order_relaxed)) return;
@@ -42,21 +46,27 @@ void ssv_prof_begin(int cls, hipStream_t s) {
   if (!g_free.empty()) { r = g_free.back(); g_free.pop_back(); }
   else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
   r.cls = cls;
+  r.closed = false;
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   g_open = (int)g_recs.size() - 1;
+  g_open_gen = g_gen;
 }
 void ssv_prof_end(int cls, hipStream_t s) {
   if (g_open < 0) return;
   (void)cls;
   std::lock_guard<std::mutex> lock(g_prof_mu);
-  if (g_open < (int)g_recs.size()) (void)hipEventRecord(g_recs[g_open].b, s);
+  if (g_open_gen == g_gen && g_open < (int)g_recs.size()) {
+    (void)hipEventRecord(g_recs[g_open].b, s);
+    g_recs[g_open].closed = true;
+  }
   g_open = -1;
 }
 extern "C" int ssv_prof_enable(int on) { g_prof_on.store(on != 0, std::memory_order_relaxed); return SSV_OK; }
 static int prof_reset_locked() {
   for (auto& r : g_recs) g_free.push_back(r);
   g_recs.clear();
+  g_gen += 1;
   return SSV_OK;
 }
 extern "C" int ssv_prof_reset(void) {
@@ -69,6 +79,7 @@ extern "C" int ssv_prof_collect(double* ms, int64_t* n) {
   std::lock_guard<std::mutex> lock(g_prof_mu);
   for (int i = 0; i < SSV_PROF_NCLASS; ++i) { ms[i] = 0.0; n[i] = 0; }
   for (auto& r : g_recs) {
+    if (!r.closed) continue;                 // begun on another thread and not ended yet: its end event was never recorded
     if (hipEventSynchronize(r.b) != hipSuccess) SSV_FAIL(SSV_ERR_LAUNCH, "prof: event sync failed");
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) SSV_FAIL(SSV_ERR_LAUNCH, "prof: elapsed failed");

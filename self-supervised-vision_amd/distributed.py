@@ -1,13 +1,17 @@
 """One process per GPU over RCCL (torch.distributed backend "nccl" on ROCm), launched with
 torch.distributed.run.  Only the exchange steps the path really has:
-  * all-gather of the projected embeddings (and their row log-sum-exps) so NT-Xent sees global negatives;
-  * one all-reduce(SUM) of the flat gradient arena before the optimizer update.
+  * all-gather of the projected embeddings (ONE call for both views) and of their row log-sum-exps (one call, the loss partial rides
+    along) so NT-Xent sees global negatives;
+  * all-reduce(SUM) of the gradient arena, per bucket (stem, the four stages, the heads), each bucket launched on a side stream as soon
+    as its last weight gradient of the backward pass has been enqueued (layer4 first) - SURVEY 8e "Collective 2".
 BatchNorm statistics stay local (per rank, per view) - the reference has no SyncBN.
 """
 import os
 
 import torch
 import torch.distributed as dist
+
+from . import ops
 
 
 _FORCE = False      # a world of ONE rank still takes the collective code paths (the single-GPU functional test of the RCCL calls)
@@ -53,24 +57,191 @@ def all_gather_rows(buf, rows_per_rank):
     if not is_on():
         return buf
     mine = buf[rank() * rows_per_rank:(rank() + 1) * rows_per_rank].clone()      # input must not alias the output
-    if dist.get_backend() == "nccl":
-        dist.all_gather_into_tensor(buf, mine)                                   # one RCCL all-gather straight into place
-    else:
-        dist.all_gather([buf[r * rows_per_rank:(r + 1) * rows_per_rank] for r in range(world_size())], mine)
+    with _timed(buf):
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(buf, mine)                               # one RCCL all-gather straight into place
+        else:
+            dist.all_gather([buf[r * rows_per_rank:(r + 1) * rows_per_rank] for r in range(world_size())], mine)
     return buf
+
+
+# ---- timing of the collectives (bench.py --gpus N: comm_ms_per_step) ------------------------------------------------------------
+_TIMED = None          # None = off; else a list of (start event, end event) recorded around every collective on the stream it was issued on
+
+
+def comm_timing(on):
+    """Start (True) / stop (False) recording an event pair around every collective.  Returns the previous records' total in ms."""
+    global _TIMED
+    total = comm_ms()
+    _TIMED = [] if on else None
+    return total
+
+
+def comm_ms():
+    """Sum of the recorded collectives' durations (device time between the events; call after a synchronize)."""
+    if not _TIMED:
+        return 0.0
+    return float(sum(a.elapsed_time(b) for a, b in _TIMED))
+
+
+class _timed:
+    def __init__(self, t):
+        self.on = _TIMED is not None and t.is_cuda
+
+    def __enter__(self):
+        if self.on:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            _TIMED.append((self.a, self.b))
+        return False
+
+
+def all_gather_blocks(out, mine):
+    """``out`` [world * n, ...] <- every rank's ``mine`` [n, ...] in rank order: ONE collective (RCCL all-gather straight into place)."""
+    if not is_on():
+        out.copy_(mine)
+        return out
+    with _timed(out):
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, mine)
+        else:
+            n = mine.shape[0]
+            dist.all_gather([out[r * n:(r + 1) * n] for r in range(world_size())], mine)
+    return out
 
 
 def all_reduce_sum(t):
     if is_on():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        with _timed(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
-def attach_grad_sync(optimizer):
-    """Data parallel: every rank back-propagates the GLOBAL-mean loss through its own samples, so the
-    SUM of the per-rank gradients is the large-batch gradient.  One contiguous all-reduce."""
+class BucketedGradSync:
+    """Data parallel gradient exchange (collective 2).  Every rank back-propagates the GLOBAL-mean loss through its own samples,
+    so the SUM of the per-rank gradients is the large-batch gradient.  The arena is cut into buckets - the stem, the four stages, the
+    heads: contiguous parameter runs - and a bucket is all-reduced as soon as every backward pass of the step (the two views run on two HIP
+    streams and accumulate into two gradient slabs) has reported its last weight gradient: on a side stream that waits for the reporting
+    streams' events, folds the second slab into the first and issues ONE all-reduce for the bucket, while the backward of the earlier
+    stages keeps the compute streams busy.  ``finish()`` (called by the optimizer's step) reduces whatever was not reported and makes the
+    update wait for the side stream.  Element by element this is the arithmetic of the single-call form (slab fold, then a SUM over ranks)."""
+
+    def __init__(self, optimizer, modules=(), bucketed=True):
+        self.arena = optimizer.arena
+        self.bucketed = bucketed
+        self.buckets = []                   # [name, lo, hi]
+        self.index = {}                     # (id(module), stage) -> bucket number
+        self.of_module = {}                 # id(outer module) -> bucket numbers its backward reports
+        self.pending, self.events, self.launched = {}, {}, set()
+        self.stream = None
+        off_of = {id(p): (o, (p.numel() + 63) // 64 * 64) for p, o in zip(self.arena.params, self.arena.offsets)}
+        taken = set()
+
+        def add(name, params, key):
+            spans = sorted(off_of[id(p)] for p in params if id(p) in off_of)
+            if not spans:
+                return None
+            lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+            if sum(n for _, n in spans) != hi - lo or any(lo <= b[1] < hi or lo < b[2] <= hi for b in self.buckets):
+                return None                 # not one contiguous, disjoint run of the arena: left to finish()
+            self.buckets.append([name, lo, hi])
+            self.index[key] = len(self.buckets) - 1
+            taken.update(id(p) for p in params)
+            return len(self.buckets) - 1
+
+        if bucketed:
+            for m in modules:
+                mine = []
+                for sub in m.modules():
+                    stages = sub.grad_stages() if hasattr(sub, "grad_stages") else []
+                    for i, params in enumerate(stages):
+                        b = add(f"{type(sub).__name__}.stage{i}", params, (id(sub), i))
+                        if b is not None:
+                            mine.append(b)
+                rest = [p for p in m.parameters() if id(p) not in taken]
+                b = add(f"{type(m).__name__}.rest", rest, (id(m), "rest"))
+                if b is not None:
+                    mine.append(b)
+                self.of_module[id(m)] = mine
+                object.__setattr__(m, "_grad_sync", self)
+
+    # ---- called by the tape ------------------------------------------------------------------------------------------------------
+    def has(self, module, stage):
+        return (id(module), stage) in self.index
+
+    def expect(self, module):
+        for b in self.of_module.get(id(module), ()):
+            self.pending[b] = self.pending.get(b, 0) + 1
+
+    def ready(self, module, stage):
+        b = self.index[(id(module), stage)]
+        if b in self.launched or self.pending.get(b, 0) <= 0:
+            return
+        grad = self.arena.grad
+        if grad.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()                      # on the view stream that has just enqueued this bucket's last weight gradient
+            self.events.setdefault(b, []).append(ev)
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    # ---- the exchange ------------------------------------------------------------------------------------------------------------
+    def _reduce(self, lo, hi):
+        a = self.arena
+        ops.add_(a.grad[lo:hi], a.grad_alt[lo:hi])          # fold the second view's slab (fixed order: slab 0 + slab 1)
+        all_reduce_sum(a.grad[lo:hi])
+
+    def _launch(self, b):
+        _, lo, hi = self.buckets[b]
+        grad = self.arena.grad
+        if grad.is_cuda:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(grad.device)
+            for ev in self.events.pop(b, ()):
+                self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                self._reduce(lo, hi)
+        else:
+            self._reduce(lo, hi)
+        self.launched.add(b)
+
+    def finish(self):
+        """Before the optimizer update: reduce every part of the arena no bucket covered or no backward pass reported, then make the
+        current stream wait for the exchange.  Afterwards slab 0 holds the global gradient (slab 1 is spent)."""
+        a = self.arena
+        done = sorted((self.buckets[b][1], self.buckets[b][2]) for b in self.launched)
+        if a.grad.is_cuda and self.stream is not None:
+            cur = torch.cuda.current_stream(a.grad.device)
+            self.stream.wait_stream(cur)                 # the leftovers below were produced on the compute streams
+            with torch.cuda.stream(self.stream):
+                self._leftovers(done)
+            cur.wait_stream(self.stream)
+        else:
+            self._leftovers(done)
+        self.pending.clear()
+        self.events.clear()
+        self.launched.clear()
+
+    def _leftovers(self, done):
+        pos = 0
+        for lo, hi in done + [(self.arena.numel, self.arena.numel)]:
+            if lo > pos:
+                self._reduce(pos, lo)
+            pos = max(pos, hi)
+
+
+def attach_grad_sync(optimizer, modules=(), bucketed=None):
+    """Data parallel: hand the optimizer its gradient exchange.  ``modules``: the bridged modules whose parameters the optimizer owns (their
+    stages become the buckets); without them - or with SSV_DIST_BUCKETS=0, a diagnostic switch - the whole arena is one call at step()."""
     if is_on():
-        optimizer.grad_sync = all_reduce_sum
+        if bucketed is None:
+            bucketed = os.environ.get("SSV_DIST_BUCKETS", "1") != "0"
+        optimizer.grad_sync = BucketedGradSync(optimizer, modules, bucketed=bucketed and len(modules) > 0)
     return optimizer
 
 

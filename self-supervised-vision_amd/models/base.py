@@ -67,10 +67,16 @@ class TwoViewTrainer:
         self.scheduler, self.warmup_epochs = train_utils.get_scheduler(sched_cfg, optimizer=self.optim)
         if self.warmup_epochs > 0:
             self.warmup_rate = (self.config["optimizer"]["lr"] - _WARMUP_FLOOR) / self.warmup_epochs
-        hdist.attach_grad_sync(self.optim)
+        hdist.attach_grad_sync(self.optim, self._sync_modules())
         self.best_metric = 0
         if args["load"] is not None:
             self.load_checkpoint(args["load"])
+
+    def _sync_modules(self):
+        """The bridged modules whose parameters the optimizer owns: their stages are the buckets of the data-parallel gradient exchange."""
+        from .. import nn as hnn
+        owned = {id(p) for p in self.optim.arena.params}
+        return [m for m in vars(self).values() if isinstance(m, hnn.HipModule) and any(id(p) in owned for p in m.parameters())]
 
     # ---- hooks an algorithm fills in ------------------------------------------------------------------------------
     def _build(self, arch):

@@ -139,9 +139,17 @@ class ResNet(hnn.HipModule):
         from .. import ops
         return ops.nchw_to_nhwc(x)
 
+    def grad_stages(self):
+        """Gradient buckets of the data-parallel exchange ("launched per bucket as wgrad finishes, layer4 first"): the stem and the
+        four stages, contiguous parameter runs of the optimizer's arena."""
+        return [list(self.conv1.parameters()) + list(self.bn1.parameters())] + \
+               [list(getattr(self, f"layer{idx}").parameters()) for idx in range(1, len(_STAGE_PLANES) + 1)]
+
     def _run(self, tape, x):
+        hnn.stage_mark(tape, self, 0)
         x = hnn.bn_relu_maxpool(tape, self.conv1._run(tape, x, bn_stats=True), self.bn1)      # one pass each way when the conv left statistics
         for idx in range(1, len(_STAGE_PLANES) + 1):
+            hnn.stage_mark(tape, self, idx)      # fires in backward once this stage's weight gradients are enqueued
             for unit in getattr(self, f"layer{idx}"):
                 x = unit._run(tape, x)
         return hnn.global_avgpool(tape, x)

@@ -107,6 +107,17 @@ class _ViewCtx:
 
 
 # ------------------------------------------------------------------------------------------- tape
+_MARK = object()
+
+
+def stage_mark(tape, module, stage):
+    """Data parallel (distributed.BucketedGradSync): tell the gradient exchange, during backward, that every parameter gradient of
+    ``module``'s stage ``stage`` has been enqueued by this pass.  Call it BEFORE running the stage's forward ops."""
+    sync = None if tape is None else tape.sync
+    if sync is not None and sync.has(module, stage):
+        tape.mark(lambda: sync.ready(module, stage))
+
+
 class Tape:
     """Records (inputs, output, backward closure) per op.  ``backward`` walks it in reverse; a
     closure gets the gradient of its output plus any gradient already accumulated for each of
@@ -117,6 +128,7 @@ class Tape:
         self.root = root
         self.root_needs_grad = root_needs_grad
         self.slot = _SLOT                     # which gradient slab this pass accumulates into
+        self.sync = None                      # data parallel: the gradient exchange that wants to hear when a bucket is complete
         self.uses = {}                        # id(input) -> number of recorded ops that read it
         self.last = ()                        # during backward: per input of the running op, "no other op will add to its gradient"
 
@@ -126,6 +138,11 @@ class Tape:
             if t is not None:
                 self.uses[id(t)] = self.uses.get(id(t), 0) + 1
 
+    def mark(self, fn):
+        """``fn()`` is called during backward once every op recorded AFTER this point has run its backward closure - i.e. when the parameter
+        gradients of everything that follows in the forward order have been enqueued (data parallel: a gradient bucket is complete)."""
+        self.ops.append((_MARK, None, fn))
+
     def needs_grad(self, t):
         return t is not self.root or self.root_needs_grad
 
@@ -134,6 +151,9 @@ class Tape:
         uses = self.uses
         while self.ops:
             inputs, output, bwd = self.ops.pop()
+            if inputs is _MARK:
+                bwd()
+                continue
             g = grads.pop(id(output), None)
             for t in inputs:
                 if t is not None:
@@ -454,7 +474,10 @@ def bn_relu_maxpool(tape, x, bn):
     """maxpool(relu(bn(x))) of the image stem (networks/resnet.py:147-148).  With the statistics partials of x at hand this is one pass
     each way: the full-resolution activation and its gradient are never written (ssv_bn_relu_maxpool_fwd / _bwd)."""
     partials = x.__dict__.get("_bn_partials")
-    if partials is None or not _FUSE_STEM_POOL or not _FUSE_BN_APPLY:
+    # the fused backward walks a map row by row in strides of RT = 256 / min(C / 4, 256) pixels and needs RT <= W (ssv_bn_relu_maxpool_bwd):
+    # narrower maps (inputs below 32 px behind the 7x7 / 2 stem) take the three-kernel path, which - like the reference - accepts any size
+    narrow = x.shape[2] < 256 // max(1, min(x.shape[3] // 4, 256))
+    if partials is None or not _FUSE_STEM_POOL or not _FUSE_BN_APPLY or narrow:
         return maxpool(tape, batchnorm(tape, x, bn, relu=True))
     x.__dict__.pop("_bn_partials")
     _bn_order_wait(bn, x)
@@ -703,6 +726,11 @@ class _Bridge(torch.autograd.Function):
             x.record_stream(torch.cuda.current_stream(x.device))      # produced on another stream, read on this one
         xin = module._prepare_input(x.detach())
         tape = Tape(xin, x.requires_grad) if record else None
+        sync = getattr(module, "_grad_sync", None)
+        if tape is not None and sync is not None:
+            tape.sync = sync
+            sync.expect(module)                  # one more backward pass will report this module's gradient buckets
+            stage_mark(tape, module, "rest")     # parameters outside any staged sub-module: complete when the whole tape has run
         y = module._run(tape, xin)
         ctx.tape, ctx.y, ctx.module = tape, y, module            # the tape keys the output by this object (it may be a LazySum)
         yt = _tensor(y)                                          # a module boundary is a consumer like any other: the tensor must exist
@@ -734,6 +762,12 @@ class HipModule(nn.Module):
 
     def _finish_input_grad(self, dx):
         return dx
+
+    def grad_stages(self):
+        """Data parallel: [[parameters of stage 0], [stage 1], ...] - runs of parameters whose gradients complete together during backward
+        (the LAST stage first) - or [] when the module is not staged.  A module that returns stages calls ``stage_mark(tape, self, i)``
+        before stage i's forward ops."""
+        return []
 
     def forward(self, x):
         # grad mode is read HERE: inside Function.forward autograd has already switched it off

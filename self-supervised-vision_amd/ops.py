@@ -51,11 +51,15 @@ def _batch_chunks(n, per_sample_elems, rows_per_sample=None):
     if n * worst < _MAX_ELEMS:
         return [(0, n)]
     nc = (_MAX_ELEMS - 1) // worst
-    if rows_per_sample is not None:
-        q = 64 // math.gcd(rows_per_sample, 64)
-        nc = nc // q * q
     if nc < 1:
         raise _lib.SsvError("a single sample exceeds the 2 GiB per-launch tensor limit of the convolution kernels")
+    if rows_per_sample is not None:
+        q = 64 // math.gcd(rows_per_sample, 64)
+        if nc // q * q < 1:
+            raise _lib.SsvError(f"the statistics epilogue needs chunks of a multiple of {q} samples ({rows_per_sample} output rows per sample) but only "
+                                f"{nc} sample(s) fit below the 2 GiB per-launch tensor limit: run this layer without the fused statistics "
+                                f"(SSV_NO_BN_STATS_FUSION=1) or with smaller images")
+        nc = nc // q * q
     return [(s0, min(s0 + nc, n)) for s0 in range(0, n, nc)]
 
 
@@ -80,6 +84,11 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
     _lib._dev(x, w)
     _, wshape = _ohwi(w)
     if (wshape[1] % 32 and wshape[1] != 4) or wshape[0] % 4:          # C == 4: the padded image stem
+        return None
+    d = conv_desc(x.shape, wshape, stride, pad)
+    try:                     # huge samples with an odd row count: no 64-row-aligned chunk fits one launch - the caller runs the stand-alone statistics pass
+        _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo)
+    except _lib.SsvError:
         return None
     y, part = conv2d_fwd_fused(x, w, stride, pad, in_affine=None, want_stats=True)
     return y, part[0], part[1]

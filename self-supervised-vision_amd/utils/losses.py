@@ -20,7 +20,8 @@ class _NTXentFn(torch.autograd.Function):
     """NT-Xent over the GLOBAL batch.  Each rank normalises its rows straight into their slots of the gathered
     matrix Z = [zi_all ; zj_all], all-gathers the slots (RCCL), computes the log-sum-exp of ITS rows against all
     columns, and - because S is symmetric - needs only the all-gathered row LSEs to form the exact gradient of the
-    global-mean loss w.r.t. its own rows (option iii): two tiny collectives, no redundant Gram work."""
+    global-mean loss w.r.t. its own rows (option iii): TWO small collectives per step - one all-gather of [zi ; zj], one of
+    the row LSEs with the loss partial riding along - and no redundant Gram work."""
 
     @staticmethod
     def forward(ctx, zi, zj, normalize, temperature):
@@ -33,11 +34,19 @@ class _NTXentFn(torch.autograd.Function):
         zall = torch.empty((rows, ld), dtype=torch.float32, device=zi.device)
         if rows > 2 * nglob:
             ops.fill_(zall[2 * nglob:], 0.0)
-        _, inv_i = ops.l2norm_fwd(zi.detach().contiguous(), normalize, ld, out=zall[seg0:seg0 + b])
-        _, inv_j = ops.l2norm_fwd(zj.detach().contiguous(), normalize, ld, out=zall[nglob + seg0:nglob + seg0 + b])
-        if world > 1:
-            hdist.all_gather_rows(zall[:nglob], b)
-            hdist.all_gather_rows(zall[nglob:2 * nglob], b)
+        exchange = hdist.is_on()          # also with a forced world of one rank (the single-GPU functional test of the RCCL calls)
+        if exchange:
+            # ONE all-gather for both views: every rank normalises into its [zi_r ; zj_r] block, the blocks are gathered in rank order and
+            # re-laid as [zi_all ; zj_all] (the layout the row kernels index: row r < N pairs with row r + N)
+            loc = torch.empty((2 * b, ld), dtype=torch.float32, device=zi.device)
+            _, inv_i = ops.l2norm_fwd(zi.detach().contiguous(), normalize, ld, out=loc[:b])
+            _, inv_j = ops.l2norm_fwd(zj.detach().contiguous(), normalize, ld, out=loc[b:])
+            blocks = torch.empty((world * 2 * b, ld), dtype=torch.float32, device=zi.device)
+            hdist.all_gather_blocks(blocks, loc)
+            zall[:2 * nglob].view(2, world, b, ld).copy_(blocks.view(world, 2, b, ld).permute(1, 0, 2, 3))
+        else:
+            _, inv_i = ops.l2norm_fwd(zi.detach().contiguous(), normalize, ld, out=zall[seg0:seg0 + b])
+            _, inv_j = ops.l2norm_fwd(zj.detach().contiguous(), normalize, ld, out=zall[nglob + seg0:nglob + seg0 + b])
         inv_t = 1.0 / float(temperature)
         gram = None
         if wide:
@@ -47,13 +56,17 @@ class _NTXentFn(torch.autograd.Function):
         else:
             lse_loc, pos_loc = ops.ntxent_fwd(zall, nglob, b, seg0, inv_t)
         loss = ops.ntxent_loss(lse_loc, pos_loc, 1.0 / (2 * nglob))
-        if world > 1:
-            hdist.all_reduce_sum(loss)                       # every rank returns the global-batch loss
+        if exchange:
+            # ONE all-gather for the row log-sum-exps of both views; this rank's share of the loss rides along as one more float, so every
+            # rank sums the same `world` partials in the same order (the global-batch loss, identical on all ranks, no all-reduce)
+            pack = torch.empty((1, 2 * b + 4), dtype=torch.float32, device=zi.device)
+            pack[0, :2 * b].copy_(lse_loc)
+            pack[0, 2 * b:].copy_(loss.expand(4))
+            got = torch.empty((world, 2 * b + 4), dtype=torch.float32, device=zi.device)
+            hdist.all_gather_blocks(got, pack)
+            loss = got[:, 2 * b].sum()
             lse_all = torch.empty((2 * nglob,), dtype=torch.float32, device=zi.device)
-            lse_all[seg0:seg0 + b].copy_(lse_loc[:b])
-            lse_all[nglob + seg0:nglob + seg0 + b].copy_(lse_loc[b:])
-            hdist.all_gather_rows(lse_all[:nglob], b)
-            hdist.all_gather_rows(lse_all[nglob:], b)
+            lse_all.view(2, world, b).copy_(got[:, :2 * b].view(world, 2, b).permute(1, 0, 2))
         else:
             lse_all = lse_loc
         ctx.saved = (zall, lse_all, inv_i, inv_j, nglob, b, seg0, d, inv_t, bool(normalize), gram)

@@ -68,7 +68,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.arena = ParamArena(params)
         self.momentum_buffer = ops.fill_(torch.empty_like(self.arena.data), 0.0)
         self._steps = 0
-        self.grad_sync = None        # set by the data-parallel wrapper: callable(flat_grad) before the update
+        self.grad_sync = None        # set by the data-parallel wrapper (distributed.attach_grad_sync): its finish() runs before the update
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
@@ -80,9 +80,8 @@ class FusedSGD(torch.optim.Optimizer):
         from .. import nn as hnn
         hnn.join_view_streams(a.data.device)         # backward kernels of the two view streams must have been ordered before us
         g2 = a.grad_alt
-        if self.grad_sync is not None:               # data parallel: fold the slabs, then ONE contiguous all-reduce
-            ops.add_(a.grad, a.grad_alt)
-            self.grad_sync(a.grad)
+        if self.grad_sync is not None:               # data parallel: the slabs are folded and all-reduced per bucket (distributed.BucketedGradSync)
+            self.grad_sync.finish()
             g2 = None
         ops.invalidate_weight_caches()               # the transposed-filter cache describes the weights we are about to change
         _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.momentum_buffer),
@@ -115,8 +114,7 @@ class FusedAdamW(torch.optim.Optimizer):
         hnn.join_view_streams(a.data.device)
         g2 = a.grad_alt
         if self.grad_sync is not None:
-            ops.add_(a.grad, a.grad_alt)
-            self.grad_sync(a.grad)
+            self.grad_sync.finish()
             g2 = None
         self._steps += 1
         ops.invalidate_weight_caches()

@@ -27,3 +27,11 @@ def golden():
 def seeded_randn(seed, *shape):
     import torch
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def corr_views(seed, b, size=224):
+    """Two noisy views of one smooth random image per sample: inputs whose samples differ at low spatial frequencies, like real images.
+    (i.i.d. noise images are a degenerate input for a BatchNorm network at 224 x 224: after global pooling all samples look alike.)"""
+    import torch
+    base = torch.nn.functional.interpolate(seeded_randn(seed, b, 3, 7, 7), size=size, mode="bilinear", align_corners=False) * 2.0
+    return base + 0.3 * seeded_randn(seed + 1, b, 3, size, size), base + 0.3 * seeded_randn(seed + 2, b, 3, size, size)

@@ -120,6 +120,7 @@ def _patch_ops():
     ops.ntxent_fwd, ops.ntxent_loss, ops.ntxent_bwd = _emu_ntxent_fwd, _emu_ntxent_loss, _emu_ntxent_bwd
     ops.scale_ = lambda x, f: x.mul_(f)
     ops.fill_ = lambda x, v: x.fill_(v)
+    ops.add_ = lambda dst, src: dst.add_(src)
     ops.mse_pair, ops.barlow_cgrad = _emu_mse_pair, _emu_barlow_cgrad
     ops.dino_loss = _emu_dino_loss
     ops.bn_train_fwd, ops.bn_train_bwd = _emu_bn_train_fwd, _emu_bn_train_bwd
@@ -149,6 +150,80 @@ def _loader_epochs(loader, epochs):
         assert [b["step"] for b in batches] == list(range(first, first + len(batches))) and len(batches) == len(loader)
         out.append([b["index"].tolist() for b in batches])
     return out
+
+
+class _FakeArena:
+    """ParamArena's layout (64-float aligned runs of one flat buffer, two gradient slabs) on the CPU."""
+
+    def __init__(self, params, rank, salt):
+        self.params, self.offsets, off = list(params), [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.numel = off
+        g = torch.Generator().manual_seed(1000 * salt + rank)
+        self._grads = torch.randn(2 * off, generator=g)
+        self.grad, self.grad_alt = self._grads[:off], self._grads[off:]
+
+
+class _StagedNet(torch.nn.Module):
+    """Three "stages" of parameters + a head that belongs to no stage, like ResNet + its bridged wrapper."""
+
+    def __init__(self):
+        super().__init__()
+        self.s0 = torch.nn.Linear(7, 5)
+        self.s1 = torch.nn.Linear(5, 33)
+        self.s2 = torch.nn.Linear(33, 9)
+        self.head = torch.nn.Linear(9, 3)
+
+    def grad_stages(self):
+        return [list(self.s0.parameters()), list(self.s1.parameters()), list(self.s2.parameters())]
+
+
+def _bucketed_exchange_checks(rank, world, hdist):
+    from types import SimpleNamespace
+    net, extra = _StagedNet(), torch.nn.Linear(4, 4)                      # `extra`: owned by the optimizer, known to no module
+    params = list(net.parameters()) + list(extra.parameters())
+    single = SimpleNamespace(arena=_FakeArena(params, rank, 1))
+    bucketed = SimpleNamespace(arena=_FakeArena(params, rank, 1))
+    assert torch.equal(single.arena._grads, bucketed.arena._grads)
+    want = single.arena.grad + single.arena.grad_alt                      # this rank's fold; summed over ranks below
+    gathered = [torch.zeros_like(want) for _ in range(world)]
+    dist.all_gather(gathered, want)
+    want = gathered[0] + gathered[1]
+    hdist.BucketedGradSync(single, (), bucketed=False).finish()
+    sync = hdist.BucketedGradSync(bucketed, [net], bucketed=True)
+    assert [b[0] for b in sync.buckets] == ["_StagedNet.stage0", "_StagedNet.stage1", "_StagedNet.stage2", "_StagedNet.rest"]
+    assert [(lo, hi) for _, lo, hi in sync.buckets] == [(0, 128), (128, 384), (384, 768), (768, 896)] and bucketed.arena.numel == 1024
+    sync.expect(net)
+    sync.expect(net)                                                      # two backward passes (the two views) will report
+    order = []
+    for _ in range(2):
+        for stage in (2, 1, 0, "rest"):                                   # backward order: the last stage completes first
+            assert sync.has(net, stage) and not sync.has(extra, 0)
+            before = len(sync.launched)
+            sync.ready(net, stage)
+            if len(sync.launched) > before:
+                order.append(stage)
+    assert order == [2, 1, 0, "rest"]                                     # each bucket goes out when the SECOND pass reports it
+    sync.ready(net, 2)                                                    # a late / duplicate report is ignored
+    assert not torch.equal(bucketed.arena.grad[896:], single.arena.grad[896:])       # `extra` not exchanged yet ...
+    sync.finish()                                                         # ... finish() picks it up
+    assert torch.equal(bucketed.arena.grad, single.arena.grad), "bucketed exchange differs from the single call"
+    np.testing.assert_allclose(single.arena.grad.numpy(), want.numpy(), rtol=0, atol=0)
+    assert not sync.pending and not sync.launched
+    # a step in which only one pass reports (the other pass's backward never ran): nothing may be lost or reduced twice
+    third = SimpleNamespace(arena=_FakeArena(params, rank, 2))
+    ref = SimpleNamespace(arena=_FakeArena(params, rank, 2))
+    hdist.BucketedGradSync(ref, (), bucketed=False).finish()
+    sync = hdist.BucketedGradSync(third, [net], bucketed=True)
+    sync.expect(net)
+    sync.expect(net)
+    for stage in (2, 1, 0, "rest"):
+        sync.ready(net, stage)
+    assert not sync.launched
+    sync.finish()
+    assert torch.equal(third.arena.grad, ref.arena.grad)
 
 
 def _worker(rank, world, port, out):
@@ -268,6 +343,9 @@ def _worker(rank, world, port, out):
                 assert a + b_ == order[16 * st:16 * st + len(a) + len(b_)].tolist()   # rank r owns rows [r*B, (r+1)*B) of the global batch
                 assert len(a) == len(b_) == (8 if st < 3 else 1)
         assert hdist.broadcast_object(f"run-of-rank-{rank}") == "run-of-rank-0"
+        # ---- 8. bucketed gradient exchange (collective 2): buckets reported stage by stage by two backward passes (two
+        #         gradient slabs) == ONE call over the whole arena, bit for bit; parameters outside every bucket are picked up by finish()
+        _bucketed_exchange_checks(rank, world, hdist)
         hdist.barrier()
         out.put((rank, "ok"))
     except Exception as e:                                        # surface the failure to the parent

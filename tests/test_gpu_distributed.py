@@ -33,24 +33,37 @@ def _worker(rank, port, q):
         from ssv_amd.utils import losses, train_utils
         hdist.init_from_env()
         dev = torch.device("cuda", torch.cuda.current_device())
-        torch.manual_seed(420)
-        enc = resnet.resnet18(reduce_bottom_conv=True).to(dev)
-        head = heads.SimclrProjectionHead(512, 128).to(dev)
-        opt = train_utils.get_optimizer({"name": "sgd", "lr": 0.2, "weight_decay": 1e-4}, list(enc.parameters()) + list(head.parameters()))
-        hdist.attach_grad_sync(opt)
-        loss_fn = losses.SimclrLoss(True, 0.5)
         a1 = seeded_randn(1, B * WORLD, 3, 32, 32)[rank * B:(rank + 1) * B].to(dev)
         a2 = seeded_randn(2, B * WORLD, 3, 32, 32)[rank * B:(rank + 1) * B].to(dev)
-        with hnn.parallel_views(dev) as pv:
-            with pv.view(0):
-                z1 = head(enc(a1))
-            with pv.view(1):
-                z2 = head(enc(a2))
-        loss = loss_fn(z1, z2)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        torch.cuda.synchronize()
+
+        def one_step(bucketed):
+            torch.manual_seed(420)
+            enc = resnet.resnet18(reduce_bottom_conv=True).to(dev)
+            head = heads.SimclrProjectionHead(512, 128).to(dev)
+            opt = train_utils.get_optimizer({"name": "sgd", "lr": 0.2, "weight_decay": 1e-4}, list(enc.parameters()) + list(head.parameters()))
+            hdist.attach_grad_sync(opt, [enc, head], bucketed=bucketed)
+            names = [b[0] for b in opt.grad_sync.buckets]
+            assert names == (["ResNet.stage0", "ResNet.stage1", "ResNet.stage2", "ResNet.stage3", "ResNet.stage4", "SimclrProjectionHead.rest"] if bucketed else []), names
+            launched = []
+            inner = opt.grad_sync._launch
+            opt.grad_sync._launch = lambda b: (launched.append(opt.grad_sync.buckets[b][0]), inner(b))[1]
+            loss_fn = losses.SimclrLoss(True, 0.5)
+            with hnn.parallel_views(dev) as pv:
+                with pv.view(0):
+                    z1 = head(enc(a1))
+                with pv.view(1):
+                    z2 = head(enc(a2))
+            loss = loss_fn(z1, z2)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            return loss, opt, launched
+        # the gradient exchange per bucket, launched from the backward pass (head first, then layer4 ... stem), against ONE call at step()
+        loss_s, opt_s, launched_s = one_step(False)
+        loss, opt, launched = one_step(True)
+        assert launched_s == [] and launched == ["SimclrProjectionHead.rest", "ResNet.stage4", "ResNet.stage3", "ResNet.stage2", "ResNet.stage1", "ResNet.stage0"], launched
+        assert loss.item() == loss_s.item() and torch.equal(opt.arena.data, opt_s.arena.data), "bucketed gradient exchange is not bitwise the single call"
         extra = _sharded_loss_checks(rank, dev, losses)
         dino = _dino_step(rank, dev)
         q.put((rank, "ok" if extra is None else extra, loss.item(), opt.arena.data.cpu().numpy(), dino))
@@ -83,7 +96,7 @@ def _dino_step(rank, dev):
     t.device, t.train_loader = dev, [None]
     torch.manual_seed(420)
     t._build("vit")
-    hdist.attach_grad_sync(t.optim)
+    hdist.attach_grad_sync(t.optim, t._sync_modules())
     loss = t.train_step(_dino_batch(rank))["loss"]
     torch.cuda.synchronize()
     return loss, t.optim.arena.data.cpu().numpy(), t.teacher_center.cpu().numpy()

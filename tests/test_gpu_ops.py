@@ -592,3 +592,29 @@ def test_gate_epilogue_also_reduces_against_the_projection_shortcut_input(dev, n
     close(pg.sum(0), want.sum(0).float(), rtol=1e-4, what="sum g")
     close(pgx.sum(0), (want * xh1).sum(0).float(), rtol=1e-4, what="sum g * xhat")
     close(pgx2.sum(0), (want * xh2).sum(0).float(), rtol=1e-4, what="sum g * xhat2")
+
+
+@pytest.mark.parametrize("n,h,c,k", [(5, 9, 64, 64), (3, 12, 256, 64), (2, 14, 128, 256), (3, 7, 96, 132)])
+@pytest.mark.parametrize("res_affine", [False, True])
+def test_conv_that_forms_and_writes_the_closing_activation_is_bitwise_bn_apply_then_conv(dev, n, h, c, k, res_affine):
+    """ssv_conv2d_fwd_sumin_stats: a = relu(x * scale + shift + (res | res * rscale + rshift)) formed while conv1 stages its input and written
+    by the same kernel.  Same fmaf / add / fmaxf on the same floats as ssv_bn_apply, the same GEMM on that operand as
+    ssv_conv2d_fwd_stats: the activation, its ReLU byte mask, the convolution output and the statistics partials are IDENTICAL bits -
+    identity shortcut and projection shortcut with its own BatchNorm affine, narrow (256 x 64) and wide (128 x 128) tiles, ragged sizes."""
+    from ssv_amd import ops
+    x, res = seeded_randn(31, n, h, h, c).to(dev), seeded_randn(32, n, h, h, c).to(dev)
+    w = (seeded_randn(33, k, c, 1, 1) * 0.1).contiguous(memory_format=torch.channels_last).to(dev)
+    scale, shift = (seeded_randn(34, c) * 0.3 + 1.0).to(dev), (seeded_randn(35, c) * 0.2).to(dev)
+    raff = ((seeded_randn(36, c) * 0.3 + 1.0).to(dev), (seeded_randn(37, c) * 0.2).to(dev)) if res_affine else None
+    a_ref, m_ref = ops.bn_apply(x, scale, shift, relu=True, residual=res, res_affine=raff, want_mask=True)
+    y_ref, pm_ref, p2_ref = ops.conv2d_fwd_stats(a_ref, w, 1, 0)
+    y, (pm, p2), a, mask = ops.conv2d_fwd_sumin(x, res, scale, shift, raff, w, want_mask=True)
+    assert torch.equal(a, a_ref) and torch.equal(mask, m_ref)
+    assert torch.equal(y, y_ref) and torch.equal(pm, pm_ref) and torch.equal(p2, p2_ref)
+    y2, _, a2, mask2 = ops.conv2d_fwd_sumin(x, res, scale, shift, raff, w, want_mask=False)
+    assert mask2 is None and torch.equal(a2, a_ref) and torch.equal(y2, y_ref)
+    # and against an fp64 evaluation (the bitwise statements above are between two of our own kernels)
+    ar = torch.relu(x.double() * scale.double() + shift.double() + (res.double() if raff is None else res.double() * raff[0].double() + raff[1].double()))
+    np.testing.assert_allclose(a.cpu().double().numpy(), ar.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    yr = torch.einsum("nhwc,kc->nhwk", ar, w.double().view(k, c))
+    np.testing.assert_allclose(y.cpu().double().numpy(), yr.cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -542,18 +542,32 @@ def test_closing_activation_formed_by_the_next_conv1_is_bitwise_the_element_wise
     3x3 conv1 cannot, so its units fall back to the element-wise pass.  Same fmaf / add / fmaxf on the same floats: loss and embeddings are
     bit-identical; the gradients agree to rounding (at the stage entries the gate + partial sums of the unit-input gradient move from the
     stride-2 data-gradient kernel's epilogue to the forward kernel's: same ReLU bits, sums grouped differently)."""
-    from ssv_amd import nn as hnn
+    from ssv_amd import nn as hnn, ops
     a1, a2 = seeded_randn(1900, b, 3, size, size), seeded_randn(1901, b, 3, size, size)
-    outs = []
-    for fuse in (True, False):
-        prev, hnn._FUSE_CLOSING = hnn._FUSE_CLOSING, fuse
-        try:
-            m = _Step(dev, arch, rbc)
-            loss, z1, z2 = m.step(a1, a2)
-            torch.cuda.synchronize()
-            outs.append((loss, z1.cpu(), z2.cpu(), m, m.grads.cpu().clone()))
-        finally:
-            hnn._FUSE_CLOSING = prev
+    outs, calls = [], []
+    inner = ops.conv2d_fwd_sumin
+
+    def counted(*a, **k):
+        calls[-1] += 1
+        return inner(*a, **k)
+    prev_hw, hnn._CLOSING_HW = hnn._CLOSING_HW, (0, 10 ** 9)     # small inputs: every stage, not only the >= 28x28 maps the shipped threshold selects
+    ops.conv2d_fwd_sumin = counted
+    try:
+        for fuse in (True, False):
+            prev, hnn._FUSE_CLOSING = hnn._FUSE_CLOSING, fuse
+            calls.append(0)
+            try:
+                m = _Step(dev, arch, rbc)
+                loss, z1, z2 = m.step(a1, a2)
+                torch.cuda.synchronize()
+                outs.append((loss, z1.cpu(), z2.cpu(), m, m.grads.cpu().clone()))
+            finally:
+                hnn._FUSE_CLOSING = prev
+    finally:
+        hnn._CLOSING_HW = prev_hw
+        ops.conv2d_fwd_sumin = inner
+    # ResNet-50: conv1 of 15 of its 16 units takes a deferred closing activation, per view; ResNet-18's 3x3 conv1 never can
+    assert calls == ([30, 0] if arch == "resnet50" else [0, 0]), calls
     (lf, zf, z2f, m, gf), (lu, zu, z2u, _, gu) = outs
     assert lf == lu and torch.equal(zf, zu) and torch.equal(z2f, z2u)
     worst = 0.0
@@ -563,7 +577,7 @@ def test_closing_activation_formed_by_the_next_conv1_is_bitwise_the_element_wise
             assert float(a.abs().max()) < 1e-5
             continue
         worst = max(worst, float((a - r).norm() / r.norm()))
-    assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"
+    assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"       # (that the fused branch ran is what `calls` shows)
 
 
 @pytest.mark.parametrize("arch,size,b", [("resnet50", 64, 6), ("resnet50", 96, 3)])

@@ -118,3 +118,21 @@ def test_cifar_pickles_are_read_into_nhwc_uint8(tmp_path):
         data_utils._load_cifar(str(tmp_path / "nowhere"), "cifar10", True)
     with pytest.raises(AssertionError):
         data_utils._load("imagenet", str(tmp_path), None)
+
+
+def test_batch_chunks_alignment_and_its_error():
+    """ops._batch_chunks (host logic): chunks keep every tensor below the per-launch limit; with a statistics epilogue the chunk size
+    is a multiple of 64 / gcd(rows per sample, 64) samples; when no such chunk fits, the error names that constraint (and
+    conv2d_fwd_stats turns it into "no fused statistics" instead of failing)."""
+    from ssv_amd import ops
+    lim = ops._MAX_ELEMS
+    assert ops._batch_chunks(4, (1000, 2000)) == [(0, 4)]
+    per = lim // 10 + 1                                    # 9 samples fit one launch
+    ch = ops._batch_chunks(40, (per, per // 2))
+    assert ch[0] == (0, 9) and ch[-1][1] == 40 and all(b - a <= 9 for a, b in ch)
+    ch = ops._batch_chunks(40, (per, per // 2), rows_per_sample=16)          # q = 4: chunks of 8 samples
+    assert ch[0] == (0, 8) and all((b - a) % 4 == 0 for a, b in ch[:-1])
+    with pytest.raises(_lib.SsvError, match="multiple of 64 samples"):
+        ops._batch_chunks(40, (per, per // 2), rows_per_sample=49)           # odd rows per sample: q = 64 > 9
+    with pytest.raises(_lib.SsvError, match="single sample"):
+        ops._batch_chunks(2, (lim + 5, 10))

@@ -5,6 +5,7 @@ BatchNorm, gated epilogue), its time, TFLOP/s of algorithmic work, and how its g
 (workgroups / (3 resident per CU x 256 CUs) = "waves of 768").
 
     python tools/bench_conv.py [batch per view = 512] [repeats = 5] [out.csv]
+SSV_BENCH_LAYERS=p64.,p128.0 restricts the table to layers whose name contains one of the comma-separated substrings.
 """
 import csv
 import os
@@ -44,6 +45,10 @@ def resnet50_shapes():
     return uniq
 
 
+def xin_b(b, h, c):
+    return 4.0 * b * h * h * c
+
+
 def timeit(fn):
     fn()
     torch.cuda.synchronize()
@@ -62,10 +67,24 @@ def grid_fwd(m, k):
 
 rows, tot = [], {}
 hdr = ["layer", "count", "HxW", "C", "K", "RxS", "stride", "GFLOP", "fwd_variant", "fwd_ms", "fwd_TF", "fwd_wgs", "fwd_waves768",
-       "dgrad_variant", "dgrad_ms", "dgrad_TF", "dgrad_wgs", "wgrad_variant", "wgrad_ms", "wgrad_TF"]
+       "dgrad_variant", "dgrad_ms", "dgrad_TF", "dgrad_wgs", "wgrad_variant", "wgrad_ms", "wgrad_TF",
+       "fwd_GB", "fwd_TBs", "fwd_frac", "dgrad_GB", "dgrad_TBs", "dgrad_frac", "wgrad_GB", "wgrad_TBs", "wgrad_frac"]
+MFMA_PEAK, HBM_PEAK = 157.3e12, 6.29e12      # fp32 MFMA dense; HBM achievable (MI355X_MICROARCH.md): a layer's own bound = max(FLOP / MFMA_PEAK, bytes / HBM_PEAK)
+
+
+def roof(flop, nbytes, ms):
+    """(GB moved when every operand stream of the variant is moved exactly once, TB/s achieved, fraction of the layer's own roofline bound)."""
+    if ms != ms:
+        return "", "", ""
+    bound = max(flop / MFMA_PEAK, nbytes / HBM_PEAK)
+    return round(nbytes / 1e9, 2), round(nbytes / (ms * 1e-3) / 1e12, 2), round(bound / (ms * 1e-3), 3)
+
 print(f"ResNet-50 @224, batch {B} per view, {REP} repeats")
 print(" ".join(f"{h:>13s}" for h in hdr))
+ONLY = [t for t in os.environ.get("SSV_BENCH_LAYERS", "").split(",") if t]
 for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
+    if ONLY and not any(t in name for t in ONLY):
+        continue
     if C == 3:
         x = ops.pad_channels(torch.randn(B, H, H, 3, device=dev), 4)
         w = ops.pad_channels((torch.randn(K, 3, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)
@@ -117,22 +136,46 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         addend = torch.randn_like(x) if kind == "plain" else None
         dv = ("fwd-kernel" if s == 1 else "dgrad-kernel") + "+gate" + ("+addend" if addend is not None else "") + ("+dy_in" if dyl is not None else "")
         t_d = timeit(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate))
+        if ".1.conv1" in name and kind == "plain" and s == 1:
+            # the first of these units sits behind a projection shortcut: its gate also reduces against that BatchNorm's input (GATE 3)
+            gate2 = ops.BnGateCtx(gx, mean, invstd, mask=gate.mask, second=(torch.randn_like(x), mean, invstd))
+            t_d2 = timeit(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate2))
+            print(f"   {name}: data gradient with the second reduction target (1 of its {cnt} instances): {t_d2:.3f} ms, {flop / (t_d2 * 1e-3) / 1e12:.1f} TFLOP/s, "
+                  f"{(xin_b(B, H, Cx) * 4 + m * K * 4 * (2 if dyl is not None else 1)) / (t_d2 * 1e-3) / 1e12:.2f} TB/s", flush=True)
+            del gate2
         dwgs = grid_fwd(B * H * H, C) if s == 1 else s * s * grid_fwd(B * (-(-H // s)) ** 2, C)
+    # algorithmic HBM bytes of each launch in the variant the step uses: every operand stream once (weights and per-channel vectors ignored)
+    n_in, n_out = B * H * H, m                                   # input pixels, output pixels
+    xin, yout = 4.0 * n_in * Cx, 4.0 * n_out * K
+    by_f = xin + yout + ((xin + xin + n_in * Cx / 4) if sum_in else 0)           # sum_in: + shortcut read, activation + byte mask written
+    by_w = xin + yout + (yout if dyl is not None else 0)                         # dy_in: + the BatchNorm input beside g
+    if C == 3:
+        by_d = 0.0
+    else:
+        by_d = yout + (yout if dyl is not None else 0) + xin                     # dy (+ BatchNorm input), dx written
+        by_d += xin if addend is not None else 0                                 # residual gradient read
+        by_d += xin + (n_in * Cx / 4 if kind != "lazy" else 0)                   # gate: the BatchNorm input (+ byte mask)
     tf = lambda t: flop / (t * 1e-3) / 1e12
     wgs = grid_fwd(m, K)
     row = [name, cnt, f"{H}x{H}", C, K, f"{R}x{R}", s, round(flop / 1e9, 1), fv, round(t_f, 3), round(tf(t_f), 1), wgs, round(wgs / 768, 2),
-           dv, round(t_d, 3), round(tf(t_d), 1) if t_d == t_d else "", dwgs, wv, round(t_w, 3), round(tf(t_w), 1)]
+           dv, round(t_d, 3), round(tf(t_d), 1) if t_d == t_d else "", dwgs, wv, round(t_w, 3), round(tf(t_w), 1),
+           *roof(flop, by_f, t_f), *roof(flop, by_d, t_d), *roof(flop, by_w, t_w)]
     rows.append(row)
     print(" ".join(f"{str(v):>13s}" for v in row), flush=True)
-    for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
+    for k, t, nb in (("fwd", t_f, by_f), ("dgrad", t_d, by_d), ("wgrad", t_w, by_w)):
         if t == t:
-            a = tot.setdefault(k, [0.0, 0.0])
+            a = tot.setdefault(k, [0.0, 0.0, 0.0, 0.0])
             a[0] += t * cnt
             a[1] += flop * cnt
+            a[2] += nb * cnt
+            a[3] += max(flop / MFMA_PEAK, nb / HBM_PEAK) * 1e3 * cnt
     del x, y, dy, w, dw
-for k, (t, f) in tot.items():
-    print(f"total {k:6s}: {t:8.2f} ms per view  {f / (t * 1e-3) / 1e12:6.1f} TFLOP/s")
-    rows.append([f"TOTAL {k}", "", "", "", "", "", "", round(f / 1e9, 1), "", round(t, 2), round(f / (t * 1e-3) / 1e12, 1)] + [""] * 9)
+for k, (t, f, nb, bound) in tot.items():
+    print(f"total {k:6s}: {t:8.2f} ms per view  {f / (t * 1e-3) / 1e12:6.1f} TFLOP/s  {nb / 1e9:7.2f} GB of operand streams  {nb / (t * 1e-3) / 1e12:5.2f} TB/s  "
+          f"sum of the layers' own bounds {bound:6.2f} ms ({bound / t:.3f})")
+    # TOTAL rows: GFLOP | ms | TFLOP/s in the fwd columns, then GB of operand streams | TB/s | sum of per-layer bounds / time in the fwd_GB.. columns
+    rows.append([f"TOTAL {k}", "", "", "", "", "", "", round(f / 1e9, 1), "", round(t, 2), round(f / (t * 1e-3) / 1e12, 1)] + [""] * 9 +
+                [round(nb / 1e9, 2), round(nb / (t * 1e-3) / 1e12, 2), round(bound / t, 3)] + [""] * 6)
 if OUT:
     with open(OUT, "w", newline="") as fh:
         wtr = csv.writer(fh)
