@@ -144,6 +144,32 @@ size_t ssv_conv2d_wgrad_workspace_bytes(const ssv_conv_desc* d);
 int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dw,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- Winograd F(2x2, 3x3) for stride-1 / padding-1 3x3 convolutions (csrc/winograd.hip) -------------------------------------
+ * replaces nn.Conv2d(k=3, s=1, p=1) forward / data gradient / weight gradient of networks/resnet.py:7-10,56-58 on the deep stages with
+ * 2.25x fewer multiplies, all in fp32:  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  per 2x2 output tile.
+ *   T = ssv_wino_tiles(N,H,W) = N * ceil(H/2) * ceil(W/2) tiles;  transformed operands are [16][T][channels] (position p = 4 xi + nu major)
+ *   forward      : U = filter_transform(w)            V = input_transform(x [, in_scale, in_shift])      M = gemm_batched(16, T, C, K, V, U)
+ *                  y = output_transform(M [, statistics partials: one per 16 tiles, for ssv_bn_stats_finalize(rows_per_group = ssv_wino_stats_rows_per_group)])
+ *   data gradient: the same chain on dy with the transposed, rotated filter (ssv_filter_transpose), optional ReLU gate in the output transform
+ *   weight grad. : dM = dy_transform(dy)   dU = gemm_batched_wgrad(16, T, C, K, V, dM)   dw (+)= filter_grad(dU)        (V kept from the forward)
+ * Every pointer 16-byte aligned, channels % 4 == 0 (gemm: C % 32 == 0).  Nothing allocates; the caller owns U, V, M, dM, dU. */
+int64_t ssv_wino_tiles(int32_t N, int32_t H, int32_t W);
+int64_t ssv_wino_groups(int32_t N, int32_t H, int32_t W);           /* workgroups of the output transform = statistics / gate partial groups */
+int32_t ssv_wino_stats_rows_per_group(int32_t N, int32_t H, int32_t W);   /* rows per statistics partial: 64 (H, W even), H*W (one image = 16 tiles), 0 = unsupported */
+int ssv_wino_filter_transform(int32_t K, int32_t C, const float* w /*[K][3][3][C]*/, float* U /*[16][K][C]*/, void* stream);
+int ssv_wino_filter_grad(int32_t K, int32_t C, const float* dU /*[16][K][C]*/, float* dw /*[K][3][3][C]*/, int accumulate, void* stream);
+int ssv_wino_input_transform(int32_t N, int32_t H, int32_t W, int32_t C, const float* x, const float* in_scale, const float* in_shift,
+                             float* V, void* stream);          /* in_scale / in_shift: x is a raw conv output, operand = relu(x*scale+shift); or both NULL */
+int ssv_wino_dy_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, float* dM, void* stream);
+int ssv_wino_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* M, float* y, float* pmean, float* pm2,
+                              const ssv_bn_gate* gate, void* stream);   /* pmean / pm2 [groups][K] or NULL; gate (mask or scale + shift, no x2) or NULL */
+/* batched GEMMs on the implicit-GEMM kernels, ONE launch: y[b] = a[b] . w[b]^T   /   dw[b] = dy[b]^T . x[b]   (b < batch) */
+int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
+                     float* y /*[batch][rows][K]*/, void* stream);
+size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K);
+int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x /*[batch][rows][C]*/, const float* dy /*[batch][rows][K]*/,
+                           float* dw /*[batch][K][C]*/, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- BatchNorm (training mode, batch statistics) over rows of an [M][C] matrix ------------
  * replaces nn.BatchNorm2d / nn.BatchNorm1d (+ReLU, + residual add) at networks/resnet.py:39-44,
  * 68-74,147 and models/simclr.py:34-35.  C % 4 == 0.

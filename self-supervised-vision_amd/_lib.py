@@ -70,6 +70,17 @@ SIGNATURES = {
     "ssv_conv2d_wgrad_dyin": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnDyin), _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_wino_tiles": (_i64, [_i32, _i32, _i32]),
+    "ssv_wino_groups": (_i64, [_i32, _i32, _i32]),
+    "ssv_wino_stats_rows_per_group": (_i32, [_i32, _i32, _i32]),
+    "ssv_wino_filter_transform": (C.c_int, [_i32, _i32, _vp, _vp, _vp]),
+    "ssv_wino_filter_grad": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int, _vp]),
+    "ssv_wino_input_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_wino_dy_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssv_wino_output_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
+    "ssv_gemm_batched": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ssv_gemm_batched_wgrad_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "ssv_gemm_batched_wgrad": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ssv_bn_train_fwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_bn_train_bwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),

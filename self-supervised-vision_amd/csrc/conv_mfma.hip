@@ -42,18 +42,6 @@
 #ifndef SSV_CONV_WGPC
 #define SSV_CONV_WGPC 3     // resident workgroups per CU the forward / data-gradient kernels are compiled for
 #endif
-#ifndef SSV_OPM_WGPC
-#define SSV_OPM_WGPC 2      // ... and the formed-on-load (OPM) / two-target gate (GATE 3) variants, whose second operand stream costs registers
-#endif
-#ifndef SSV_NARROW_DEEP
-#define SSV_NARROW_DEEP 0   // 1: layers with fewer than 128 output channels run a 128 x 64 tile with K-step 64 (256-byte row pieces) instead of 256 x 64 / K-step 32
-#endif
-#ifndef SSV_OPM_BK
-#define SSV_OPM_BK 32       // K-step of the formed-on-load variants on the 128 x 128 tile (16: half the staging registers per stream)
-#endif
-#ifndef SSV_GATE_HB
-#define SSV_GATE_HB 0       // > 0: rows per load batch of the gated epilogues (default: 2 for GATE 1 / 3, 4 otherwise)
-#endif
 
 namespace {
 
@@ -86,6 +74,8 @@ struct ConvKP {
   // formed on load from the unit's last conv output x (the operand pointer) and its shortcut; the column-tile-0 workgroups also WRITE it
   const float* sum_res; const float* sum_scale; const float* sum_shift; const float* sum_rscale; const float* sum_rshift;
   float* sum_out; uint8_t* sum_mask;
+  // batched launches (blockIdx.y = batch index: the 16 GEMMs of a Winograd convolution): element strides of the three operands, 0 otherwise
+  long long bs_a, bs_b, bs_o;
 };
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
@@ -324,8 +314,10 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
                                              const ssv_bn_gate* bn = nullptr, long long group = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
   constexpr bool GMASK = GATE >= 2, GX2 = GATE == 3;
-  constexpr int HB0 = (GATE != 0 && SSV_GATE_HB > 0) ? SSV_GATE_HB : ((GATE == 1 || GX2) ? 2 : 4);
-  constexpr int HB = NP < HB0 ? NP : HB0;   // rows per batch: the loads of a batch are in flight together (register budget of 3 workgroups per CU)
+  // rows per batch: the loads of a batch are in flight together.  GATE 1 lives in kernels compiled for 3 workgroups per CU (register budget: 2 rows);
+  // the two-target gate (GATE 3) is compiled for 2 per CU and uses the room for 4 rows in flight (r03 x1: 1.43 -> 1.34 ms on the 56x56 unit input)
+  constexpr int HB0 = GATE == 1 ? 2 : 4;
+  constexpr int HB = NP < HB0 ? NP : HB0;
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
@@ -462,7 +454,11 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
 template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0>
-__global__ void __launch_bounds__(256, (OPM || GATE == 3) ? SSV_OPM_WGPC : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+// Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
+// The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
+// the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
+// 28x28 layers); the two-target gate (GATE 3) needs 218.  (kernel_resources.py lists every variant; r03_experiments_step_time.txt the A/Bs.)
+__global__ void __launch_bounds__(256, (OPM == 2 || GATE == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC)) SSV_CONV_ATTR
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -483,6 +479,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
+  x += (size_t)blockIdx.y * p.bs_a; w += (size_t)blockIdx.y * p.bs_b; y += (size_t)blockIdx.y * p.bs_o;      // batched GEMMs (uniform; 0 otherwise)
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
@@ -976,6 +973,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   const int i0 = it * BM, j0 = jt * BN;
   const int ms = split * chunk_rows;
   const int me = min(ms + chunk_rows, p.M);
+  x += (size_t)blockIdx.y * p.bs_a; dy += (size_t)blockIdx.y * p.bs_b; partial += (size_t)blockIdx.y * p.bs_o;     // batched weight gradients
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
@@ -1148,6 +1146,7 @@ wgrad_reduce_k(const float* __restrict__ partial, int nsplit, int64_t n, float* 
   __shared__ float sm[4][64];
   const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  partial += (size_t)blockIdx.y * nsplit * n; dw += (size_t)blockIdx.y * n;          // batched weight gradients: [batch][split][n] -> [batch][n]
   const int per = (nsplit + 3) / 4;
   const int k0 = grp * per, k1 = min(k0 + per, nsplit);
   float s = 0.f;
@@ -1194,6 +1193,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   memset(&p.gate, 0, sizeof(p.gate));
   p.dyin_x = nullptr; p.dyin_coef = nullptr;
   p.sum_res = p.sum_scale = p.sum_shift = p.sum_rscale = p.sum_rshift = nullptr; p.sum_out = nullptr; p.sum_mask = nullptr;
+  p.bs_a = p.bs_b = p.bs_o = 0;
   return p;
 }
 
@@ -1226,8 +1226,6 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d) {
 // K-step 32 when the contraction's channel count allows it, else 16; tile by output width.
 namespace {
 
-// narrow layers (fewer than 128 output channels) on the 128 x 64 tile with K-step 64: SSV_NARROW_DEEP builds, channel counts that allow it
-inline bool narrow_deep(const ssv_conv_desc* d) { return SSV_NARROW_DEEP && d->K < 128 && d->C % 64 == 0; }
 
 // forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
 int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
@@ -1236,14 +1234,12 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
   const bool wide = d->K >= 128;
-  const bool deep = narrow_deep(d) && !xf;                     // 128 x 64 tile, K-step 64 (SSV_NARROW_DEEP builds)
-  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, deep ? 128 : 256) * cdiv(d->K, 64));
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
   if (gate) {                                                  // C % 32 == 0 checked by the caller
     p.gate = *gate;
-#define FWDG(BM_, BN_, WM_, WN_, BK_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, false, false, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWDG_TILE(G_) do { if (wide) FWDG(128, 128, 2, 2, 32, G_); else if (deep) { if constexpr (SSV_NARROW_DEEP) FWDG(128, 64, 2, 2, 64, G_); } \
-                           else FWDG(256, 64, 4, 1, 32, G_); } while (0)
+#define FWDG(BM_, BN_, WM_, WN_, G_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWDG_TILE(G_) do { if (wide) FWDG(128, 128, 2, 2, G_); else FWDG(256, 64, 4, 1, G_); } while (0)
     if (gate->x2) FWDG_TILE(3); else if (gate->mask) FWDG_TILE(2); else FWDG_TILE(1);
 #undef FWDG_TILE
 #undef FWDG
@@ -1251,9 +1247,7 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   }
 #define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); \
-                                          else if (deep && !(C4_) && !(XF_) && BK_ == 32) { if constexpr (SSV_NARROW_DEEP && !(C4_) && !(XF_) && BK_ == 32) FWD(128, 64, 2, 2, 64, ST_, false, false); } \
-                                          else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
+#define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
   if (stats && d->C == 4) {                                    // the padded image stem with the statistics epilogue
     FWD_TILE(32, true, true, false);
   } else if (stats || xf) {                                    // C % 32 == 0 checked by the callers
@@ -1307,7 +1301,7 @@ int check_gate(const ssv_bn_gate* g, const char* who) {
 extern "C" int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d) {
   if (!d || d->K <= 0) return 0;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  const int bm = (d->K >= 128 || narrow_deep(d)) ? 128 : 256;
+  const int bm = d->K >= 128 ? 128 : 256;
   return cdiv64(M, bm) * (bm / 64);
 }
 
@@ -1342,13 +1336,12 @@ extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const
   ConvKP p = make_kp(d);
   p.dyin_x = dyin->x; p.dyin_coef = dyin->coef;
   if (gate) p.gate = *gate;
-  const bool wide = d->K >= 128, deep = narrow_deep(d);
-  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, deep ? 128 : 256) * cdiv(d->K, 64));
+  const bool wide = d->K >= 128;
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
   const int gm = gate ? (gate->x2 ? 3 : (gate->mask ? 2 : 1)) : 0;
-#define FWDD(BM_, BN_, WM_, WN_, BK_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
-#define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, SSV_OPM_BK, G_); else if (deep) { if constexpr (SSV_NARROW_DEEP) FWDD(128, 64, 2, 2, 64, G_); } \
-                           else FWDD(256, 64, 4, 1, 32, G_); } while (0)
+#define FWDD(BM_, BN_, WM_, WN_, G_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+#define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
   if (gm == 3) FWDD_TILE(3); else if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
 #undef FWDD_TILE
 #undef FWDD
@@ -1374,10 +1367,11 @@ extern "C" int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x
   ConvKP p = make_kp(d);
   p.aux_out = pmean; p.aux_out2 = pm2;
   p.sum_res = res; p.sum_scale = scale; p.sum_shift = shift; p.sum_rscale = rscale; p.sum_rshift = rshift; p.sum_out = a_out; p.sum_mask = mask_out;
-  const bool wide = d->K >= 128, deep = narrow_deep(d);
-  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, deep ? 128 : 256) * cdiv(d->K, 64));
-  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, SSV_OPM_BK, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
-  else if (deep) { if constexpr (SSV_NARROW_DEEP) hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, 64, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y); }
+  // (a 128 x 64 tile with K-step 64 - 256-byte row pieces - is 6 % faster for the 256 -> 64 conv1 of the 56x56 stage, r03 x1, but its statistics
+  // epilogue sums each 64-row group in another order: the forward would no longer be bit-identical to bn_apply + conv2d_fwd_stats.  Not taken.)
+  const bool wide = d->K >= 128;
+  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
   else      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_sumin_stats");
   return SSV_OK;
@@ -1600,6 +1594,79 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   return SSV_OK;
 }
 }  // namespace
+
+// ---- batched GEMMs (the 16 transformed-domain products of a Winograd convolution, csrc/winograd.hip) -------------------------------------
+// y[b] [rows][K] = a[b] [rows][C] . w[b]^T [K][C] for b < batch, ONE launch (blockIdx.y = b) of the forward kernel's float4 path
+extern "C" int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a, const float* w, float* y, void* stream) {
+  SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "ssv_gemm_batched: bad shape");
+  SSV_REQUIRE(C % 32 == 0 && K % 4 == 0, "ssv_gemm_batched: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", C, K);
+  SSV_REQUIRE(a && w && y && (((uintptr_t)a | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "ssv_gemm_batched: null or unaligned pointer");
+  ssv_conv_desc d = {(int32_t)rows, 1, 1, C, K, 1, 1, 1, 0, 1, 1};
+  if (int rc = check_desc(&d, "ssv_gemm_batched")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(&d);
+  p.bs_a = rows * C; p.bs_b = (long long)K * C; p.bs_o = rows * K;
+  const bool wide = K >= 128;
+  const dim3 grid((unsigned)(wide ? cdiv(p.M, 128) * cdiv(K, 128) : cdiv(p.M, 256) * cdiv(K, 64)), (unsigned)batch);
+  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false>), grid, dim3(256), 0, s, p, a, w, (const float*)nullptr, (const float*)nullptr, y);
+  else      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, false, false, false, false>), grid, dim3(256), 0, s, p, a, w, (const float*)nullptr, (const float*)nullptr, y);
+  SSV_CHECK_LAUNCH("ssv_gemm_batched");
+  return SSV_OK;
+}
+
+namespace {
+struct BatchedWgradPlan { int bm, bn, tiles, nsplit, chunk; };
+BatchedWgradPlan plan_batched_wgrad(int batch, int64_t rows, int C, int K) {
+  BatchedWgradPlan w;
+  w.bm = K >= 128 ? 128 : 64;
+  w.bn = C <= 64 ? 64 : 128;
+  w.tiles = cdiv(K, w.bm) * cdiv(C, w.bn);
+  const int slots = w.bm == 128 ? 768 : 1024;                 // one resident round over ALL batches (round down: see plan_wgrad)
+  int64_t ns = slots / ((int64_t)w.tiles * batch);
+  const int64_t max_by_rows = cdiv64(rows, 256);
+  if (ns > max_by_rows) ns = max_by_rows;
+  if (ns < 1) ns = 1;
+  const int64_t chunk = cdiv64(cdiv64(rows, ns), 32) * 32;
+  w.chunk = (int)chunk;
+  w.nsplit = (int)cdiv64(rows, chunk);
+  return w;
+}
+}  // namespace
+
+extern "C" size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K) {
+  if (batch <= 0 || rows <= 0 || C <= 0 || K <= 0) return 0;
+  const BatchedWgradPlan w = plan_batched_wgrad(batch, rows, C, K);
+  return (size_t)batch * w.nsplit * K * C * sizeof(float);
+}
+
+// dw[b] [K][C] = dy[b]^T [K][rows] . x[b] [rows][C] for b < batch: one launch of the weight-gradient kernel (split over the rows, fixed-order reduce)
+extern "C" int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "ssv_gemm_batched_wgrad: bad shape");
+  SSV_REQUIRE(C % 4 == 0 && K % 4 == 0, "ssv_gemm_batched_wgrad: needs C %% 4 == 0 and K %% 4 == 0 (got C=%d K=%d)", C, K);
+  SSV_REQUIRE(x && dy && dw && ws && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws) & 15) == 0, "ssv_gemm_batched_wgrad: null or unaligned pointer");
+  ssv_conv_desc d = {(int32_t)rows, 1, 1, C, K, 1, 1, 1, 0, 1, 1};
+  if (int rc = check_desc(&d, "ssv_gemm_batched_wgrad")) return rc;
+  const BatchedWgradPlan wp = plan_batched_wgrad(batch, rows, C, K);
+  const size_t need = (size_t)batch * wp.nsplit * K * C * sizeof(float);
+  if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_gemm_batched_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_WGRAD, s);
+  ConvKP p = make_kp(&d);
+  p.bs_a = rows * C; p.bs_b = rows * K; p.bs_o = (long long)wp.nsplit * K * C;
+  float* part = (float*)ws;
+  const dim3 grid((unsigned)(wp.tiles * wp.nsplit), (unsigned)batch);
+#define BWG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles)
+  if (wp.bm == 128) { if (wp.bn == 64) BWG(128, 64, 2, 2); else BWG(128, 128, 2, 2); }
+  else              { if (wp.bn == 64) BWG(64, 64, 2, 2); else BWG(64, 128, 1, 4); }
+#undef BWG
+  SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(partial)");
+  const int64_t n = (int64_t)K * C;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
+  SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(reduce)");
+  return SSV_OK;
+}
 
 #ifdef SSV_STAMP
 extern "C" int ssv_debug_stamps(unsigned long long* out_host, int reset) {

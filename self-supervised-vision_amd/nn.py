@@ -285,14 +285,14 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
     if y is not None:
         pass
     elif lazy is not None:
-        y, part = ops.conv2d_fwd_fused(src, weight, stride, pad, in_affine=affine, want_stats=want)
+        y, part = ops.conv2d_fwd_fused(src, weight, stride, pad, in_affine=affine, want_stats=want, keep_v=tape is not None)
         if part is not None:
             y._bn_partials = part
     else:
-        fused = ops.conv2d_fwd_stats(src, weight, stride, pad) if want else None
+        fused = ops.conv2d_fwd_stats(src, weight, stride, pad, keep_v=tape is not None) if want else None
         if fused is not None:
             y = fused[0]
-            y._bn_partials = (fused[1], fused[2])
+            y._bn_partials = tuple(fused[1:])
         else:
             y = ops.conv2d_fwd(src, weight, stride, pad, bias=bias)
     if (tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW
@@ -302,9 +302,10 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
         need_dx = lazy is not None or tape.needs_grad(x)
 
         slot = tape.slot
+        wino_v = y.__dict__.pop("_wino_v", None)       # Winograd forward: its transformed input is the weight gradient's operand
 
         def bwd(dy, existing):
-            ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine)
+            ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine, wino_v=wino_v)
             if bias is not None:
                 ops.colsum(dy, grad_of(bias, slot), accumulate=True)
             if not need_dx:
@@ -328,7 +329,7 @@ def stem_conv(tape, x, weight, stride, pad, bn_stats=False):
     fused = ops.conv2d_fwd_stats(xp, wp, stride, pad) if (bn_stats and _FUSE_BN_STATS) else None
     if fused is not None:
         y = fused[0]
-        y._bn_partials = (fused[1], fused[2])
+        y._bn_partials = tuple(fused[1:])
     else:
         y = ops.conv2d_fwd(xp, wp, stride, pad)
     if tape is not None:
@@ -612,6 +613,9 @@ def _stacked(a, b, c):
         return None
     if a.data_ptr() + nbytes != b.data_ptr() or b.data_ptr() + nbytes != c.data_ptr():
         return None
+    base = a.untyped_storage()
+    if base.data_ptr() != b.untyped_storage().data_ptr() or base.data_ptr() != c.untyped_storage().data_ptr():
+        return None                      # adjacent by accident of the allocator, not views of one arena: three GEMMs
     return a.as_strided((3 * a.shape[0], a.shape[1]), (a.shape[1], 1))
 
 

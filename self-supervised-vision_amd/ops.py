@@ -3,6 +3,7 @@
 kernels on the current HIP stream; torch provides allocation, nothing else."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -78,9 +79,10 @@ def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None):
     return y
 
 
-def conv2d_fwd_stats(x, w, stride=1, pad=0):
-    """y = conv(x, w) plus the BatchNorm statistics partials of y from the same epilogue: (y, pmean, pm2) with one partial per
-    64 output rows.  Returns None when the shape is outside the fused kernel's preconditions (C % 32, K % 4)."""
+def conv2d_fwd_stats(x, w, stride=1, pad=0, keep_v=False):
+    """y = conv(x, w) plus the BatchNorm statistics partials of y from the same epilogue: (y, pmean, pm2[, rows per group]) with one partial
+    per 64 output rows unless the third element says otherwise.  Returns None when the shape is outside the fused kernel's preconditions
+    (C % 32, K % 4)."""
     _lib._dev(x, w)
     _, wshape = _ohwi(w)
     if (wshape[1] % 32 and wshape[1] != 4) or wshape[0] % 4:          # C == 4: the padded image stem
@@ -90,17 +92,24 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
         _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo)
     except _lib.SsvError:
         return None
-    y, part = conv2d_fwd_fused(x, w, stride, pad, in_affine=None, want_stats=True)
-    return y, part[0], part[1]
+    y, part = conv2d_fwd_fused(x, w, stride, pad, in_affine=None, want_stats=True, keep_v=keep_v)
+    return (y,) + tuple(part)
 
 
-def conv2d_fwd_fused(x, w, stride=1, pad=0, in_affine=None, want_stats=True):
+def conv2d_fwd_fused(x, w, stride=1, pad=0, in_affine=None, want_stats=True, keep_v=False):
     """y = conv(act(x), w) where act is the identity or, with ``in_affine = (scale, shift)``, relu(x * scale[c] + shift[c]) applied while
     the operand is staged (x is then the producer's RAW conv output: the activation itself is never written).  With ``want_stats``
-    the epilogue also leaves the BatchNorm statistics partials of y: returns (y, (pmean, pm2) | None)."""
+    the epilogue also leaves the BatchNorm statistics partials of y: returns (y, (pmean, pm2[, rows per group]) | None).
+    Stride-1 3x3 convolutions of the deep stages run through Winograd F(2x2, 3x3) (`use_winograd`); ``keep_v`` then leaves the transformed
+    input on the result (``y._wino_v``) for `conv2d_wgrad`."""
     _lib._dev(x, w)
     w, wshape = _ohwi(w)
     d = conv_desc(x.shape, wshape, stride, pad)
+    if use_winograd(wshape, stride, pad, x.shape, want_stats):
+        y, part, v = wino_conv2d_fwd(x, w, in_affine=in_affine, want_stats=want_stats, keep_v=keep_v)
+        if v is not None:
+            y._wino_v = v                  # the transformed input: the weight gradient's operand (nn.conv hands it to conv2d_wgrad)
+        return y, part
     if in_affine is None and not want_stats:
         return conv2d_fwd(x, w, stride, pad), None
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
@@ -156,12 +165,14 @@ def can_fuse_conv_input(cin, cout, groups=1):
 
 
 _WT_CACHE = {}          # (weight address, stream) -> (storage kept alive, transposed filter): one transpose per weight, stream and step
+_WINO_U = {}            # (weight address, stream, shape, transposed?) -> (storage kept alive, Winograd-transformed filter), same lifetime
 
 
 def invalidate_weight_caches():
     """Called by everything that mutates a GEMM operand in place (the optimizers' step() and zero_grad(), the EMA of target
     networks, MemoryBank pushes, checkpoint loads): a cached transposed filter must never outlive the weights it was made from."""
     _WT_CACHE.clear()
+    _WINO_U.clear()
 
 
 def _transposed_filter(w, wshape):
@@ -250,6 +261,9 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
         gate = None
     lib = _lib.load()
     n = dy.shape[0]
+    if (lazy is None and addend is None and out is None and (gate is None or gate.x2 is None)
+            and use_winograd((c, k, r, s_), stride, pad, dy.shape, False)):
+        return wino_conv2d_dgrad(dy, w, gate=gate)
     chunks = _batch_chunks(n, (dy[0].numel(), dx[0].numel()))
     as_fwd = stride == 1 and r == s_ and r - 1 - pad >= 0 and k % 16 == 0 and c % 4 == 0
     if gate is not None and not as_fwd and stride > 8:
@@ -295,9 +309,12 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     return dx
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None):
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None):
     """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI).  ``in_affine = (scale, shift)``: x is a raw conv output and
-    the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation)."""
+    the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation).  ``wino_v``: the transformed
+    input the Winograd forward of this convolution kept - the weight gradient is then 16 batched GEMMs on it (x / in_affine are not read)."""
+    if wino_v is not None and not isinstance(dy, LazyGrad):
+        return wino_conv2d_wgrad(wino_v, dy, w_like, dw, accumulate=accumulate)
     lazy = dy if isinstance(dy, LazyGrad) else None
     if lazy is not None:
         dy = lazy.g
@@ -324,6 +341,12 @@ def _rows(x):
     return x.numel() // c, c
 
 
+def _rows_per_group(partials):
+    """Statistics partials are (pmean, pm2) over groups of 64 output rows (the GEMM epilogues) or (pmean, pm2, rows per group) (the Winograd
+    output transform on odd maps: one image per group)."""
+    return int(partials[2]) if len(partials) > 2 else 64
+
+
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, nbt, relu=False, residual=None,
                  eps=BN_EPS, momentum=BN_MOMENTUM, want_mask=False, skip_mask=False, partials=None):
     """Returns (y, mean, invstd[, relu_mask]).  relu_mask: uint8, one byte per four channels, for the backward.
@@ -335,7 +358,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, nbt, relu=False, res
     mask = torch.empty((m * c // 4,), dtype=torch.uint8, device=x.device) if (want_mask and relu and not skip_mask) else None
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), x.device)
     if partials is not None:
-        call("ssv_bn_train_fwd_partials", m, c, ptr(x), ptr(partials[0]), ptr(partials[1]), 64, ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
+        call("ssv_bn_train_fwd_partials", m, c, ptr(x), ptr(partials[0]), ptr(partials[1]), _rows_per_group(partials), ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
              ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mask), ptr(mean), ptr(invstd), ptr(ws), ws.numel(), stream())
         return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
     call("ssv_bn_train_fwd", m, c, ptr(x), ptr(gamma), ptr(beta), ptr(residual), int(relu), eps, momentum,
@@ -349,7 +372,7 @@ def bn_stats_finalize(x_shape_rows, c, partials, gamma, beta, running_mean, runn
     dev = gamma.device
     stats = torch.empty((4, c), dtype=torch.float32, device=dev)            # mean | invstd | scale | shift
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(m, c), dev)
-    call("ssv_bn_stats_finalize", m, c, ptr(partials[0]), ptr(partials[1]), 64, ptr(gamma), ptr(beta), eps, momentum,
+    call("ssv_bn_stats_finalize", m, c, ptr(partials[0]), ptr(partials[1]), _rows_per_group(partials), ptr(gamma), ptr(beta), eps, momentum,
          ptr(running_mean), ptr(running_var), ptr(nbt), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(ws), ws.numel(), stream())
     return stats[0], stats[1], stats[2], stats[3]
 
@@ -836,3 +859,111 @@ def unpad_channels(t, out, accumulate=True):
     _lib._dev(t, out)
     call("ssv_pad_channels", t.numel() // t.shape[-1], t.shape[-1], out.shape[-1], ptr(t), ptr(out), int(accumulate), stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------- Winograd F(2x2, 3x3)
+def _wino_filter(w, wshape, transposed=False):
+    """U = G g G^T of the filter [K][3][3][C] - or, ``transposed``, of the rotated filter with the channel roles swapped (data gradient)."""
+    key = (w.data_ptr(), stream(), wshape, transposed)
+    hit = _WINO_U.get(key)
+    if hit is not None:
+        return hit[1]
+    k, c, _, _ = wshape
+    src, kk, cc = (w, k, c) if not transposed else (_transposed_filter(w, wshape), c, k)
+    u = torch.empty((16, kk, cc), dtype=torch.float32, device=w.device)
+    call("ssv_wino_filter_transform", kk, cc, ptr(src), ptr(u), stream())
+    _WINO_U[key] = (w.untyped_storage(), u)
+    return u
+
+
+WINOGRAD = os.environ.get("SSV_NO_WINOGRAD", "0") != "1"          # diagnostic switch: every 3x3 convolution on the direct implicit-GEMM kernels
+# Measured at bs 512 (tools/probe_winograd.py, profiles/r03_probe_winograd.txt): 14x14 x 256 channels forward 1.50x, data gradient 1.62x, weight
+# gradient 1.97x; 7x7 x 512: 1.76 / 1.73 / 1.72; 28x28 x 128: 1.13 / 1.10 / 1.54; 56x56 x 64: 0.79 / 0.71 (the transforms move 9x the tensors
+# and that layer is HBM-heavy already) - so: at least 128 channels on both sides.
+WINOGRAD_MIN_CHANNELS = int(os.environ.get("SSV_WINOGRAD_MIN_CHANNELS", "128"))
+WINOGRAD_MIN_TILES = 256                                           # below that the three launches cost more than they save
+
+
+def _lanes_ok(ch):
+    return ch % 32 == 0 and ((ch // 4 <= 256 and 256 % (ch // 4) == 0) or (ch // 4) % 256 == 0)
+
+
+def use_winograd(wshape, stride, pad, x_shape, want_stats):
+    """Does this convolution run through F(2x2, 3x3)?  3x3 / stride 1 / padding 1, channel counts the transforms' lane mapping takes, enough
+    tiles, every operand slice below the per-launch limit, and - when the statistics epilogue is wanted - a map that partitions evenly."""
+    k, c, r, s_ = wshape
+    if not (WINOGRAD and r == 3 and s_ == 3 and stride == 1 and pad == 1 and _lanes_ok(c) and _lanes_ok(k)
+            and min(c, k) >= WINOGRAD_MIN_CHANNELS):
+        return False
+    n, h, w_ = x_shape[0], x_shape[1], x_shape[2]
+    t = n * ((h + 1) // 2) * ((w_ + 1) // 2)
+    if t < WINOGRAD_MIN_TILES or t * max(c, k) >= _MAX_ELEMS:
+        return False
+    return not want_stats or int(_lib.load().ssv_wino_stats_rows_per_group(n, h, w_)) > 0
+
+
+def wino_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
+    """y = conv3x3(act(x), w) (stride 1, padding 1) through F(2x2, 3x3).  Returns (y, (pmean, pm2) | None, V | None): the statistics
+    partials are one per 16 tiles = 64 output rows (needs even H, W); V is the transformed input, kept for the weight gradient."""
+    _lib._dev(x, w)
+    w, wshape = _ohwi(w)
+    n, h, w_, c = x.shape
+    k = wshape[0]
+    lib = _lib.load()
+    t = int(lib.ssv_wino_tiles(n, h, w_))
+    u = _wino_filter(w, wshape)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    v = torch.empty((16, t, c), dtype=torch.float32, device=x.device)
+    call("ssv_wino_input_transform", n, h, w_, c, ptr(x), ptr(sc), ptr(sh), ptr(v), stream())
+    m = torch.empty((16, t, k), dtype=torch.float32, device=x.device)
+    call("ssv_gemm_batched", 16, t, c, k, ptr(v), ptr(u), ptr(m), stream())
+    y = _empty((n, h, w_, k), x)
+    part = None
+    if want_stats:
+        groups = int(lib.ssv_wino_groups(n, h, w_))
+        part = _empty((2, groups, k), x)
+    call("ssv_wino_output_transform", n, h, w_, k, ptr(m), ptr(y), None if part is None else ptr(part[0]), None if part is None else ptr(part[1]), None, stream())
+    rpg = int(lib.ssv_wino_stats_rows_per_group(n, h, w_)) if want_stats else 0
+    return y, (None if part is None else (part[0], part[1], rpg)), (v if keep_v else None)
+
+
+def wino_conv2d_dgrad(dy, w, gate=None):
+    """dx = conv3x3 data gradient (stride 1, padding 1) through F(2x2, 3x3) on the transposed, rotated filter; ``gate`` (BnGateCtx without
+    a second target): dx is gated and its partial sums come back as ``dx._gate_partials`` like conv2d_dgrad's."""
+    _lib._dev(dy, w)
+    w, wshape = _ohwi(w)
+    n, h, w_, k = dy.shape
+    c = wshape[1]
+    lib = _lib.load()
+    t = int(lib.ssv_wino_tiles(n, h, w_))
+    u = _wino_filter(w, wshape, transposed=True)                  # [16][C][K]
+    v = torch.empty((16, t, k), dtype=torch.float32, device=dy.device)
+    call("ssv_wino_input_transform", n, h, w_, k, ptr(dy), None, None, ptr(v), stream())
+    m = torch.empty((16, t, c), dtype=torch.float32, device=dy.device)
+    call("ssv_gemm_batched", 16, t, k, c, ptr(v), ptr(u), ptr(m), stream())
+    dx = _empty((n, h, w_, c), dy)
+    if gate is not None:
+        groups = int(lib.ssv_wino_groups(n, h, w_))
+        st, part = _gate_struct(gate, groups, c, dy)
+        call("ssv_wino_output_transform", n, h, w_, c, ptr(m), ptr(dx), None, None, C.byref(st), stream())
+        dx._gate_partials = (part[0], part[1], groups)
+    else:
+        call("ssv_wino_output_transform", n, h, w_, c, ptr(m), ptr(dx), None, None, None, stream())
+    return dx
+
+
+def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
+    """dw (+)= weight gradient of the 3x3 convolution whose transformed input V was kept by wino_conv2d_fwd."""
+    _lib._dev(v, dy, dw)
+    _, wshape = _ohwi(w_like)
+    n, h, w_, k = dy.shape
+    c = wshape[1]
+    lib = _lib.load()
+    t = int(lib.ssv_wino_tiles(n, h, w_))
+    dm = torch.empty((16, t, k), dtype=torch.float32, device=dy.device)
+    call("ssv_wino_dy_transform", n, h, w_, k, ptr(dy), ptr(dm), stream())
+    ws = workspace.get(lib.ssv_gemm_batched_wgrad_workspace_bytes(16, t, c, k), dy.device)
+    du = torch.empty((16, k, c), dtype=torch.float32, device=dy.device)
+    call("ssv_gemm_batched_wgrad", 16, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
+    call("ssv_wino_filter_grad", k, c, ptr(du), ptr(dw), int(accumulate), stream())
+    return dw

@@ -114,10 +114,13 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True))
         del res
     elif kind == "lazy" and ops.can_fuse_conv_input(Cx, K):
-        fv = "stats+bn_in"
-        t_f = timeit(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True))
-        wv = "bn_in" + ("+dy_in" if dyl is not None else "")
-        t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True, in_affine=aff))
+        wino = ops.use_winograd(tuple(w.shape), s, p, x.shape, True)        # stride-1 3x3 layers of the deep stages: Winograd F(2x2, 3x3)
+        fv = "stats+bn_in" + ("+winograd" if wino else "")
+        t_f = timeit(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True, keep_v=True))
+        vkeep = getattr(ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True, keep_v=True)[0], "_wino_v", None)
+        wv = "bn_in" + ("+dy_in" if dyl is not None else "") + ("+winograd" if vkeep is not None else "")
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True, in_affine=aff, wino_v=vkeep))
+        del vkeep
     else:
         fv = "stats" if stats_ok else ("c4" if Cx == 4 else "plain")
         t_f = timeit((lambda: ops.conv2d_fwd_stats(x, w, s, p)) if stats_ok else (lambda: ops.conv2d_fwd(x, w, s, p)))
@@ -134,7 +137,8 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         else:
             gate = ops.BnGateCtx(gx, mean, invstd, mask=torch.randint(0, 16, (x.numel() // 4,), device=dev, dtype=torch.uint8))
         addend = torch.randn_like(x) if kind == "plain" else None
-        dv = ("fwd-kernel" if s == 1 else "dgrad-kernel") + "+gate" + ("+addend" if addend is not None else "") + ("+dy_in" if dyl is not None else "")
+        dv = ("winograd" if (addend is None and dyl is None and kind == "lazy" and ops.use_winograd((C, K, R, R), s, p, dy.shape, False)) else
+              ("fwd-kernel" if s == 1 else "dgrad-kernel")) + "+gate" + ("+addend" if addend is not None else "") + ("+dy_in" if dyl is not None else "")
         t_d = timeit(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate))
         if ".1.conv1" in name and kind == "plain" and s == 1:
             # the first of these units sits behind a projection shortcut: its gate also reduces against that BatchNorm's input (GATE 3)
