@@ -116,7 +116,7 @@ def test_r50_224_teacher_forced_steps(dev):
     seen = []
     make = lambda: oracle.SimCLROracle("resnet50", False, 128, lr=lr, weight_decay=1e-4)
     o32, o64 = make(), _oracle64_like(make)
-    for s in range(3):
+    for s in range(2):                                              # step 1 starts from moved weights AND a filled momentum buffer
         a1, a2 = corr_views(7100 + 3 * s, B, SIZE)
         # every evaluation starts this step from the CPU trajectory's state
         with torch.no_grad():
