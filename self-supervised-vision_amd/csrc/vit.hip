@@ -301,6 +301,152 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dv_lo, dv_hi, 1.f);
 }
 
+// ------------------------------------------------------------------------------------------------ attention backward, ONE pass (T <= 256)
+// The two-pass form above recomputes S = Q K^T and dP = dO V^T twice (once per pass): 7 products per (query tile, key tile) pair for the 4 the
+// backward needs + 1.  Here ONE workgroup holds every key tile of an (image, head) - wave w owns keys [32 w, 32 w + 32): its V fragment and its
+// dK / dV accumulators live in registers, all K rows of the head sit in LDS - and walks the query tiles once: S and dP are computed once,
+// dV += P^T dO and dK += dS^T Q accumulate per wave, and the query gradient dQ_i = sum over the key tiles of dS_ij K_j is reduced ACROSS the
+// waves through LDS in fixed wave order (deterministic).  dS has the key on the lane and the query on the register index; the dQ product
+// contracts over keys, so each wave transposes its 32 x 32 dS tile through its own LDS scratch (written row = query, read back 4 keys per
+// ds_read_b128), which afterwards takes the wave's dQ partial (register-major, so that the reduction reads one b128 per wave and group).
+// 5 products instead of 7 per tile pair; delta = rowsum(O * dO) is formed while the query rows are staged (no extra pass, DELTA is still
+// written for callers that want it).  Per query tile: two barriers (all partials written -> reduce + restage -> next tile).
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_bwd_fused_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, int ld, float scale,
+                                                            const float* __restrict__ O, const float* __restrict__ dO, int ldo,
+                                                            const float* __restrict__ LSE, float* __restrict__ DELTA,
+                                                            float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int ldg) {
+  __shared__ __attribute__((aligned(16))) float sK[NW * 32 * TS];      // every key row of this (image, head)
+  __shared__ __attribute__((aligned(16))) float sq[32 * TS], sd[32 * TS];
+  __shared__ float sstat[2][32];                                        // lse (log2 units) | delta of the staged query rows
+  __shared__ __attribute__((aligned(16))) float scr[NW][2048];          // per wave: dS^T staging (32 x 36), then its dQ partial (32 registers x 64 lanes)
+  constexpr int N4 = 512 / (NW * 64);                                   // float4 per thread per staged 32 x 64 tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0 = wave * 32;
+  const bool active = k0 < T;
+  const int nact = (T + 31) >> 5;                                       // waves that own keys
+  const int64_t tok0 = (int64_t)b * T;
+  const int krow = min(k0 + c, T - 1);
+  const bool kvalid = k0 + c < T;
+  const int64_t stat = ((int64_t)b * heads + h) * T;
+  const float* qbase = Q + tok0 * ld + h * DH;
+  const float* kbase = K + tok0 * ld + h * DH;
+  const float* obase = O + tok0 * ldo + h * DH;
+  const float* dobase = dO + tok0 * ldo + h * DH;
+  // all keys -> LDS (rows past T repeat the last row: their probabilities are forced to 0 below)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
+    *(f32x4*)(sK + r * TS + c4) = *(const f32x4*)(kbase + (int64_t)min(r, T - 1) * ld + c4);
+  }
+  float vreg[32];
+  load_row32(V + (tok0 + krow) * ld + h * DH + half * 32, vreg, 1.f);
+  f32x16 dk_lo = zero16(), dk_hi = zero16(), dv_lo = zero16(), dv_hi = zero16();
+  // staging of one query tile: Q and dO rows to registers, delta = sum_d O * dO reduced over the 16 lanes that share a row
+  f32x4 ra[N4], rb[N4];
+  float rdelta[N4], rlse[N4];
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
+      const int64_t row = min(q0 + r, T - 1);
+      ra[i] = *(const f32x4*)(qbase + row * ld + c4);
+      rb[i] = *(const f32x4*)(dobase + row * ldo + c4);
+      const f32x4 ov = *(const f32x4*)(obase + row * ldo + c4);
+      float d = ov[0] * rb[i][0] + ov[1] * rb[i][1] + ov[2] * rb[i][2] + ov[3] * rb[i][3];
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      rdelta[i] = d;
+      rlse[i] = LSE[stat + row] * LOG2E;
+    }
+  };
+  auto store_tile = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
+      *(f32x4*)(sq + r * TS + c4) = ra[i];
+      *(f32x4*)(sd + r * TS + c4) = rb[i];
+      if ((e & 15) == 0) {
+        sstat[0][r] = rlse[i]; sstat[1][r] = rdelta[i];
+        if (q0 + r < T) DELTA[stat + q0 + r] = rdelta[i];
+      }
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  float* myscr = scr[wave];
+  for (int q0 = 0; q0 < T; q0 += 32) {
+    const bool more = q0 + 32 < T;
+    if (more) load_tile(q0 + 32);                           // next tile's rows fly under this tile's MFMAs
+    if (active) {
+      float fr[32];
+      f32x16 s = zero16(), dp = zero16();
+      {
+        float kf[32];
+        lds_row32(sq, c, half, fr);
+        lds_row32(sK + k0 * TS, c, half, kf);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[i] * (scale * LOG2E), kf[i], s, 0, 0, 0);   // rows = query, col = key
+      }
+      lds_row32(sd, c, half, fr);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[i], vreg[i], dp, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = rowof(j, half);
+        const float p = (q0 + r < T && kvalid) ? ex2(s[j] - sstat[0][r]) : 0.f;
+        s[j] = p;                                              // P
+        dp[j] = p * (dp[j] - sstat[1][r]);                     // dS
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (q0 + rowof(j, 0) >= T) continue;                   // padding queries: P and dS are 0
+        const float* qr = sq + rowof(j, half) * TS;
+        const float* dr = sd + rowof(j, half) * TS;
+        dv_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[c], s[j], dv_lo, 0, 0, 0);
+        dv_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[32 + c], s[j], dv_hi, 0, 0, 0);
+        dk_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[c], dp[j], dk_lo, 0, 0, 0);
+        dk_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 + c], dp[j], dk_hi, 0, 0, 0);
+      }
+      // dS (query on the register index, key on the lane) -> dS^T (key on the register index, query on the lane) through this wave's scratch
+#pragma unroll
+      for (int j = 0; j < 16; ++j) myscr[rowof(j, half) * 36 + c] = dp[j];
+      f32x16 st_;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 t = *(const f32x4*)(myscr + c * 36 + 8 * jj + 4 * half);
+        st_[4 * jj] = t[0]; st_[4 * jj + 1] = t[1]; st_[4 * jj + 2] = t[2]; st_[4 * jj + 3] = t[3];
+      }
+      f32x16 g_lo = zero16(), g_hi = zero16();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (k0 + rowof(j, 0) >= T) continue;                   // both keys of this step are padding (wave-uniform): dS is 0 there
+        const float* kr = sK + (k0 + rowof(j, half)) * TS;
+        g_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[c], st_[j], g_lo, 0, 0, 0);
+        g_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[32 + c], st_[j], g_hi, 0, 0, 0);
+      }
+      // this wave's dQ partial, group-major: group G = registers 4 G' .. 4 G' + 3 of lo (G < 4) / hi, one b128 per lane and group
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        *(f32x4*)(myscr + (G * 64 + lane) * 4) = f32x4{g_lo[4 * G], g_lo[4 * G + 1], g_lo[4 * G + 2], g_lo[4 * G + 3]};
+        *(f32x4*)(myscr + ((G + 4) * 64 + lane) * 4) = f32x4{g_hi[4 * G], g_hi[4 * G + 1], g_hi[4 * G + 2], g_hi[4 * G + 3]};
+      }
+    }
+    __syncthreads();                                           // every partial is in LDS; nobody reads sq / sd any more
+    for (int G = wave; G < 8; G += NW) {                       // dQ of this query tile: sum over the key tiles in wave order, 4 consecutive d per lane
+      f32x4 acc = *(const f32x4*)(scr[0] + (G * 64 + lane) * 4);
+      for (int w = 1; w < nact; ++w) acc += *(const f32x4*)(scr[w] + (G * 64 + lane) * 4);
+      if (q0 + c < T) *(f32x4*)(dQ + (tok0 + q0 + c) * ldg + h * DH + (G < 4 ? 0 : 32) + 8 * (G & 3) + 4 * half) = acc * scale;
+    }
+    if (more) store_tile(q0 + 32);
+    __syncthreads();
+  }
+  store_tile_T(dK + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dk_lo, dk_hi, scale);
+  store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dv_lo, dv_hi, 1.f);
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // one wavefront per row; lane owns columns 4*lane + 256*it
 __global__ void __launch_bounds__(256) ln_fwd_k(int64_t M, int C, const float* __restrict__ x, const float* __restrict__ gamma,
@@ -516,6 +662,16 @@ extern "C" int ssv_attention_bwd(int32_t B, int32_t T, int32_t heads, int32_t dh
   SSV_REQUIRE(B <= 65535 && heads <= 65535, "ssv_attention_bwd: grid too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_ATTN, s);
+#ifndef SSV_ATTN_TWO_PASS          // diagnostic builds only: the two-pass backward for every T
+  if (T <= 256) {                   // one pass: a workgroup holds all key tiles of an (image, head), dQ reduced across its waves
+    const dim3 grid(1, heads, B);
+    if (T <= 64) hipLaunchKernelGGL(attn_bwd_fused_k<2>, grid, dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, dk, dv, ldg);
+    else if (T <= 128) hipLaunchKernelGGL(attn_bwd_fused_k<4>, grid, dim3(256), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, dk, dv, ldg);
+    else hipLaunchKernelGGL(attn_bwd_fused_k<8>, grid, dim3(512), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, dk, dv, ldg);
+    SSV_CHECK_LAUNCH("attn_bwd_fused_k");
+    return SSV_OK;
+  }
+#endif
   if (T <= 64) {
     const dim3 grid(cdiv(T, 64), heads, B);
     hipLaunchKernelGGL(attn_bwd_dq_k<2>, grid, dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, dout, ldo, lse, delta, dq, ldg);
