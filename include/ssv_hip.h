@@ -132,6 +132,14 @@ int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, const float* i
 int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x, const float* res, const float* scale, const float* shift,
                                const float* rscale, const float* rshift, const float* w, float* y, float* pmean, float* pm2,
                                float* a_out, uint8_t* mask_out, void* stream);
+/* The data gradient of a 1x1 / stride-2 projection shortcut (networks/resnet.py:131-135) as a dense GEMM on the subsampled grid: it is computed by
+ * ssv_conv2d_fwd on the [N][ceil(H/2)][ceil(W/2)][K] grid and handed, COMPACT, to the unit input's other contribution - conv1's data gradient,
+ * which runs on the forward kernel - as its addend: addend [N][H2][W2][K] belongs to the output pixels with even (h, w), every other pixel gets
+ * none.  (The full-resolution tensor of three quarters zeros, and its re-read, never exist.)  K >= 128, byte-mask gate. */
+int ssv_conv2d_fwd_gated_s2add(const ssv_conv_desc* d, const float* x, const float* w, const float* addend, int32_t H2, int32_t W2, float* y,
+                               const ssv_bn_gate* gate, void* stream);
+int ssv_conv2d_fwd_dyin_s2add(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend,
+                              int32_t H2, int32_t W2, float* y, const ssv_bn_gate* gate, void* stream);
 /* ssv_conv2d_dgrad with the gate.  K % 32 == 0, C % 4 == 0 */
 int64_t ssv_conv2d_dgrad_gate_groups(const ssv_conv_desc* d);
 int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend, float* dx,

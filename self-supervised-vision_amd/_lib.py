@@ -62,6 +62,8 @@ SIGNATURES = {
     "ssv_conv2d_dgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp]),
     "ssv_conv2d_fwd_gate_groups": (_i64, [_cd]),
     "ssv_conv2d_fwd_gated": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
+    "ssv_conv2d_fwd_gated_s2add": (C.c_int, [_cd, _vp, _vp, _vp, _i32, _i32, _vp, C.POINTER(BnGate), _vp]),
+    "ssv_conv2d_fwd_dyin_s2add": (C.c_int, [_cd, _vp, C.POINTER(BnDyin), _vp, _vp, _i32, _i32, _vp, C.POINTER(BnGate), _vp]),
     "ssv_conv2d_dgrad_gate_groups": (_i64, [_cd]),
     "ssv_conv2d_dgrad_gated": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
     "ssv_bn_bwd_from_partials": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),

@@ -76,6 +76,9 @@ struct ConvKP {
   float* sum_out; uint8_t* sum_mask;
   // batched launches (blockIdx.y = batch index: the 16 GEMMs of a Winograd convolution): element strides of the three operands, 0 otherwise
   long long bs_a, bs_b, bs_o;
+  // compact addend (ADDS2 variants): the addend is [N][add_H2][add_W2][K] and belongs to the output pixels with even (h, w) - the data gradient
+  // of a 1x1 / stride-2 projection shortcut, computed as a dense GEMM on the subsampled grid instead of a full-resolution tensor of 3/4 zeros
+  int add_H2, add_W2;
 };
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
@@ -306,12 +309,16 @@ __device__ __forceinline__ void bstore4(rsrc_t rs, int voff_bytes, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, voff_bytes, 0, 0);
 }
 
-template <int TM, int TN, int EPI = 0, bool STATS = false, int GATE = 0, class RowOff>
+// AddOff: where the addend of output row r lives when it is NOT laid out like the output: a functor (row of the wave tile) -> element offset
+// of that row in the addend tensor, or -1 for "this row has no addend" (the compact gradient of a stride-2 shortcut: only rows with even
+// (h, w) carry one).  SameOff = the addend has the output's layout.
+struct SameOff {};
+template <int TM, int TN, int EPI = 0, bool STATS = false, int GATE = 0, class RowOff, class AddOff = SameOff>
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
                                              const float* __restrict__ bias, const float* addend, float* out, long long out_elems, RowOff&& row_off,
                                              float* out_act = nullptr, const float* gate = nullptr,
                                              float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0,
-                                             const ssv_bn_gate* bn = nullptr, long long group = 0) {
+                                             const ssv_bn_gate* bn = nullptr, long long group = 0, AddOff add_off = AddOff(), long long add_elems = 0) {
   constexpr int LDE = TN * 32 + 4, C4 = TN * 8, RPI = 64 / C4, NP = 32 / RPI;
   constexpr bool GMASK = GATE >= 2, GX2 = GATE == 3;
   // rows per batch: the loads of a batch are in flight together.  GATE 1 lives in kernels compiled for 3 workgroups per CU (register budget: 2 rows);
@@ -339,7 +346,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 
   const bool ADD = addend != nullptr;            // uniform
   {
-    const rsrc_t r_add = make_rsrc(ADD ? addend : out, bytes);
+    constexpr bool ADD_SAME = std::is_same<AddOff, SameOff>::value;
+    const rsrc_t r_add = make_rsrc(ADD ? addend : out, ADD_SAME ? bytes : (unsigned)(add_elems * 4));
     const rsrc_t r_gx = make_rsrc(GATE != 0 ? bn->x : out, bytes);
     const rsrc_t r_gm = make_rsrc(GMASK ? reinterpret_cast<const float*>(bn->mask) : out, bytes / 16);
     const rsrc_t r_gx2 = make_rsrc(GX2 ? bn->x2 : out, bytes);
@@ -362,7 +370,12 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
         for (int i = 0; i < HB; ++i) {
           const long long off = row_off(tm * 32 + (q0 + i) * RPI + r_in);
           voff[i] = (off >= 0 && cok) ? (int)(off + gcol) * 4 : OOB_OFF;        // tensors stay below 2^29 elements (check_desc)
-          if (ADD) av[i] = bload4(r_add, voff[i], 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          int aoff = voff[i];
+          if constexpr (!ADD_SAME) {
+            const long long ao = add_off(tm * 32 + (q0 + i) * RPI + r_in);
+            aoff = (ao >= 0 && voff[i] != OOB_OFF) ? (int)(ao + gcol) * 4 : OOB_OFF;
+          }
+          if (ADD) av[i] = bload4(r_add, aoff, 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == 2) gv[i] = bload4(r_gate, voff[i], 0);
           if constexpr (GATE != 0) xv[i] = bload4(r_gx, voff[i], 0);
           if constexpr (GMASK) mb[i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[i] == OOB_OFF ? OOB_OFF : voff[i] >> 4, 0, 0);
@@ -453,7 +466,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false>
 // Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
@@ -746,9 +759,26 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
                                           nullptr, nullptr, p.aux_out + (size_t)g * p.K, p.aux_out2 + (size_t)g * p.K, valid > 0 ? valid : 0);
       } else if constexpr (GATE != 0) {
         static_assert(BM / WGM == 64, "gate partials are per 64 output rows");
-        epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
-                                                 [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
-                                                 nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
+        auto row_off = [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; };
+        if constexpr (ADDS2) {
+          static_assert(GATE != 0, "the compact stride-2 addend rides on the gated epilogues");
+          auto add_off = [&](int r) -> long long {            // output row -> row of the compact addend, or -1 (odd h or w: no contribution)
+            const int m = rbase + r;
+            if (m >= p.M) return -1;
+            const uint32_t n = fdiv((uint32_t)m, p.dHoWo);
+            const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Ho * p.Wo);
+            const uint32_t ho = fdiv(rem, p.dWo);
+            const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+            if ((ho | wo) & 1u) return -1;
+            return ((long long)((int)n * p.add_H2 + (int)(ho >> 1)) * p.add_W2 + (int)(wo >> 1)) * p.K;
+          };
+          epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
+                                                   nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64), add_off,
+                                                   (long long)p.N * p.add_H2 * p.add_W2 * p.K);
+        } else {
+          epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
+                                                   nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
+        }
       } else {
         epilogue_vec<TM, TN, EPI ? 1 : 0>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
@@ -1194,6 +1224,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dyin_x = nullptr; p.dyin_coef = nullptr;
   p.sum_res = p.sum_scale = p.sum_shift = p.sum_rscale = p.sum_rshift = nullptr; p.sum_out = nullptr; p.sum_mask = nullptr;
   p.bs_a = p.bs_b = p.bs_o = 0;
+  p.add_H2 = p.add_W2 = 0;
   return p;
 }
 
@@ -1229,8 +1260,10 @@ namespace {
 
 // forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
 int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
-               float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s, const ssv_bn_gate* gate = nullptr) {
+               float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s, const ssv_bn_gate* gate = nullptr,
+               int add_H2 = 0, int add_W2 = 0) {
   ConvKP p = make_kp(d);
+  p.add_H2 = add_H2; p.add_W2 = add_W2;
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
   const bool wide = d->K >= 128;
@@ -1240,7 +1273,11 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
 #define FWDG(BM_, BN_, WM_, WN_, G_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
 #define FWDG_TILE(G_) do { if (wide) FWDG(128, 128, 2, 2, G_); else FWDG(256, 64, 4, 1, G_); } while (0)
-    if (gate->x2) FWDG_TILE(3); else if (gate->mask) FWDG_TILE(2); else FWDG_TILE(1);
+    if (add_H2 > 0) {                                          // compact stride-2 addend: wide tile, byte-mask gates (checked by the caller)
+#define FWDGS(G_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 0, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+      if (gate->x2) FWDGS(3); else FWDGS(2);
+#undef FWDGS
+    } else if (gate->x2) FWDG_TILE(3); else if (gate->mask) FWDG_TILE(2); else FWDG_TILE(1);
 #undef FWDG_TILE
 #undef FWDG
     return SSV_OK;
@@ -1319,10 +1356,28 @@ extern "C" int ssv_conv2d_fwd_gated(const ssv_conv_desc* d, const float* x, cons
   return SSV_OK;
 }
 
+// ssv_conv2d_fwd_gated whose addend is the COMPACT data gradient of a stride-2 projection shortcut: addend [N][H2][W2][K] belongs to the output
+// pixels with even (h, w) (H2 = ceil(Ho / 2), W2 = ceil(Wo / 2)); every other pixel gets no addend.  K >= 128, byte-mask gate.
+extern "C" int ssv_conv2d_fwd_gated_s2add(const ssv_conv_desc* d, const float* x, const float* w, const float* addend, int32_t H2, int32_t W2, float* y,
+                                          const ssv_bn_gate* gate, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_gated_s2add")) return rc;
+  if (int rc = check_gate(gate, "ssv_conv2d_fwd_gated_s2add")) return rc;
+  SSV_REQUIRE(x && w && y && addend, "ssv_conv2d_fwd_gated_s2add: null pointer");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)addend) & 15) == 0, "ssv_conv2d_fwd_gated_s2add: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0 && d->K >= 128 && gate->mask, "ssv_conv2d_fwd_gated_s2add: needs C %% 32 == 0, K %% 4 == 0, K >= 128 and the byte-mask gate (got C=%d K=%d)", d->C, d->K);
+  SSV_REQUIRE(H2 == (d->Ho + 1) / 2 && W2 == (d->Wo + 1) / 2, "ssv_conv2d_fwd_gated_s2add: the compact addend must be ceil(Ho/2) x ceil(Wo/2) (got %d x %d for %d x %d)", H2, W2, d->Ho, d->Wo);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  launch_fwd(d, x, w, nullptr, addend, y, nullptr, nullptr, nullptr, nullptr, s, gate, H2, W2);
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_gated_s2add");
+  return SSV_OK;
+}
+
 // 1x1 / stride-1 forward convolution whose input operand is the BatchNorm backward's dx, formed on load (the data gradient of a 1x1
 // convolution runs here with the transposed filter); optional gate on the output as in ssv_conv2d_fwd_gated.
-extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend, float* y,
-                                   const ssv_bn_gate* gate, void* stream) {
+namespace {
+int fwd_dyin_impl(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend, int add_H2, int add_W2, float* y,
+                  const ssv_bn_gate* gate, void* stream) {
   if (int rc = check_desc(d, "ssv_conv2d_fwd_dyin")) return rc;
   if (gate) { if (int rc = check_gate(gate, "ssv_conv2d_fwd_dyin")) return rc; }
   SSV_REQUIRE(g && w && y && dyin && dyin->x && dyin->coef, "ssv_conv2d_fwd_dyin: null pointer");
@@ -1335,6 +1390,7 @@ extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   ConvKP p = make_kp(d);
   p.dyin_x = dyin->x; p.dyin_coef = dyin->coef;
+  p.add_H2 = add_H2; p.add_W2 = add_W2;
   if (gate) p.gate = *gate;
   const bool wide = d->K >= 128;
   const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
@@ -1342,11 +1398,29 @@ extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const
 #define FWDD(BM_, BN_, WM_, WN_, G_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
 #define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
-  if (gm == 3) FWDD_TILE(3); else if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
+  if (add_H2 > 0) {                                          // compact stride-2 addend: wide tile and byte-mask gate checked by the caller
+#define FWDDS(G_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 1, true>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+    if (gm == 3) FWDDS(3); else FWDDS(2);
+#undef FWDDS
+  } else if (gm == 3) FWDD_TILE(3); else if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
 #undef FWDD_TILE
 #undef FWDD
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_dyin");
   return SSV_OK;
+}
+}  // namespace
+
+extern "C" int ssv_conv2d_fwd_dyin(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend, float* y,
+                                   const ssv_bn_gate* gate, void* stream) {
+  return fwd_dyin_impl(d, g, dyin, w, addend, 0, 0, y, gate, stream);
+}
+
+// ssv_conv2d_fwd_dyin with the compact stride-2 addend of ssv_conv2d_fwd_gated_s2add (K >= 128, byte-mask gate required)
+extern "C" int ssv_conv2d_fwd_dyin_s2add(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyin, const float* w, const float* addend,
+                                         int32_t H2, int32_t W2, float* y, const ssv_bn_gate* gate, void* stream) {
+  SSV_REQUIRE(d && gate && gate->mask && addend && d->K >= 128, "ssv_conv2d_fwd_dyin_s2add: needs the compact addend, the byte-mask gate and K >= 128");
+  SSV_REQUIRE(H2 == (d->Ho + 1) / 2 && W2 == (d->Wo + 1) / 2, "ssv_conv2d_fwd_dyin_s2add: the compact addend must be ceil(Ho/2) x ceil(Wo/2) (got %d x %d for %d x %d)", H2, W2, d->Ho, d->Wo);
+  return fwd_dyin_impl(d, g, dyin, w, addend, H2, W2, y, gate, stream);
 }
 
 // 1x1 / stride-1 forward convolution (with the statistics epilogue) whose input is the closing activation of the previous residual unit,

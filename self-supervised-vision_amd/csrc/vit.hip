@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 // 5 products instead of 7 per tile pair; delta = rowsum(O * dO) is formed while the query rows are staged (no extra pass, DELTA is still
 // written for callers that want it).  Per query tile: two barriers (all partials written -> reduce + restage -> next tile).
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_bwd_fused_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 1 : 2, 2))) attn_bwd_fused_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, int ld, float scale,
                                                             const float* __restrict__ O, const float* __restrict__ dO, int ldo,
                                                             const float* __restrict__ LSE, float* __restrict__ DELTA,

@@ -61,7 +61,12 @@ class _ResidualUnit(hnn.HipModule):
         shortcut = x
         if self.downsample is not None:                      # conv1x1 -> BN: no ReLU, its only consumer is the closing BatchNorm below
             fold = getattr(self, f"conv{self.depth}").has_stats_epilogue()
-            shortcut = hnn.batchnorm(tape, self.downsample[0]._run(tape, x, bn_stats=True), self.downsample[1], lazy=fold)
+            # a stride-2 shortcut next to a wide 1x1 / stride-1 conv1 (every bottleneck stage entry): its data gradient stays compact and conv1's
+            # data gradient - the last contribution to the unit input's gradient - adds it in its epilogue (hnn.conv, ops.StridedGrad)
+            c1 = self.conv1
+            compact = (c1.weight.shape[2] == 1 and c1.stride == 1 and c1.groups == 1 and c1.weight.shape[1] >= 128 and c1.weight.shape[1] % 4 == 0
+                       and c1.weight.shape[0] % 32 == 0)
+            shortcut = hnn.batchnorm(tape, self.downsample[0]._run(tape, x, bn_stats=True, compact_dx=compact), self.downsample[1], lazy=fold)
         h = x
         for i in range(1, self.depth + 1):
             h = h1 if i == 1 else getattr(self, f"conv{i}")._run(tape, h, bn_stats=True)      # every conv here is followed by its BatchNorm

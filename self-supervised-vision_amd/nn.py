@@ -173,6 +173,8 @@ def _accum(existing, fresh):
     """Generic fallback when a producer cannot fuse the accumulation."""
     if existing is None:
         return fresh
+    if isinstance(existing, ops.StridedGrad):          # a compact stride-2 gradient met a consumer that cannot take it as its addend
+        existing = existing.materialize()
     return ops.add_(existing, fresh)
 
 
@@ -210,6 +212,7 @@ _FUSE_CLOSING = os.environ.get("SSV_NO_CLOSING_FUSION", "0") != "1"        # dia
 _CLOSING_HW = tuple(int(v) for v in os.environ.get("SSV_CLOSING_HW", "784,1000000000").split(","))
 _FUSE_SHORTCUT_GATE = os.environ.get("SSV_NO_SHORTCUT_GATE", "0") != "1"   # diagnostic switch: the projection shortcut's BatchNorm backward reduces in its own pass
 _FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
+_COMPACT_S2_DGRAD = os.environ.get("SSV_NO_COMPACT_S2_DGRAD", "0") != "1"        # diagnostic switch: the stride-2 shortcut's data gradient at full resolution
 
 
 class LazyAct:
@@ -263,8 +266,11 @@ def _tensor(x):
     return x.tensor() if isinstance(x, LazySum) else x
 
 
-def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
-    """``bn_stats``: the caller normalises the output next - let the conv epilogue produce the statistics partials (kept on the
+def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=False):
+    """``compact_dx`` (a 1x1 / stride-2 projection shortcut whose input's other consumer is a wide 1x1 conv1): when this is the FIRST contribution
+    to the input's gradient it is handed on compact (ops.StridedGrad: one dense GEMM on the subsampled grid) and conv1's data gradient adds it
+    in its epilogue - the full-resolution tensor of three quarters zeros is never written nor re-read.
+    ``bn_stats``: the caller normalises the output next - let the conv epilogue produce the statistics partials (kept on the
     output tensor as ``_bn_partials`` for `batchnorm`), which saves BatchNorm's own pass over the conv output.
     ``x`` may be a LazyAct (conv -> BN -> ReLU output that was never written): the kernels then apply it while staging."""
     lazy = x if isinstance(x, LazyAct) else None
@@ -311,6 +317,9 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False):
             if not need_dx:
                 return (None,)
             ex = existing[0]
+            if (compact_dx and _COMPACT_S2_DGRAD and _FUSE_BN_BWD and ex is None and not tape.last[0] and stride == 2 and pad == 0
+                    and weight.shape[2] == 1 and weight.shape[3] == 1 and not isinstance(dy, ops.LazyGrad)):
+                return (ops.compact_s2_dgrad(dy, weight, src.shape),)
             # x is the output of a BatchNorm + ReLU and nothing else will add to its gradient: gate + reduce in this epilogue
             gate = getattr(x, "_bn_gate", None) if (tape.last[0] and _FUSE_BN_BWD) else None
             dx = ops.conv2d_dgrad(dy, weight, src.shape, stride, pad, addend=ex, out=ex, gate=gate)
@@ -807,12 +816,12 @@ class HipConv2d(HipModule):
             return False
         return _FUSE_BN_APPLY and _FUSE_BN_STATS and ops.can_fuse_conv_input(self.weight.shape[1] * self.groups, self.weight.shape[0], self.groups)
 
-    def _run(self, tape, x, bn_stats=False):
+    def _run(self, tape, x, bn_stats=False, compact_dx=False):
         if self.groups > 1:
             return grouped_conv(tape, x, self.weight, self.groups, self.stride, self.pad)
         if self.weight.shape[1] == 3 and (tape is None or not tape.needs_grad(x)) and _PAD_STEM:
             return stem_conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats)
-        return conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats)
+        return conv(tape, x, self.weight, self.stride, self.pad, bn_stats=bn_stats, compact_dx=compact_dx)
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)

@@ -217,6 +217,34 @@ class LazyGrad:
         return self.g.shape
 
 
+class StridedGrad:
+    """The data gradient of a 1x1 / stride-2 convolution (the projection shortcut of a stage entry, networks/resnet.py:131-135), COMPACT: ``t``
+    [N, ceil(H/2), ceil(W/2), C] holds the gradient of the input pixels with even (h, w); every other pixel's is zero and is not stored.  The
+    unit input's other contribution (conv1's data gradient) takes it as its addend (ssv_conv2d_fwd_*_s2add); `materialize` is the fallback."""
+    __slots__ = ("t", "full_shape")
+
+    def __init__(self, t, full_shape):
+        self.t, self.full_shape = t, tuple(full_shape)
+
+    @property
+    def shape(self):
+        return self.full_shape
+
+    def materialize(self):
+        full = fill_(torch.empty(self.full_shape, dtype=torch.float32, device=self.t.device), 0.0)
+        full[:, ::2, ::2, :].copy_(self.t)            # rare path (a consumer that cannot take the compact form): torch's strided copy
+        return full
+
+
+def compact_s2_dgrad(dy, w, x_shape):
+    """dx of a 1x1 / stride-2 / unpadded convolution on the subsampled grid: one dense GEMM, as a StridedGrad."""
+    n, h, w_, c = x_shape
+    ho, wo = dy.shape[1], dy.shape[2]
+    if (ho, wo) != ((h + 1) // 2, (w_ + 1) // 2):
+        raise _lib.SsvError("compact_s2_dgrad: output grid does not match a 1x1 / stride-2 convolution")
+    return StridedGrad(conv2d_dgrad(dy, w, (n, ho, wo, c), 1, 0), x_shape)
+
+
 def can_lazy_dy(w_shape, stride, pad):
     """Can the weight and data gradient of this convolution take their dY operand as a LazyGrad?"""
     k, c, r, s_ = w_shape
@@ -249,6 +277,17 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     lazy = dy if isinstance(dy, LazyGrad) else None
     if lazy is not None:
         dy = lazy.g
+    compact = addend if isinstance(addend, StridedGrad) else None
+    if compact is not None:
+        _, wsh = _ohwi(w)
+        fits = (gate is not None and gate.mask is not None and stride == 1 and wsh[2] == 1 and wsh[3] == 1 and pad == 0 and wsh[1] >= 128
+                and wsh[0] % 32 == 0 and tuple(gate.x.shape) == tuple(x_shape) and dy[0].numel() * dy.shape[0] < _MAX_ELEMS
+                and x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] < _MAX_ELEMS)
+        if not fits:
+            addend, compact = compact.materialize(), None
+            out = addend
+        else:
+            addend, out = compact.t, None
     _lib._dev(dy, w, addend)
     w, wshape = _ohwi(w)
     k, c, r, s_ = wshape
@@ -277,7 +316,17 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
             d = conv_desc(dyc.shape, (c, k, r, s_), 1, r - 1 - pad)
             if (d.Ho, d.Wo) != (x_shape[1], x_shape[2]):
                 raise _lib.SsvError("conv2d_dgrad: input shape does not match the stride-1 geometry")
-            if lazy is not None:
+            if compact is not None:         # one chunk (checked above); the compact stride-2 addend rides on the byte-mask gate epilogues
+                h2, w2 = compact.t.shape[1], compact.t.shape[2]
+                groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))
+                st, part = _gate_struct(gate, groups, c, dy, second)
+                parts.append(part)
+                if lazy is not None:
+                    dyin = _dyin_struct(lazy, n0, n1)
+                    call("ssv_conv2d_fwd_dyin_s2add", C.byref(d), ptr(dyc), C.byref(dyin), ptr(wt), ptr(compact.t), h2, w2, ptr(dxc), C.byref(st), stream())
+                else:
+                    call("ssv_conv2d_fwd_gated_s2add", C.byref(d), ptr(dyc), ptr(wt), ptr(compact.t), h2, w2, ptr(dxc), C.byref(st), stream())
+            elif lazy is not None:
                 st = None
                 if gate is not None:
                     groups = int(lib.ssv_conv2d_fwd_gate_groups(C.byref(d)))

@@ -611,3 +611,47 @@ def test_projection_shortcut_backward_without_its_reduction_pass_matches_the_two
             continue
         worst = max(worst, float((a - r).norm() / r.norm()))
     assert 0.0 < worst < 2e-5, f"worst per-tensor gradient difference {worst:.2e} (0 = the fused path did not run)"
+
+
+@pytest.mark.parametrize("size,b", [(64, 6), (96, 3), (70, 2)])
+def test_compact_stride2_shortcut_gradient_matches_the_full_resolution_form(dev, size, b):
+    """The data gradient of a stage entry's 1x1 / stride-2 projection shortcut (networks/resnet.py:131-135) stays compact - one dense GEMM on the
+    subsampled grid (ops.StridedGrad) - and conv1's data gradient, the last contribution to the unit input's gradient, adds it in its gate
+    epilogue at the pixels with even (h, w) (ssv_conv2d_fwd_gated_s2add / _dyin_s2add).  Against the full-resolution form (the parity-class
+    kernel writing three quarters zeros, read back as a dense addend): forward untouched, every gradient equal to rounding; odd map sizes
+    (35 -> 18, 9 -> 5) included."""
+    from ssv_amd import nn as hnn, ops
+    a1, a2 = seeded_randn(2100, b, 3, size, size), seeded_randn(2101, b, 3, size, size)
+    outs, calls = [], []
+    inner = ops.compact_s2_dgrad
+    prev_hw, hnn._BN_DY_MIN_HW = hnn._BN_DY_MIN_HW, 0            # small inputs: the dy_in form of conv1's data gradient too
+    try:
+        for compact in (True, False):
+            prev, hnn._COMPACT_S2_DGRAD = hnn._COMPACT_S2_DGRAD, compact
+            calls.append(0)
+
+            def counted(*a, **k):
+                calls[-1] += 1
+                return inner(*a, **k)
+            ops.compact_s2_dgrad = counted
+            try:
+                m = _Step(dev, "resnet50", False)
+                loss, z1, z2 = m.step(a1, a2)
+                torch.cuda.synchronize()
+                outs.append((loss, z1.cpu(), m, m.grads.cpu().clone()))
+            finally:
+                hnn._COMPACT_S2_DGRAD = prev
+                ops.compact_s2_dgrad = inner
+    finally:
+        hnn._BN_DY_MIN_HW = prev_hw
+    assert calls == [6, 0], calls                                 # layer2 / layer3 / layer4 entries, two views
+    (lf, zf, m, gf), (lu, zu, _, gu) = outs
+    assert lf == lu and torch.equal(zf, zu)
+    worst = 0.0
+    for p, off in zip(m.params(), m.optim.arena.offsets):
+        a, r = gf[off:off + p.numel()].double(), gu[off:off + p.numel()].double()
+        if float(r.norm()) < 1e-5:
+            assert float(a.abs().max()) < 1e-5
+            continue
+        worst = max(worst, float((a - r).norm() / r.norm()))
+    assert worst < 2e-6, f"worst per-tensor gradient difference {worst:.2e}"
