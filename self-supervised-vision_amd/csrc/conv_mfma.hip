@@ -1682,6 +1682,10 @@ extern "C" int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t 
   ConvKP p = make_kp(&d);
   p.bs_a = rows * C; p.bs_b = (long long)K * C; p.bs_o = rows * K;
   const bool wide = K >= 128;
+  // (Tried: ONE resident round of workgroups, each walking a contiguous run of (tile, batch) units as one continuous k-stream, so that a unit's
+  // epilogue runs under the next unit's first loads - the products alone got 10-12 % faster (0.533 -> 0.478 ms at 14x14 x 256), the two-stream
+  // training step did not move (231.8 vs 231.7 ms, r03 e2): the other view's kernels already fill those bubbles, and a persistent grid shuts
+  // them out.  Not kept.)
   const dim3 grid((unsigned)(wide ? cdiv(p.M, 128) * cdiv(K, 128) : cdiv(p.M, 256) * cdiv(K, 64)), (unsigned)batch);
   if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false>), grid, dim3(256), 0, s, p, a, w, (const float*)nullptr, (const float*)nullptr, y);
   else      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, false, false, false, false>), grid, dim3(256), 0, s, p, a, w, (const float*)nullptr, (const float*)nullptr, y);
