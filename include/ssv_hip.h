@@ -152,6 +152,14 @@ size_t ssv_conv2d_wgrad_workspace_bytes(const ssv_conv_desc* d);
 int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dw,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the 3-channel image stem on the unpadded image (networks/resnet.py:96-99,147: conv7x7/2 or conv3x3/1 on [B,3,H,W]) -------------------------
+ * Row-taps form: for one filter row the S taps x 3 channels of an output pixel are 3 S contiguous floats of the NHWC image row, so the
+ * contraction runs over R rows of 24 floats (3 S <= 24 real ones, zero weights behind them): 168 columns for the 7x7 stem's 147, no channel
+ * padding of the images.  wrows / dwrows [K][R][24]: ssv_pad_channels of the OHWI filter viewed as [K*R][3 S] (and back for the gradient). */
+int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x /*[N][H][W][3]*/, const float* wrows, float* y, float* pmean, float* pm2, void* stream);
+size_t ssv_stem_conv_wgrad_workspace_bytes(const ssv_conv_desc* d);
+int ssv_stem_conv_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dwrows, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Winograd F(2x2, 3x3) for stride-1 / padding-1 3x3 convolutions (csrc/winograd.hip) -------------------------------------
  * replaces nn.Conv2d(k=3, s=1, p=1) forward / data gradient / weight gradient of networks/resnet.py:7-10,56-58 on the deep stages with
  * 2.25x fewer multiplies, all in fp32:  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  per 2x2 output tile.

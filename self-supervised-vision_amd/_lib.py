@@ -72,6 +72,9 @@ SIGNATURES = {
     "ssv_conv2d_wgrad_dyin": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnDyin), _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_stem_conv_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_stem_conv_wgrad_workspace_bytes": (_sz, [_cd]),
+    "ssv_stem_conv_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_wino_tiles": (_i64, [_i32, _i32, _i32]),
     "ssv_wino_groups": (_i64, [_i32, _i32, _i32]),
     "ssv_wino_stats_rows_per_group": (_i32, [_i32, _i32, _i32]),

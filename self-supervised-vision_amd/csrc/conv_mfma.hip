@@ -103,6 +103,32 @@ __device__ __forceinline__ f32x4 bload4(rsrc_t rs, int voff_bytes, int soff_byte
   return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0));
 }
 
+// 16-byte loads at 4-byte-aligned offsets (the row-taps stem: windows of 3 S floats start at any pixel).  A window may straddle the START or the
+// END of the tensor - the first / last pixels of the whole batch - where a buffer load that is partly out of range returns zeros for ALL of its
+// dwords.  straddle_off() moves such a load to the nearest offset that is wholly inside and reports how many floats the wanted window lies
+// from it (rot in -3 .. 3); straddle_fix() shifts the elements accordingly (elements from outside the tensor become 0).  rot != 0 is rare
+// (a handful of lanes of the first and last workgroup), so callers branch on it.
+__device__ __forceinline__ int straddle_off(int off, int bytes, int& rot) {
+  rot = 0;
+  if (off == OOB_OFF) return OOB_OFF;
+  if (off <= -16 || off >= bytes) return OOB_OFF;                  // wholly outside
+  const int c = off < 0 ? 0 : (off > bytes - 16 ? bytes - 16 : off);
+  rot = (off - c) >> 2;                                            // off and c are multiples of 4
+  return c;
+}
+__device__ __forceinline__ f32x4 straddle_fix(f32x4 v, int rot) {
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int sidx = e + rot;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t = sidx == q ? v[q] : t;
+    o[e] = t;
+  }
+  return o;
+}
+
 template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const float* __restrict__ Bs,
                                           int wr0, int wc0, int lane, f32x16 (&acc)[TM][TN]) {
@@ -328,7 +354,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
-  const bool cok = gcol < ncols;
+  const bool cok = gcol < ncols && r_in < RPI;          // TN = 3 (C4 = 24 lanes per row): the last 16 lanes of a wave have no row in a pass
   const unsigned bytes = (unsigned)(out_elems * 4);
   const rsrc_t r_out = make_rsrc(out, bytes);
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
@@ -466,7 +492,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, bool C4 = false, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false>
 // Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
@@ -477,9 +503,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;                   // ROWK row stride: 16-lane b128 read groups hit 16 distinct 16-B slots
   constexpr int STAGE = (BM + BN) * LDT;
-  static_assert(!XF || (VEC && !C4), "the fused-input variant is the float4 path");
+  static_assert(!XF || (VEC && C4 == 0), "the fused-input variant is the float4 path");
   constexpr bool DYF = OPM == 1, SUM = OPM == 2;
-  static_assert(OPM == 0 || (VEC && !C4 && !XF), "the formed-on-load operands are the float4 path");
+  static_assert(OPM == 0 || (VEC && C4 == 0 && !XF), "the formed-on-load operands are the float4 path");
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);     // the vectorised epilogue's staging area (one 32-row slab per wave)
   constexpr int SMEM = (VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE;
   __shared__ __attribute__((aligned(16))) float smem[SMEM + SSV_EXP_LDS_PAD];
@@ -497,7 +523,78 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
-  if constexpr (VEC && C4) {
+  if constexpr (VEC && C4 == 2) {
+    // ---- the image stem on the UNPADDED 3-channel input: for one filter row r the S taps x 3 channels of an output pixel are 3 S CONTIGUOUS
+    //      floats of the image row (NHWC), so a k-tile = one filter row = 3 S (21) floats padded to BK (24) with zero WEIGHTS: the contraction
+    //      is 7 x 24 = 168 columns for 147 real ones (the 4-channel form: 224 for 147, plus the padding pass over the images).  One thread stages
+    //      one output row: six 16-byte loads at a 12-byte-aligned address; pixels left / right of the image row (real floats of the neighbouring
+    //      row sit there) are zeroed per element, rows above / below and rows past M by the out-of-range offset. ----
+    static_assert(BK == 24 && BM == 256, "one staged output row per thread, six float4 per row");
+    constexpr int CHN = BK / 4;
+    constexpr int BF = (BN * CHN + 255) / 256;                     // weight float4s per thread
+    const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * 12u);
+    const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.R * BK * 4u);
+    int hi0, rowbase;
+    unsigned wmask = 0;                                            // bit px: tap column px of this output pixel lies inside the image row
+    {
+      const int m = m0 + tid;
+      const bool ok = m < p.M;
+      const uint32_t mm = ok ? (uint32_t)m : 0u;
+      const uint32_t n = fdiv(mm, p.dHoWo);
+      const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
+      const uint32_t ho = fdiv(rem, p.dWo);
+      const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+      hi0 = ok ? (int)ho * p.stride - p.pad : -(1 << 20);
+      const int wi0 = (int)wo * p.stride - p.pad;
+      rowbase = ok ? (((int)n * p.H + hi0) * p.W + wi0) * 12 : 0;
+#pragma unroll
+      for (int px = 0; px < 8; ++px) wmask |= (unsigned)((px < p.S) & ((unsigned)(wi0 + px) < (unsigned)p.W)) << px;
+    }
+    int boff[BF];
+#pragma unroll
+    for (int i = 0; i < BF; ++i) {
+      const int f = tid + 256 * i, kf = f / CHN, ch = f - kf * CHN;
+      boff[i] = (f < BN * CHN && n0 + kf < p.K) ? ((n0 + kf) * p.R * BK + ch * 4) * 4 : OOB_OFF;
+    }
+    int lr = 0;
+    f32x4 ra[CHN], rb[BF];
+    const int xbytes = p.N * p.H * p.W * 12;
+    int rots = 0;                                                  // 4 bits per float4: rot + 8 where the load was moved (straddle_off), else 0
+    auto load_tile = [&]() {
+      const bool hv = (unsigned)(hi0 + lr) < (unsigned)p.H;        // filter rows past R read zero weights (offset past the weight tensor's rows is OOB)
+      const int base = rowbase + lr * p.W * 12;
+      rots = 0;
+#pragma unroll
+      for (int j = 0; j < CHN; ++j) {
+        int rot;
+        ra[j] = bload4(rx, straddle_off((hv && lr < p.R) ? base + j * 16 : OOB_OFF, xbytes, rot), 0);
+        rots |= (rot != 0 ? rot + 8 : 0) << (4 * j);
+      }
+#pragma unroll
+      for (int i = 0; i < BF; ++i) rb[i] = bload4(rw, (lr < p.R) ? boff[i] : OOB_OFF, lr * BK * 4);
+      lr += 1;
+    };
+    auto xform_tile = [&]() {
+      if (rots != 0) {                                             // the first / last pixels of the whole batch only
+#pragma unroll
+        for (int j = 0; j < CHN; ++j) { const int q = (rots >> (4 * j)) & 15; if (q) ra[j] = straddle_fix(ra[j], q - 8); }
+      }
+#pragma unroll
+      for (int j = 0; j < CHN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[j][e] = ((wmask >> ((4 * j + e) / 3)) & 1u) ? ra[j][e] : 0.f;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < CHN; ++j) *reinterpret_cast<f32x4*>(&As[tid * LDT + 4 * j]) = ra[j];
+#pragma unroll
+      for (int i = 0; i < BF; ++i) {
+        const int f = tid + 256 * i, kf = f / CHN, ch = f - kf * CHN;
+        if (f < BN * CHN) *reinterpret_cast<f32x4*>(&Bs[kf * LDT + ch * 4]) = rb[i];
+      }
+    };
+    k_loop<TM, TN, true, true, LDT, LDT, BK, CHN + BF>(p.R, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
+  } else if constexpr (VEC && C4 == 1) {
     // ---- C == 4 (the image stem with its 3 channels padded to 4): one 16-byte load = one filter TAP of one pixel, a k-tile = BK/4
     //      consecutive taps.  Lane group tl owns tap kt*CH + tl of the tile: (r, s) by one fast division, bounds per staged row. ----
     constexpr int CH = BK / 4, RPP = 256 / CH;
@@ -977,7 +1074,9 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // =============================================================================================
 // wgrad: partial[split][K][RSC] over a chunk of the N*Ho*Wo contraction
 // =============================================================================================
-// GATHER: 0 generic (fastdiv per staged row and tile), 1 LIN (1x1 / stride 1 / no padding: X row m is x + m*C),
+// GATHER: 3 ROWS (the 3-channel image stem, unpadded: column j = 24 r + e is float e of the 3 S contiguous floats that filter row r sees at an output pixel;
+//           the output is dW' [K][R][24] with the columns e >= 3 S zero - see conv_fwd_k's row-taps loader),
+//         0 generic (fastdiv per staged row and tile), 1 LIN (1x1 / stride 1 / no padding: X row m is x + m*C),
 //         2 S1 (stride 1, any filter/padding: X row of tap (r,s) is x + (m + (r-pad)*W + (s-pad))*C, validity from
 //           (ho, wo) kept incrementally per staged row - no division in the loop)
 // XF: x is the producer's RAW conv output; the X operand is relu(x * xf_scale[c] + xf_shift[c]) (the activation the forward never
@@ -996,7 +1095,8 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   float* Bs = smem + BK * BM;     // [BK][BN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr0 = (wave / WGN) * (BM / WGM), wc0 = (wave % WGN) * (BN / WGN);
-  const int JT = (p.RSC + BN - 1) / BN;
+  const int NCOL = GATHER == 3 ? p.R * 24 : p.RSC;      // columns of the weight-gradient matrix this launch produces
+  const int JT = (NCOL + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);     // tiles of one row-slab are neighbours: they share dY / X rows in L2
   const int split = bid / tiles, tile = bid - split * tiles;
   const int it = tile / JT, jt = tile - it * JT;
@@ -1013,7 +1113,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   const int acol = (tid % ACV) * 4, arow = tid / ACV;
   const bool acok = i0 + acol < p.K;
   // B = gathered X (float4 along input channels when C % 4 == 0, scalar otherwise)
-  constexpr int BCV = VECB ? BN / 4 : BN, BRP = 256 / BCV, BP = BK / BRP;
+  constexpr int BCV = VECB ? BN / 4 : BN, BRP = GATHER == 3 ? 1 : 256 / BCV, BP = GATHER == 3 ? (BK * BCV + 255) / 256 : BK / BRP;
   const int bcol = VECB ? (tid % BCV) * 4 : (tid % BCV), brow = tid / BCV;
   const int j = j0 + bcol;
   const bool jok = j < p.RSC;
@@ -1060,10 +1160,49 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
       s1_base[i] = ((brow + BRP * i + (rj - p.pad) * p.W + (sj - p.pad)) * p.C + cj) * 4;
     }
   }
+  // ROWS state: float4 f = tid + 256 i of the [BK][BN] tile: staged row f / BCV, column 4 (f % BCV) = 24 r + e0
+  int rw_row[GATHER == 3 ? BP : 1], rw_r[GATHER == 3 ? BP : 1], rw_e0[GATHER == 3 ? BP : 1];
+  unsigned rw_mask[GATHER == 3 ? BP : 1];
+  int rw_rot[GATHER == 3 ? BP : 1];
+  if constexpr (GATHER == 3) {
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int f = tid + 256 * i, col = j0 + (f % BCV) * 4;
+      rw_row[i] = f / BCV;
+      rw_r[i] = col / 24;
+      rw_e0[i] = col - rw_r[i] * 24;
+      if (f >= BK * BCV || col >= NCOL) rw_r[i] = -1;            // not a column / row of this tile
+      rw_mask[i] = 0;
+      rw_rot[i] = 0;
+    }
+  }
   auto load_tile = [&]() {
     const int soff_a = mcur * p.K * 4;
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[i] = bload4(rdy, avoff[i], soff_a);
+    if constexpr (GATHER == 3) {
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const int m = mcur + rw_row[i];
+        bool ok = rw_r[i] >= 0 && m < p.M;
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t n = fdiv(mm, p.dHoWo);
+        const uint32_t rem = mm - n * (uint32_t)(p.Ho * p.Wo);
+        const uint32_t ho = fdiv(rem, p.dWo);
+        const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+        const int hi = (int)ho * p.stride - p.pad + rw_r[i], wi0 = (int)wo * p.stride - p.pad;
+        ok = ok & ((unsigned)hi < (unsigned)p.H);
+        int rot;
+        rbv[i] = bload4(rx, straddle_off(ok ? (((int)n * p.H + hi) * p.W + wi0) * 12 + rw_e0[i] * 4 : OOB_OFF, p.N * p.H * p.W * 12, rot), 0);
+        rw_rot[i] = rot;
+        unsigned mk = 0;                                          // element e is pixel (e0 + e) / 3 of the window: inside the image row and a real tap?
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int px = (rw_e0[i] + e) / 3; mk |= (unsigned)((px < p.S) & ((unsigned)(wi0 + px) < (unsigned)p.W)) << e; }
+        rw_mask[i] = mk;
+      }
+      mcur += BK;
+      return;
+    }
     if constexpr (DYF) {
       a_ok = 0;
 #pragma unroll
@@ -1117,6 +1256,14 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
     mcur += BK;
   };
   auto xform_tile = [&]() {
+    if constexpr (GATHER == 3) {
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        if (rw_rot[i] != 0) rbv[i] = straddle_fix(rbv[i], rw_rot[i]);       // the first / last pixels of the whole batch only
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rbv[i][e] = ((rw_mask[i] >> e) & 1u) ? rbv[i][e] : 0.f;
+      }
+    }
     if constexpr (DYF) {         // rows past M must contribute nothing (g and x read as zeros there, the affine form would not)
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
@@ -1141,17 +1288,20 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
+      if constexpr (GATHER == 3) {
+        const int f = tid + 256 * i;
+        if (f < BK * BCV) *reinterpret_cast<f32x4*>(&Bs[(f / BCV) * BN + (f % BCV) * 4]) = rbv[i];
+      } else if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
       else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
   k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
 
-  float* out = partial + (size_t)split * p.K * p.RSC;
-  if ((p.RSC & 3) == 0) {      // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
+  float* out = partial + (size_t)split * p.K * NCOL;
+  if ((NCOL & 3) == 0) {       // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
     const int rbase = i0 + wr0;
-    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, p.RSC, nullptr, nullptr, out, (long long)p.K * p.RSC,
-                         [&](int r) -> long long { const int row = rbase + r; return row < p.K ? (long long)row * p.RSC : -1; });
+    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, NCOL, nullptr, nullptr, out, (long long)p.K * NCOL,
+                         [&](int r) -> long long { const int row = rbase + r; return row < p.K ? (long long)row * NCOL : -1; });
     return;
   }
   const int l31 = lane & 31, h = lane >> 5;
@@ -1668,6 +1818,67 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   return SSV_OK;
 }
 }  // namespace
+
+// ---- the 3-channel image stem on the UNPADDED image (networks/resnet.py:96-99, 147): row-taps form ------------------------------------------
+// x [N][H][W][3]; wrows [K][R][24] = the filter's rows, 3 S floats each ((s, c) order = OHWI memory) zero-padded to 24; y [N][Ho][Wo][K];
+// optional statistics partials as ssv_conv2d_fwd_stats.  3 S <= 24, K % 4 == 0.
+extern "C" int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x, const float* wrows, float* y, float* pmean, float* pm2, void* stream) {
+  if (int rc = check_desc(d, "ssv_stem_conv_fwd")) return rc;
+  SSV_REQUIRE(x && wrows && y && (pmean == nullptr) == (pm2 == nullptr), "ssv_stem_conv_fwd: bad pointers");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)wrows | (uintptr_t)y | (uintptr_t)pmean | (uintptr_t)pm2) & 15) == 0, "ssv_stem_conv_fwd: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C == 3 && d->S * 3 <= 24 && d->S <= 8 && d->K % 4 == 0, "ssv_stem_conv_fwd: a 3-channel input, at most 8 taps per filter row, K %% 4 == 0 (got C=%d S=%d K=%d)", d->C, d->S, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.aux_out = pmean; p.aux_out2 = pm2;
+  const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
+  if (pmean) hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 24, true, false, true, 2>), dim3(grid), dim3(256), 0, s, p, x, wrows, (const float*)nullptr, (const float*)nullptr, y);
+  else       hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 24, true, false, false, 2>), dim3(grid), dim3(256), 0, s, p, x, wrows, (const float*)nullptr, (const float*)nullptr, y);
+  SSV_CHECK_LAUNCH("ssv_stem_conv_fwd");
+  return SSV_OK;
+}
+
+namespace {
+struct StemWgradPlan { int tiles, nsplit, chunk; };
+StemWgradPlan plan_stem_wgrad(const ssv_conv_desc* d) {
+  StemWgradPlan w;
+  const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+  w.tiles = cdiv(d->K, 64) * cdiv(d->R * 24, 192);
+  int64_t ns = 512 / w.tiles;                                    // this variant holds 207 registers: 2 workgroups per CU, one resident round
+  const int64_t max_by_rows = cdiv64(M, 256);
+  if (ns > max_by_rows) ns = max_by_rows;
+  if (ns < 1) ns = 1;
+  const int64_t chunk = cdiv64(cdiv64(M, ns), 32) * 32;
+  w.chunk = (int)chunk;
+  w.nsplit = (int)cdiv64(M, chunk);
+  return w;
+}
+}  // namespace
+
+extern "C" size_t ssv_stem_conv_wgrad_workspace_bytes(const ssv_conv_desc* d) {
+  if (!d || d->K <= 0 || d->R <= 0) return 0;
+  return (size_t)plan_stem_wgrad(d).nsplit * d->K * d->R * 24 * sizeof(float);
+}
+
+// dwrows [K][R][24] = weight gradient in the row-taps layout (columns >= 3 S are zero); overwritten, not accumulated
+extern "C" int ssv_stem_conv_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dwrows, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_desc(d, "ssv_stem_conv_wgrad")) return rc;
+  SSV_REQUIRE(x && dy && dwrows && ws && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dwrows | (uintptr_t)ws) & 15) == 0, "ssv_stem_conv_wgrad: null or unaligned pointer");
+  SSV_REQUIRE(d->C == 3 && d->S * 3 <= 24 && d->S <= 8 && d->K % 4 == 0, "ssv_stem_conv_wgrad: a 3-channel input, at most 8 taps per filter row, K %% 4 == 0 (got C=%d S=%d K=%d)", d->C, d->S, d->K);
+  const StemWgradPlan wp = plan_stem_wgrad(d);
+  const size_t need = (size_t)wp.nsplit * d->K * d->R * 24 * sizeof(float);
+  if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_stem_conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_WGRAD, s);
+  const ConvKP p = make_kp(d);
+  float* part = (float*)ws;
+  hipLaunchKernelGGL((conv_wgrad_k<64, 192, 2, 2, 32, true, 3>), dim3((unsigned)(wp.tiles * wp.nsplit)), dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles);
+  SSV_CHECK_LAUNCH("ssv_stem_conv_wgrad(partial)");
+  const int64_t n = (int64_t)d->K * d->R * 24;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dwrows, 0);
+  SSV_CHECK_LAUNCH("ssv_stem_conv_wgrad(reduce)");
+  return SSV_OK;
+}
 
 // ---- batched GEMMs (the 16 transformed-domain products of a Winograd convolution, csrc/winograd.hip) -------------------------------------
 // y[b] [rows][K] = a[b] [rows][C] . w[b]^T [K][C] for b < batch, ONE launch (blockIdx.y = b) of the forward kernel's float4 path

@@ -328,14 +328,36 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
     return y
 
 
+_ROW_STEM = os.environ.get("SSV_NO_ROW_STEM", "0") != "1"          # diagnostic switch: the 3-channel stem with both operands padded to 4 channels
+
+
 def stem_conv(tape, x, weight, stride, pad, bn_stats=False):
-    """The 3-channel image convolution with both operands padded to 4 channels: the kernels then move one filter tap per 16-byte
-    load (forward) / take their float4 path (wgrad) instead of gathering scalars.  Exact: the fourth channel is zero on both
-    sides.  No input gradient (images).  ``bn_stats``: the epilogue leaves the BatchNorm statistics partials, as in `conv`."""
+    """The 3-channel image convolution (networks/resnet.py:96-99, 147).  No input gradient (images).  ``bn_stats``: the epilogue leaves the
+    BatchNorm statistics partials, as in `conv`.
+
+    Row-taps form (default): the image stays unpadded; for one filter row the S taps x 3 channels of an output pixel are 3 S contiguous floats
+    of the NHWC image row, so the contraction runs over R rows of 24 floats (the filter's rows zero-padded from 3 S) - 168 columns for the 7x7
+    stem's 147 real ones.  (Round 1-2 form, `SSV_NO_ROW_STEM=1`: both operands zero-padded to 4 channels, one filter tap per 16-byte load:
+    224 columns, and a padding pass over the images.)"""
     k, c, r, s_ = weight.shape
+    want = bn_stats and _FUSE_BN_STATS
+    if _ROW_STEM and ops.can_row_stem(weight.shape):
+        wrows = ops.stem_weight_rows(weight)
+        y, part = ops.stem_conv_fwd(x, wrows, tuple(weight.shape), stride, pad, want_stats=want)
+        if part is not None:
+            y._bn_partials = part
+        if tape is not None:
+            slot = tape.slot
+
+            def bwd_rows(dy, existing):
+                dwr = ops.stem_conv_wgrad(x, dy, tuple(weight.shape), stride, pad)                       # [K*R][24]
+                ops.unpad_channels(dwr, grad_of(weight, slot).permute(0, 2, 3, 1).reshape(k * r, s_ * c), accumulate=True)
+                return (None,)
+            tape.record((x,), y, bwd_rows)
+        return y
     xp = ops.pad_channels(x, 4)                                                  # [N,H,W,4]
     wp = ops.pad_channels(weight.permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)     # OHWI [K,R,S,4], seen as [K,4,R,S] channels_last
-    fused = ops.conv2d_fwd_stats(xp, wp, stride, pad) if (bn_stats and _FUSE_BN_STATS) else None
+    fused = ops.conv2d_fwd_stats(xp, wp, stride, pad) if want else None
     if fused is not None:
         y = fused[0]
         y._bn_partials = tuple(fused[1:])

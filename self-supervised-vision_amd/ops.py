@@ -1016,3 +1016,47 @@ def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     call("ssv_gemm_batched_wgrad", 16, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
     call("ssv_wino_filter_grad", k, c, ptr(du), ptr(dw), int(accumulate), stream())
     return dw
+
+
+# ------------------------------------------------------------------------------------------- the 3-channel image stem, row-taps form
+def can_row_stem(w_shape):
+    k, c, r, s_ = w_shape
+    return c == 3 and 3 * s_ <= 24 and s_ <= 8 and k % 4 == 0
+
+
+def stem_weight_rows(w):
+    """[K,3,R,S] filter (OHWI memory) -> [K*R][24]: its rows of 3 S floats, (s, c) order, zero-padded to 24."""
+    w, (k, c, r, s_) = _ohwi(w)
+    return pad_channels(w.permute(0, 2, 3, 1).reshape(k * r, s_ * c), 24)
+
+
+def stem_conv_fwd(x, wrows, w_shape, stride, pad, want_stats=False):
+    """y = conv(x, w) for a 3-channel NHWC image batch, x UNPADDED: returns (y, (pmean, pm2) | None)."""
+    _lib._dev(x, wrows)
+    d = conv_desc(x.shape, w_shape, stride, pad)
+    y = _empty((d.N, d.Ho, d.Wo, d.K), x)
+    lib = _lib.load()
+    part = _empty((2, int(lib.ssv_conv2d_fwd_stats_groups(C.byref(d))), d.K), x) if want_stats else None
+    g0 = 0
+    for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo if want_stats else None):
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), w_shape, stride, pad)
+        gc = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(dc)))
+        call("ssv_stem_conv_fwd", C.byref(dc), ptr(x[n0:n1]), ptr(wrows), ptr(y[n0:n1]),
+             ptr(part[0][g0:g0 + gc]) if want_stats else None, ptr(part[1][g0:g0 + gc]) if want_stats else None, stream())
+        g0 += gc
+    return y, (None if part is None else (part[0], part[1]))
+
+
+def stem_conv_wgrad(x, dy, w_shape, stride, pad):
+    """Weight gradient in the row-taps layout: [K*R][24] (columns >= 3 S are zero)."""
+    _lib._dev(x, dy)
+    k, c, r, s_ = w_shape
+    lib = _lib.load()
+    out = None
+    for n0, n1 in _batch_chunks(x.shape[0], (x[0].numel(), dy[0].numel())):
+        d = conv_desc(x[n0:n1].shape, w_shape, stride, pad)
+        ws = workspace.get(lib.ssv_stem_conv_wgrad_workspace_bytes(C.byref(d)), x.device)
+        dwr = torch.empty((k * r, 24), dtype=torch.float32, device=x.device)
+        call("ssv_stem_conv_wgrad", C.byref(d), ptr(x[n0:n1]), ptr(dy[n0:n1]), ptr(dwr), ptr(ws), ws.numel(), stream())
+        out = dwr if out is None else add_(out, dwr)
+    return out

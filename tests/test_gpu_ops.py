@@ -618,3 +618,36 @@ def test_conv_that_forms_and_writes_the_closing_activation_is_bitwise_bn_apply_t
     np.testing.assert_allclose(a.cpu().double().numpy(), ar.cpu().numpy(), rtol=1e-5, atol=1e-5)
     yr = torch.einsum("nhwc,kc->nhwk", ar, w.double().view(k, c))
     np.testing.assert_allclose(y.cpu().double().numpy(), yr.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,h,w_,k,r,stride,pad", [(3, 20, 20, 64, 7, 2, 3), (2, 9, 11, 64, 3, 1, 1), (2, 13, 7, 132, 7, 2, 3), (1, 7, 7, 16, 3, 1, 1), (5, 33, 31, 64, 7, 2, 3)])
+def test_stem_conv_in_the_row_taps_form_on_the_unpadded_image(dev, n, h, w_, k, r, stride, pad):
+    """ssv_stem_conv_fwd / ssv_stem_conv_wgrad: the 3-channel stem without channel padding - a k-tile is one filter row, 3 S contiguous floats of
+    the image row at a 12-byte-aligned address, left / right image borders masked per element - against torch fp64, with the statistics epilogue;
+    odd sizes, non-square images, ragged channel tiles (K = 132)."""
+    from ssv_amd import ops
+    x3 = seeded_randn(1, n, h, w_, 3)
+    w3 = seeded_randn(2, k, 3, r, r) * 0.2
+    xr, wr = x3.permute(0, 3, 1, 2).double(), w3.double().requires_grad_()
+    ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    dy = seeded_randn(3, *ref.permute(0, 2, 3, 1).shape)
+    ref.backward(dy.permute(0, 3, 1, 2).double())
+    wd = w3.contiguous(memory_format=torch.channels_last).to(dev)
+    assert ops.can_row_stem(tuple(wd.shape))
+    wrows = ops.stem_weight_rows(wd)
+    assert wrows.shape == (k * r, 24) and float(wrows[:, 3 * r:].abs().max()) == 0.0
+    y, part = ops.stem_conv_fwd(x3.to(dev), wrows, tuple(wd.shape), stride, pad, want_stats=True)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=2e-5)
+    y0, none = ops.stem_conv_fwd(x3.to(dev), wrows, tuple(wd.shape), stride, pad, want_stats=False)
+    assert none is None and torch.equal(y0, y)
+    m = y.numel() // k
+    y2 = y.view(m, k).cpu().double()
+    assert part[0].shape == ((m + 63) // 64, k)
+    for g in range(part[0].shape[0]):
+        blk = y2[64 * g:64 * g + 64]
+        np.testing.assert_allclose(part[0][g].cpu().numpy(), blk.mean(0).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(part[1][g].cpu().numpy(), ((blk - blk.mean(0)) ** 2).sum(0).numpy(), rtol=1e-3, atol=1e-4)
+    dwr = ops.stem_conv_wgrad(x3.to(dev), dy.to(dev), tuple(wd.shape), stride, pad)
+    assert dwr.shape == (k * r, 24) and float(dwr[:, 3 * r:].abs().max()) == 0.0            # the padding columns see zero operands
+    got = dwr[:, :3 * r].reshape(k, r, r, 3).permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.cpu().double().numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-4)

@@ -85,15 +85,15 @@ ONLY = [t for t in os.environ.get("SSV_BENCH_LAYERS", "").split(",") if t]
 for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     if ONLY and not any(t in name for t in ONLY):
         continue
-    if C == 3:
-        x = ops.pad_channels(torch.randn(B, H, H, 3, device=dev), 4)
-        w = ops.pad_channels((torch.randn(K, 3, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)
-        Cx = 4
+    if C == 3:                        # the image stem: row-taps form on the unpadded image (nn.stem_conv)
+        x = torch.randn(B, H, H, 3, device=dev)
+        w = (torch.randn(K, 3, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+        Cx = 3
     else:
         x = torch.randn(B, H, H, C, device=dev)
         w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
         Cx = C
-    y = ops.conv2d_fwd(x, w, s, p)
+    y = ops.stem_conv_fwd(x, ops.stem_weight_rows(w), tuple(w.shape), s, p)[0] if C == 3 else ops.conv2d_fwd(x, w, s, p)
     Ho = y.shape[1]
     m = B * Ho * Ho
     flop = 2.0 * y.numel() * C * R * R                        # algorithmic: the 3 real channels for the stem
@@ -106,7 +106,12 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     big = Ho * Ho >= 784
     dyl = ops.LazyGrad(dy, torch.randn_like(y), torch.randn(4, K, device=dev).contiguous()) if (big and C != 3 and ops.can_lazy_dy(w.shape, s, p)) else None
     sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= 784 and ops.can_form_closing_sum(w.shape, s, p)
-    if sum_in:
+    if C == 3:
+        fv = wv = "row-taps"
+        wrows = ops.stem_weight_rows(w)
+        t_f = timeit(lambda: ops.stem_conv_fwd(x, wrows, tuple(w.shape), s, p, want_stats=True))
+        t_w = timeit(lambda: ops.stem_conv_wgrad(x, dy, tuple(w.shape), s, p))
+    elif sum_in:
         fv = "stats+sum_in"
         res = torch.randn_like(x)
         t_f = timeit(lambda: ops.conv2d_fwd_sumin(x, res, aff[0], aff[1], None, w, want_mask=True))
