@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle (ATen / oneDNN) is pathologically slow with one thread per core of a 256-thread GPU box (320 s for a step that
+    takes 3.5 s on 32 threads): bound the intra-op pool for the whole session."""
+    import torch
+    torch.set_num_threads(min(torch.get_num_threads(), 48))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
