@@ -389,7 +389,7 @@ def main():
         comm = torch.tensor([hdist.comm_timing(False) / 2], device=device, dtype=torch.float64)
         dist.all_reduce(comm, op=dist.ReduceOp.MAX)
         sync = getattr(train_step.trainer.optim, "grad_sync", None)
-        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_gpu": 1,
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_gpu": max(1, dist.get_world_size() // max(1, torch.cuda.device_count())),
                      "ms_per_step_min_over_ranks": round(min(per_rank) / args.steps * 1e3, 3), "ms_per_step_max_over_ranks": round(max(per_rank) / args.steps * 1e3, 3),
                      "comm_ms_per_step": round(float(comm.item()), 3),
                      "comm_note": "device time between HIP events around every collective (embedding / LSE all-gathers, per-bucket gradient all-reduces on the "

@@ -28,6 +28,17 @@ def timeit(fn):
     return e0.elapsed_time(e1) / REP
 
 
+class direct:
+    """Inside: ops.* dispatch stays on the direct implicit-GEMM kernels (what the probe compares Winograd WITH)."""
+
+    def __enter__(self):
+        self.prev, ops.WINOGRAD = ops.WINOGRAD, False
+
+    def __exit__(self, *exc):
+        ops.WINOGRAD = self.prev
+        return False
+
+
 def rel(a, b):
     return float((a.double() - b).norm() / b.norm())
 
@@ -42,8 +53,9 @@ for name, H, Cc in (("p64.0.conv2", 56, 64), ("p128.1.conv2", 28, 128), ("p256.1
     flop = 2.0 * B * H * H * Cc * Cc * 9
     tf = lambda ms: flop / (ms * 1e-3) / 1e12
     # ---- forward (fused input BatchNorm + statistics epilogue, as the step launches it)
-    stats = H % 2 == 0
-    t_dir = timeit(lambda: ops.conv2d_fwd_fused(x, w, 1, 1, in_affine=aff, want_stats=True))
+    stats = int(_lib.load().ssv_wino_stats_rows_per_group(B, H, H)) > 0
+    with direct():
+        t_dir = timeit(lambda: ops.conv2d_fwd_fused(x, w, 1, 1, in_affine=aff, want_stats=True))
     t_win = timeit(lambda: ops.wino_conv2d_fwd(x, w, in_affine=aff, want_stats=stats, keep_v=True))
     lib = _lib.load()
     n, h, w_, c = x.shape
@@ -61,7 +73,8 @@ for name, H, Cc in (("p64.0.conv2", 56, 64), ("p128.1.conv2", 28, 128), ("p256.1
     gx = torch.randn(B, H, H, Cc, device=dev, generator=g)
     mean, invstd = torch.randn(Cc, device=dev, generator=g) * 0.1, torch.rand(Cc, device=dev, generator=g) + 0.5
     gate = ops.BnGateCtx(gx, mean, invstd, scale=aff[0], shift=aff[1])
-    t_dd = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, 1, 1, gate=gate))
+    with direct():
+        t_dd = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, 1, 1, gate=gate))
     t_dw = timeit(lambda: ops.wino_conv2d_dgrad(dy, w, gate=gate))
     print(f"{'':14s} dgrad direct {t_dd:6.3f} ({tf(t_dd):5.1f} TF)  winograd {t_dw:6.3f} ({tf(t_dw):5.1f} TF)   x{t_dd / t_dw:.2f}")
     # ---- weight gradient (V kept from the forward)
@@ -75,12 +88,14 @@ for name, H, Cc in (("p64.0.conv2", 56, 64), ("p128.1.conv2", 28, 128), ("p256.1
     xs = torch.relu(x[:ns].double() * aff[0].double() + aff[1].double()).cpu()
     ws_ = w.double().cpu()
     ref = F.conv2d(xs.permute(0, 3, 1, 2), ws_, padding=1).permute(0, 2, 3, 1)
-    yd, _ = ops.conv2d_fwd_fused(x[:ns].contiguous(), w, 1, 1, in_affine=aff, want_stats=True)
+    with direct():
+        yd, _ = ops.conv2d_fwd_fused(x[:ns].contiguous(), w, 1, 1, in_affine=aff, want_stats=True)
     yw, pw, _ = ops.wino_conv2d_fwd(x[:ns].contiguous(), w, in_affine=aff, want_stats=stats)
     line = f"{'':14s} error vs fp64 (rel l2): fwd direct {rel(yd.cpu(), ref):.2e} winograd {rel(yw.cpu(), ref):.2e}"
     dys = dy[:ns].double().cpu()
     refdx = F.conv_transpose2d(dys.permute(0, 3, 1, 2), ws_, padding=1).permute(0, 2, 3, 1)
-    dxd = ops.conv2d_dgrad(dy[:ns].contiguous(), w, (ns, H, H, Cc), 1, 1)
+    with direct():
+        dxd = ops.conv2d_dgrad(dy[:ns].contiguous(), w, (ns, H, H, Cc), 1, 1)
     dxw = ops.wino_conv2d_dgrad(dy[:ns].contiguous(), w)
     line += f" | dgrad direct {rel(dxd.cpu(), refdx):.2e} winograd {rel(dxw.cpu(), refdx):.2e}"
     xr = xs.permute(0, 3, 1, 2).clone().requires_grad_(False)
@@ -93,9 +108,16 @@ for name, H, Cc in (("p64.0.conv2", 56, 64), ("p128.1.conv2", 28, 128), ("p256.1
     line += f" | wgrad direct {rel(dwd.cpu(), wr.grad):.2e} winograd {rel(dww.cpu(), wr.grad):.2e}"
     print(line, flush=True)
     if stats:      # the statistics partials of the output transform against the direct kernel's, merged
-        _, pd = ops.conv2d_fwd_fused(x[:ns].contiguous(), w, 1, 1, in_affine=aff, want_stats=True)
-        mrg = lambda pm, p2, cnt: (pm.double().mean(0), (p2.double().sum(0) + ((pm.double() - pm.double().mean(0)) ** 2).sum(0) * cnt))
+        with direct():
+            _, pd = ops.conv2d_fwd_fused(x[:ns].contiguous(), w, 1, 1, in_affine=aff, want_stats=True)
+        m_rows = ns * H * H
+
+        def mrg(pm, p2, rpg):          # Chan merge of the per-group (mean, M2) partials; the last group may be ragged
+            cnt = torch.full((pm.shape[0], 1), float(rpg), dtype=torch.float64, device=pm.device)
+            cnt[-1] = m_rows - rpg * (pm.shape[0] - 1)
+            mean = (pm.double() * cnt).sum(0) / m_rows
+            return mean, p2.double().sum(0) + (cnt * (pm.double() - mean) ** 2).sum(0)
         md, vd = mrg(pd[0], pd[1], 64)
-        mw, vw = mrg(pw[0], pw[1], 64)
+        mw, vw = mrg(pw[0], pw[1], pw[2])
         print(f"{'':14s} statistics partials: mean diff {float((md - mw).abs().max()):.2e}, M2 rel diff {float(((vd - vw).abs() / vd).max()):.2e}")
     del x, w, dy, v, m, y, vkeep
