@@ -161,98 +161,6 @@ attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restric
   if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = (m + log2f(l)) * LN2;
 }
 
-// ------------------------------------------------------------------------------------------------ attention for short sequences (T <= 48)
-// The 37-token local crops of DINO's multi-crop (networks/vit.py:22-31 on 96x96 / 16 crops) pad to 64 on the 32-row tiles above: 3.0x the
-// work.  Here a sequence is cut into 16-row tiles for v_mfma_f32_16x16x4_f32 (48 x 48 for 37: 1.68x) and ONE wavefront owns a whole
-// (image, head): no barriers, no cross-wave traffic.  The same orientation trick as above: S^T = K Q^T puts the query on the lane
-// (D[row = key 4 g + r][col = query]), so the softmax statistics are lane-local up to two shuffles over the lane groups g, and the P^T
-// accumulator registers are directly the B operand of O^T += V^T P^T - step r of that product contracts the keys {4 g + r}, which is what
-// register r of lane group g holds.  The contraction over the head dimension runs in the order d = 16 g + step, so a lane's Q / K operand
-// fragment is 16 CONSECUTIVE floats of its row (4 x 16-byte loads straight from HBM / L2, no LDS); only V is staged (its fragment is
-// "lane = d", a column access).
-constexpr int TS16 = 68;                // LDS row stride (floats)
-constexpr int SMALL_T = 48;
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ void load_frag16(const float* __restrict__ p, float* __restrict__ r, float mul) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x4 v = *(const f32x4*)(p + 4 * i);
-    r[4 * i] = v[0] * mul; r[4 * i + 1] = v[1] * mul; r[4 * i + 2] = v[2] * mul; r[4 * i + 3] = v[3] * mul;
-  }
-}
-
-__global__ void __launch_bounds__(256) attn_small_fwd_k(int T, int heads, int nprob, const float* __restrict__ Q, const float* __restrict__ K,
-                                                       const float* __restrict__ V, int ld, float scale, float* __restrict__ O, int ldo,
-                                                       float* __restrict__ LSE) {
-  __shared__ __attribute__((aligned(16))) float sv_all[4][SMALL_T * TS16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-  const int prob = blockIdx.x * 4 + wave;
-  if (prob >= nprob) return;                                  // no workgroup barriers below: a wave is on its own
-  const int b = prob / heads, h = prob - b * heads;
-  const int64_t tok0 = (int64_t)b * T;
-  const int nt = (T + 15) >> 4;
-  float* sv = sv_all[wave];
-  const float* vbase = V + tok0 * ld + h * DH;
-  for (int e = lane; e < SMALL_T * 16; e += 64) {            // V rows -> LDS (rows past T: zeros)
-    const int row = e >> 4, c4 = (e & 15) * 4;
-    *(f32x4*)(sv + row * TS16 + c4) = row < T ? *(const f32x4*)(vbase + (int64_t)row * ld + c4) : zero4();
-  }
-  float kf[3][16];
-#pragma unroll
-  for (int kt = 0; kt < 3; ++kt) {
-    const int row = min(16 * kt + r16, T - 1);
-    load_frag16(K + (tok0 + row) * ld + h * DH + 16 * g, kf[kt], 1.f);
-  }
-  for (int qt = 0; qt < nt; ++qt) {
-    const int qrow = min(16 * qt + r16, T - 1);
-    float qf[16];
-    load_frag16(Q + (tok0 + qrow) * ld + h * DH + 16 * g, qf, scale * LOG2E);
-    f32x4 s[3] = {zero4(), zero4(), zero4()};
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      if (kt < nt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][i], qf[i], s[kt], 0, 0, 0);   // row = key 4 g + r, col = query
-      }
-    }
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (16 * kt + 4 * g + r >= T) s[kt][r] = -INFINITY;
-        m = fmaxf(m, s[kt][r]);
-      }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s[kt][r] = ex2(s[kt][r] - m); l += s[kt][r]; }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    f32x4 o[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (16 * kt + r >= T) continue;                      // the four keys of this step (16 kt + 4 g + r, g = 0..3) are all padding (uniform)
-        const float* vr = sv + (16 * kt + 4 * g + r) * TS16 + r16;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[16 * dt], s[kt][r], o[dt], 0, 0, 0);
-      }
-    }
-    if (16 * qt + r16 < T) {
-      const float inv = 1.f / l;
-      float* op = O + (tok0 + 16 * qt + r16) * ldo + h * DH + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *(f32x4*)(op + 16 * dt) = o[dt] * inv;      // row = d 16 dt + 4 g + r: four consecutive floats of the output row
-      if (g == 0) LSE[((int64_t)b * heads + h) * T + 16 * qt + r16] = (m + log2f(l)) * LN2;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ attention backward: dQ (and delta)
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
@@ -736,14 +644,8 @@ extern "C" int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh
   SSV_REQUIRE(B <= 65535 && heads <= 65535, "ssv_attention_fwd: grid too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_ATTN, s);
-#ifndef SSV_ATTN_NO_SMALL
-  if (T <= SMALL_T) {               // short sequences: 16-row tiles, one wavefront per (image, head)
-    const int64_t nprob = (int64_t)B * heads;
-    hipLaunchKernelGGL(attn_small_fwd_k, dim3((unsigned)cdiv64(nprob, 4)), dim3(256), 0, s, T, heads, (int)nprob, q, k, v, ld, scale, o, ldo, lse);
-    SSV_CHECK_LAUNCH("attn_small_fwd_k");
-    return SSV_OK;
-  }
-#endif
+  // 37-token local crops run the 64-row tile too: a 16x16x4-tile kernel with one wavefront per (image, head) was measured at 0.161 ms against
+  // 0.166 ms here (T 37, 2048 images; profiles/r03_attention_kernels.txt) - both sit at ~2.9 TB/s of q/k/v/o traffic, not on the padded MFMA work.
   if (T <= 64) hipLaunchKernelGGL(attn_fwd_k<2>, dim3(cdiv(T, 64), heads, B), dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
   else hipLaunchKernelGGL(attn_fwd_k<4>, dim3(cdiv(T, 128), heads, B), dim3(256), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
   SSV_CHECK_LAUNCH("attn_fwd_k");
