@@ -23,9 +23,9 @@ sys.path.insert(0, ROOT)
 
 # rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh); newest kernel state first
 PMC_FILES = {"simclr": ("r03_simclr_b%d_pmc_hbm_traffic.json", "r02_simclr_b%d_pmc_hbm_traffic.json", "r01_n_pmc_hbm_traffic_b%d.json"),
-             "dino": ("r02_dino_b%d_pmc_hbm_traffic.json", "r01_l_pmc_hbm_traffic_dino_b%d.json")}
+             "dino": ("r03_dino_b%d_pmc_hbm_traffic.json", "r02_dino_b%d_pmc_hbm_traffic.json", "r01_l_pmc_hbm_traffic_dino_b%d.json")}
 CONV_LAYER_FILES = ("r03_conv_layers_b%d.csv",)     # tools/bench_conv.py: per-layer operand-stream bytes of the variants the step launches
-PMC_MFMA_FILES = {"simclr": ("r03_simclr_b%d_pmc_mfma.json", "r02_simclr_b%d_pmc_mfma.json"), "dino": ("r02_dino_b%d_pmc_mfma.json",)}
+PMC_MFMA_FILES = {"simclr": ("r03_simclr_b%d_pmc_mfma.json", "r02_simclr_b%d_pmc_mfma.json"), "dino": ("r03_dino_b%d_pmc_mfma.json", "r02_dino_b%d_pmc_mfma.json")}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 

@@ -386,6 +386,10 @@ int ssv_layernorm_bwd(int64_t M, int32_t C, const float* dy, const float* x, con
 int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* h, float* act, void* stream);
 int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, const float* w, const float* h, const float* addend,
                           float* dx, void* stream);
+/* the same backward on the forward kernel, given the TRANSPOSED weights wt [C_in][K_out] of fc2 (ssv_filter_transpose): d describes the GEMM as
+ * launched - rows of dy with d->C columns (fc2's outputs, % 32), d->K result columns (fc2's inputs = the width of h, % 4, >= 128) */
+int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, const float* wt, const float* h, const float* addend,
+                            float* dh, void* stream);
 /* nn.GELU() (erf form; networks/vit.py:38, models/dino.py:30-33) on n floats, n % 4 == 0 */
 int ssv_gelu_fwd(int64_t n, const float* x, float* y, void* stream);
 int ssv_gelu_bwd(int64_t n, const float* x, const float* dy, float* dx, void* stream);

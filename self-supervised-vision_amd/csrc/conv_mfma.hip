@@ -492,7 +492,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, bool EPI = false, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false>
 // Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
@@ -877,9 +877,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
                                                    nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
         }
       } else {
-        epilogue_vec<TM, TN, EPI ? 1 : 0>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
-                                          [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
-                                          EPI ? p.aux_out : nullptr, nullptr);
+        epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
+                                  [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
+                                  EPI == 1 ? p.aux_out : nullptr, EPI == 2 ? p.aux_in : nullptr);
       }
       return;
     }
@@ -1642,7 +1642,7 @@ extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const
   p.aux_out = act;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
   // K-step 32 only: its LDS stage is what the vectorised epilogue (the one that writes the second tensor) needs
-  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
+  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 1>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
   return SSV_OK;
 }
@@ -1662,6 +1662,26 @@ extern "C" int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, co
   const unsigned gx = (unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128));
   hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32, true>), dim3(gx, 1), dim3(256), 0, s, p, dy, w, addend, dx);
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad_gelu");
+  return SSV_OK;
+}
+
+// The same product on the FORWARD kernel: dh = (dy wt^T) * gelu'(h) (+ addend) with wt = w transposed ([C][K], ssv_filter_transpose), so both
+// operands are k-contiguous rows (ds_read_b128) as in every other stride-1 data gradient - the dgrad kernel reads the in-place weight image k-major.
+// `d` describes the GEMM as launched: N*H*W rows of dy with d->C columns (the Linear's outputs), d->K result columns (its inputs, = h's width).
+extern "C" int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, const float* wt, const float* h, const float* addend,
+                                       float* dh, void* stream) {
+  if (int rc = check_desc(d, "ssv_linear_fwd_gelugrad")) return rc;
+  SSV_REQUIRE(dy && wt && h && dh, "ssv_linear_fwd_gelugrad: null pointer");
+  SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)wt | (uintptr_t)h | (uintptr_t)dh | (uintptr_t)addend) & 15) == 0, "ssv_linear_fwd_gelugrad: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0 && d->K >= 128 && d->stride == 1 && d->R == 1 && d->S == 1 && d->pad == 0,
+              "ssv_linear_fwd_gelugrad: a Linear layer with C %% 32 == 0, K %% 4 == 0, K >= 128 (got C=%d K=%d)", d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_DGRAD, s);
+  ConvKP p = make_kp(d);
+  p.aux_in = h;
+  const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  SSV_CHECK_LAUNCH("ssv_linear_fwd_gelugrad");
   return SSV_OK;
 }
 

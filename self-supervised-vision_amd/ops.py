@@ -866,6 +866,9 @@ def linear_gelu_fwd(x, w, bias):
     return h, act
 
 
+LINEAR_GELUGRAD_ON_FWD = os.environ.get("SSV_NO_GELUGRAD_FWD_KERNEL", "0") != "1"     # diagnostic switch: fc2's data gradient on the dgrad kernel
+
+
 def linear_dgrad_gelu(dy, w, h, addend=None, out=None):
     """dh = (dy w) * gelu'(h) (+ addend): the backward of `gelu(h) -> Linear(w)` down to the pre-activation, in the dgrad epilogue."""
     _lib._dev(dy, w, h, addend)
@@ -873,6 +876,12 @@ def linear_dgrad_gelu(dy, w, h, addend=None, out=None):
     w, wshape = _ohwi(w)
     d = conv_desc((m, 1, 1, wshape[1]), wshape, 1, 0)
     dh = out if out is not None else torch.empty_like(h)
+    k, c = wshape[0], wshape[1]
+    if LINEAR_GELUGRAD_ON_FWD and k % 32 == 0 and c % 4 == 0 and c >= 128:
+        # forward kernel on the transposed weights (cached per step like every stride-1 data gradient's): both operands k-contiguous rows
+        dt = conv_desc((m, 1, 1, k), (c, k, 1, 1), 1, 0)
+        call("ssv_linear_fwd_gelugrad", C.byref(dt), ptr(dy), ptr(_transposed_filter(w, wshape)), ptr(h), ptr(addend), ptr(dh), stream())
+        return dh
     call("ssv_conv2d_dgrad_gelu", C.byref(d), ptr(dy), ptr(w), ptr(h), ptr(addend), ptr(dh), stream())
     return dh
 

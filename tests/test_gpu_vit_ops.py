@@ -200,5 +200,13 @@ def test_linear_gelu_epilogue_fusions(dev, m, c, k):
     (F.gelu(hh) @ w2.double().t()).backward(dy.double())
     got = ops.linear_dgrad_gelu(dy.to(dev), w2.to(dev), h, addend=add.to(dev))
     _close(got, hh.grad + add.double(), 2e-4, 2e-5)
+    assert ops.LINEAR_GELUGRAD_ON_FWD                 # shipped: the forward kernel on the transposed weights; the dgrad-kernel form stays available
+    ops.LINEAR_GELUGRAD_ON_FWD = False
+    try:
+        other = ops.linear_dgrad_gelu(dy.to(dev), w2.to(dev), h, addend=add.to(dev))
+    finally:
+        ops.LINEAR_GELUGRAD_ON_FWD = True
+    _close(other, hh.grad + add.double(), 2e-4, 2e-5)
+    _close(other, got.double().cpu(), 1e-5, 1e-6)
     with pytest.raises(Exception):
         ops.linear_dgrad_gelu(seeded_randn(1, m, 48).to(dev), seeded_randn(2, 48, k).to(dev), h)      # K % 32 != 0 is refused, not silently unfused
