@@ -350,12 +350,14 @@ def main():
     counter = [0]
 
     def step():
-        if multi_crop is not None:                                # two augmented copies -> 2 x (2 global + 8 local) bicubic crops
-            batch = multi_crop(source, rows, counter[0], sample_ids=sample_ids)
-        else:
-            params = tf.draw(source, sample_ids, counter[0])      # RNG keyed by the GLOBAL sample id
-            views = tf.apply(source, rows, params)
-            batch = {"aug_1": views[0], "aug_2": views[1]}
+        with hnn.input_stream(device) as ins:                         # as utils/data_utils.GpuTwoViewLoader does: the views are built on their own stream
+            if multi_crop is not None:                                # two augmented copies -> 2 x (2 global + 8 local) bicubic crops
+                batch = multi_crop(source, rows, counter[0], sample_ids=sample_ids)
+            else:
+                params = tf.draw(source, sample_ids, counter[0])      # RNG keyed by the GLOBAL sample id
+                views = tf.apply(source, rows, params)
+                batch = {"aug_1": views[0], "aug_2": views[1]}
+            ins.publish(*batch.values())
         counter[0] += 1
         return train_step(batch)
 

@@ -27,10 +27,11 @@ class BarlowTwins(TwoViewTrainer):
             with pv.view(1):
                 z_2 = self._embed(img_2)
         loss = self.loss_fn(z_1, z_2)
+        loss_now = hnn.early_item(loss)                  # the scalar leaves for the host now; the backward does not wait for it, nor it for the backward
         self.optim.zero_grad()
         loss.backward()
         self.optim.step()
-        return {"loss": loss.item()}
+        return {"loss": loss_now.get()}
 
     def _checkpoint_state(self):
         return {"encoder": self.encoder.state_dict(), "proj_head": self.proj_head.state_dict()}

@@ -163,10 +163,11 @@ class DINO(TwoViewTrainer):
         loss = self.loss_fn(student_g, student_l, teacher_g, self.teacher_center.view(-1), bs, vg, vl, self.temp_student, self.temp_teacher)
         ng = bs * vg
         self.update_teacher_center(teacher_g[:ng], teacher_g[ng:])
+        loss_now = hnn.early_item(loss)                  # the scalar leaves for the host now; the backward does not wait for it, nor it for the backward
         self.optim.zero_grad()
         loss.backward()
         self.optim.step()
-        return {"loss": loss.item()}
+        return {"loss": loss_now.get()}
 
     def _embed(self, img):
         return self.student_model(img)

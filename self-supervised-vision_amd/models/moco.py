@@ -79,12 +79,13 @@ class MoCo(TwoViewTrainer):
                 with torch.no_grad():
                     keys = self.key_encoder(img_2)
         loss = self.loss_fn(query, keys, self.memory_bank.get_vectors(), self.memory_bank.size)
+        loss_now = hnn.early_item(loss)                  # the scalar leaves for the host now; the backward does not wait for it, nor it for the backward
         self.optim.zero_grad()
         loss.backward()
         self.optim.step()
         self.momentum_update()
         self.memory_bank.add_batch(keys)
-        return {"loss": loss.item()}
+        return {"loss": loss_now.get()}
 
     def _checkpoint_state(self):
         return {"encoder": self.query_encoder.state_dict()}

@@ -87,10 +87,11 @@ class SimSiam(TwoViewTrainer):
                 with torch.no_grad():
                     target_2 = self.target_network(img_2)
         loss = self.loss_fn(online_1, online_2, target_1, target_2)
+        loss_now = hnn.early_item(loss)                  # the scalar leaves for the host now; the backward does not wait for it, nor it for the backward
         self.optim.zero_grad()
         loss.backward()
         self.optim.step()
-        return {"loss": loss.item()}
+        return {"loss": loss_now.get()}
 
     def _checkpoint_state(self):
         return {"encoder": self.online_network.state_dict()}

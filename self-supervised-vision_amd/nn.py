@@ -64,8 +64,7 @@ class parallel_views:
 
     def __enter__(self):
         if self.enabled:
-            if self.device not in _STREAMS:
-                _STREAMS[self.device] = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            _view_stream_pair(self.device)
             self.main = torch.cuda.current_stream(self.device)
             self.start = torch.cuda.Event()
             self.start.record(self.main)
@@ -104,6 +103,83 @@ class _ViewCtx:
             self.ctx.__exit__(*exc)
         _SLOT = self.prev
         return False
+
+
+_INPUT_STREAM = os.environ.get("SSV_NO_INPUT_STREAM", "0") != "1"     # diagnostic switch: the next batch's augmentation on the ambient stream
+_INPUT_STREAMS = {}
+
+
+def _view_stream_pair(device):
+    if device not in _STREAMS:
+        _STREAMS[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _STREAMS[device]
+
+
+class input_stream:
+    """with input_stream(device) as ins:  batch = <augmentation kernels>;  ins.publish(*tensors)
+    The kernels inside run on a stream of their own, so the NEXT batch's views are built while the previous step's backward is still
+    executing (the ambient stream is ordered behind that backward by the optimizer's join; with ``early_item`` the host gets here long before
+    it has run).  Everything they read must already be complete - static, resident data (the first entry waits for the ambient stream once) or
+    tensors created inside the block.  ``publish`` tells the caching allocator which other streams will read the outputs; on exit the ambient
+    stream waits for the block's kernels.  Disabled (or on the CPU) the block simply runs on the ambient stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.enabled = _INPUT_STREAM and _VIEW_STREAMS and self.device.type == "cuda"
+
+    def __enter__(self):
+        if self.enabled:
+            self.main = torch.cuda.current_stream(self.device)
+            side = _INPUT_STREAMS.get(self.device)
+            if side is None:
+                side = _INPUT_STREAMS[self.device] = torch.cuda.Stream(self.device)
+                side.wait_stream(self.main)               # whatever built the dataset on the ambient stream
+            self.side = side
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def publish(self, *tensors):
+        if self.enabled:
+            readers = (self.main,) + tuple(_view_stream_pair(self.device))
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    for st in readers:
+                        t.record_stream(st)
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            done = torch.cuda.Event()
+            done.record(self.side)
+            self.ctx.__exit__(*exc)
+            self.main.wait_event(done)
+        return False
+
+
+_EARLY_LOSS = os.environ.get("SSV_LATE_LOSS_READ", "0") != "1"      # diagnostic switch: read the loss with .item() after the update (drains the queue)
+
+
+class early_item:
+    """``loss.item()`` that does not drain the queue (reference: ``return {"loss": loss.item()}`` after ``optim.step()``, models/simclr.py:95).
+    Constructed right after the loss kernel, BEFORE the backward is enqueued: the scalar travels to pinned host memory on the ambient stream and
+    ``get()`` waits for that copy only.  ``train_step`` then returns while the backward and the update are still executing, and the host enqueues
+    the next step's augmentation and first view behind them - otherwise every step starts with one view stream running alone for as long as
+    the host needs to enqueue the first view's forward (12 ms of a 228 ms step at bs 512, and the other view finishes that much later)."""
+
+    def __init__(self, t):
+        self.t = t.detach()
+        self.ev = None
+        if self.t.is_cuda and _EARLY_LOSS:
+            self.host = torch.empty(1, dtype=self.t.dtype, pin_memory=True)
+            self.host.copy_(self.t.reshape(1), non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record(torch.cuda.current_stream(self.t.device))
+
+    def get(self):
+        if self.ev is None:
+            return self.t.item()
+        self.ev.synchronize()
+        return self.host.item()
 
 
 # ------------------------------------------------------------------------------------------- tape

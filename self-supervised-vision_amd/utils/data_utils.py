@@ -170,9 +170,12 @@ class GpuTwoViewLoader:
         if self.streamed:
             yield from self._iter_streamed(order, slices)
             return
+        from .. import nn as hnn
         for a, b in slices:
-            idx = order[a:b].to(self.device)
-            batch = self._make(idx, self.step)                              # self.step is the GLOBAL step: same on every rank
+            with hnn.input_stream(self.device) as ins:                      # built beside the previous step's backward (resident data only)
+                idx = order[a:b].to(self.device)
+                batch = self._make(idx, self.step)                          # self.step is the GLOBAL step: same on every rank
+                ins.publish(*batch.values())
             self.step += 1
             yield batch
 

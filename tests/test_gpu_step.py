@@ -301,6 +301,38 @@ def _bare_trainer(cls, dev, config, loader_len=1):
     return t
 
 
+def test_input_stream_and_early_loss_read_change_no_bit(dev):
+    """The loader builds the next batch's views on a stream of its own (hnn.input_stream) and train_step reads the loss from a pinned-memory copy
+    enqueued before the backward (hnn.early_item), so the host runs one step ahead of the GPU.  Four steps of the SimCLR trainer fed by the loader:
+    every loss and every parameter afterwards equal the serial form's (views on the ambient stream, .item() after the update) bit for bit."""
+    from ssv_amd import nn as hnn
+    from ssv_amd.models.simclr import SimCLR
+    from ssv_amd.utils import data_utils
+    rng = np.random.default_rng(11)
+    imgs, labels = rng.integers(0, 256, size=(96, 40, 40, 3), dtype=np.uint8), rng.integers(0, 10, size=96)
+    norm = {"mean": [0.5, 0.5, 0.5], "std": [0.25, 0.25, 0.25]}
+    aug = {"color_jitter": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.4, "hue": 0.1, "apply_prob": 0.8}, "random_gray": {"p": 0.2},
+           "random_resized_crop": {"size": [32, 32], "scale": [0.2, 1.0]}, "random_flip": None, "to_tensor": None, "normalize": norm}
+    tfs = {"train": aug, "test": {"center_crop": {"size": [32, 32]}, "to_tensor": None, "normalize": norm}}
+    cfg = {"epochs": 100, "proj_dim": 128, "encoder": {"reduce_bottom_conv": True}, "optimizer": {"name": "sgd", "lr": 0.05, "weight_decay": 1e-6},
+           "scheduler": {"name": "cosine", "warmup_epochs": 0}, "loss_fn": {"normalize": True, "temperature": 0.5}}
+    runs = []
+    for ahead in (True, False):
+        prev = hnn._INPUT_STREAM, hnn._EARLY_LOSS
+        hnn._INPUT_STREAM = hnn._EARLY_LOSS = ahead
+        try:
+            t = _bare_trainer(SimCLR, dev, cfg)
+            loader = data_utils.GpuTwoViewLoader(imgs, labels, tfs, batch_size=24, shuffle=True, device=dev)
+            losses = [t.train_step(batch)["loss"] for batch in loader]
+            torch.cuda.synchronize()
+            runs.append((losses, t.optim.arena.data.cpu().clone()))
+        finally:
+            hnn._INPUT_STREAM, hnn._EARLY_LOSS = prev
+    (l0, p0), (l1, p1) = runs
+    assert len(l0) == 4 and l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1)
+
+
 def test_barlow_r18_steps_match_reference(dev, golden):
     from ssv_amd.models.barlow import BarlowTwins
     g = golden["step_level"]
