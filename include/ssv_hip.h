@@ -58,10 +58,21 @@ int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const
 int ssv_pad_channels(int64_t npix, int32_t cin, int32_t cout, const float* in, float* out, int32_t accumulate, void* stream);
 /* Grouped convolution (conv3x3(groups=32) of the ResNeXt encoders, networks/resnet.py:8-10,57): the grouped filter bank
  * [K][R][S][C/groups] is expanded to the dense block-diagonal [K][R][S][C] one (zeros elsewhere - exact, they contribute 0) and
- * run through the dense kernels; the dense weight gradient is gathered back (+= when accumulate).  Correct, not yet fast: the
- * 3x3 of a 32x4d block does 32x the grouped FLOPs; a group-aware MFMA tiling is the follow-up. */
+ * run through the MFMA kernels (the group-aware entry points below); the bank-layout weight gradient is gathered back (+= when accumulate). */
 int ssv_group_expand(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* wg, float* wd, void* stream);
 int ssv_group_extract(int32_t K, int32_t R, int32_t S, int32_t Cg, int32_t groups, const float* dwd, float* dwg, int32_t accumulate, void* stream);
+
+/* Grouped convolutions on the DENSE block-diagonal bank wd [K][R][S][C] made by ssv_group_expand (networks/resnet.py:8-10,57: conv3x3(groups = 32) of
+ * the ResNeXt bottlenecks): the kernels of ssv_conv2d_fwd / _dgrad / _wgrad, but every output-column tile contracts only over the channels of the
+ * groups it falls into - exact (the skipped products are against zero weights) and C/64 (forward), K/64 (data gradient) times fewer k-tiles.
+ * groups must divide C and K.  The stride-1 data gradient is ssv_conv2d_fwd_grouped on the transposed bank (ssv_filter_transpose), like the dense one.
+ * ssv_conv2d_wgrad_grouped leaves the weight gradient in the bank's layout with ONLY the diagonal blocks defined (what ssv_group_extract reads). */
+int ssv_conv2d_fwd_grouped(const ssv_conv_desc* d, int32_t groups, const float* x, const float* wd, const float* bias, const float* addend,
+                           float* y, void* stream);
+int ssv_conv2d_dgrad_grouped(const ssv_conv_desc* d, int32_t groups, const float* dy, const float* wd, const float* addend, float* dx, void* stream);
+size_t ssv_conv2d_wgrad_grouped_workspace_bytes(const ssv_conv_desc* d, int32_t groups);
+int ssv_conv2d_wgrad_grouped(const ssv_conv_desc* d, int32_t groups, const float* x, const float* dy, float* dwd, int accumulate,
+                             void* ws, size_t ws_bytes, void* stream);
 /* wt[c][R-1-r][S-1-s][k] = w[k][r][s][c].  For stride 1, dgrad(dy, w) == ssv_conv2d_fwd(dy, wt) with pad' = R-1-pad: the host
  * routes stride-1 layers that way (both GEMM operands then stream k-contiguous rows; measured 5-15 % faster than the dgrad kernel) */
 int ssv_filter_transpose(int32_t K, int32_t R, int32_t S, int32_t C, const float* w, float* wt, void* stream);

@@ -71,6 +71,10 @@ SIGNATURES = {
     "ssv_conv2d_fwd_dyin": (C.c_int, [_cd, _vp, C.POINTER(BnDyin), _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
     "ssv_conv2d_wgrad_dyin": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.POINTER(BnDyin), _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad_workspace_bytes": (_sz, [_cd]),
+    "ssv_conv2d_fwd_grouped": (C.c_int, [_cd, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_dgrad_grouped": (C.c_int, [_cd, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_conv2d_wgrad_grouped_workspace_bytes": (_sz, [_cd, _i32]),
+    "ssv_conv2d_wgrad_grouped": (C.c_int, [_cd, _i32, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_stem_conv_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_stem_conv_wgrad_workspace_bytes": (_sz, [_cd]),

@@ -79,7 +79,19 @@ struct ConvKP {
   // compact addend (ADDS2 variants): the addend is [N][add_H2][add_W2][K] and belongs to the output pixels with even (h, w) - the data gradient
   // of a 1x1 / stride-2 projection shortcut, computed as a dense GEMM on the subsampled grid instead of a full-resolution tensor of 3/4 zeros
   int add_H2, add_W2;
+  // block-diagonal filter banks (a grouped convolution expanded to dense form, ssv_group_expand): input / output channels per group, 0 = dense.
+  // Output columns [n0, n1) only depend on the input channels of the groups they fall into, so a tile's contraction runs over that channel range
+  // instead of all of C (fwd: channels, dgrad: output channels), and a weight-gradient tile whose rows and columns share no group is skipped.
+  int Cg, Kg;
 };
+
+// [lo, hi) of the contraction channels (multiples of `bk`, hi capped at `ctot`) that the output columns [n0, n1) of a block-diagonal product can see:
+// the columns come in groups of `og`, each fed by `ig` consecutive contraction channels
+__device__ __forceinline__ void group_span(int n0, int n1, int og, int ig, int bk, int ctot, int& lo, int& hi) {
+  const int glo = n0 / og, ghi = (n1 - 1) / og;
+  lo = glo * ig / bk * bk;
+  hi = min(ctot, ((ghi + 1) * ig + bk - 1) / bk * bk);
+}
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
 
@@ -678,6 +690,14 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     }
     const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;     // 1x1 / no padding: every tap of a valid row is in bounds
     int lr = 0, ls = 0, lc0 = 0;   // loader position (tap r, s, first channel)
+    int ktiles = p.RSC / BK;
+    if constexpr (!XF && OPM == 0) {
+      if (p.Kg != 0) {             // block-diagonal filter bank (uniform): only the channels of this column tile's groups
+        int c_hi;
+        group_span(n0, min(n0 + BN, p.K), p.Kg, p.Cg, BK, p.C, lc0, c_hi);
+        ktiles = p.R * p.S * ((c_hi - lc0) / BK);
+      }
+    }
     f32x4 ra[AP], rb[BP];
     f32x4 ra2[OPM ? AP : 1], co[OPM ? 4 : 1];
     const rsrc_t rx2 = make_rsrc(DYF ? p.dyin_x : (SUM ? p.sum_res : x), (unsigned)p.N * p.H * p.W * p.C * 4u);
@@ -778,7 +798,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
       for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(p.RSC / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
+    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
     static_assert(BK == GBK, "generic path is BK=16");
@@ -1004,6 +1024,12 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   const bool inb = p.pad == 0 && p.R == 1 && p.S == 1;       // 1x1: the single tap maps every class pixel onto a valid dY pixel
 
   int ti = 0, lk0 = 0;                   // loader position: tap index, first output channel
+  int kspan = p.K;
+  if (p.Cg != 0) {                       // block-diagonal filter bank (uniform): only the output channels of this column tile's groups
+    int k_hi;
+    group_span(n0, min(n0 + BN, p.C), p.Cg, p.Kg, BK, p.K, lk0, k_hi);
+    kspan = k_hi - lk0;
+  }
   int dho = 0, dwo = 0, tapoff = 0;
   if (ntaps > 0) { dho = taps[0]; dwo = taps[1]; tapoff = taps[2]; }
   f32x4 ra[AP], rb[BP];
@@ -1031,7 +1057,7 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 #pragma unroll
     for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rb[i];
   };
-  k_loop<TM, TN, true, false, LDT, BN, BK, AP + BP>(ntaps * (p.K / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  k_loop<TM, TN, true, false, LDT, BN, BK, AP + BP>(ntaps * (kspan / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
   static_assert(!EPI || EP_FLOATS <= STAGE, "the fused-activation dgrad needs the vectorised epilogue");
@@ -1104,6 +1130,14 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   const int ms = split * chunk_rows;
   const int me = min(ms + chunk_rows, p.M);
   x += (size_t)blockIdx.y * p.bs_a; dy += (size_t)blockIdx.y * p.bs_b; partial += (size_t)blockIdx.y * p.bs_o;     // batched weight gradients
+  if constexpr (GATHER != 3) {
+    if (p.Kg != 0 && j0 / p.C == (min(j0 + BN, NCOL) - 1) / p.C) {     // block-diagonal bank, column tile inside one tap (uniform)
+      const int c0 = j0 % p.C, c1 = c0 + min(BN, NCOL - j0);
+      // rows i0.. are output channels, columns input channels c0..c1 of one tap: a tile that no group touches is identically zero
+      // and is NOT written - ssv_group_extract reads the diagonal blocks only
+      if ((min(i0 + BM, p.K) - 1) / p.Kg < c0 / p.Cg || (c1 - 1) / p.Cg < i0 / p.Kg) return;
+    }
+  }
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
@@ -1375,19 +1409,26 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.sum_res = p.sum_scale = p.sum_shift = p.sum_rscale = p.sum_rshift = nullptr; p.sum_out = nullptr; p.sum_mask = nullptr;
   p.bs_a = p.bs_b = p.bs_o = 0;
   p.add_H2 = p.add_W2 = 0;
+  p.Cg = p.Kg = 0;
   return p;
 }
 
 struct WgradPlan { int bm, bn, it, jt, nsplit, chunk; };
-WgradPlan plan_wgrad(const ssv_conv_desc* d) {
+WgradPlan plan_wgrad(const ssv_conv_desc* d, int groups = 0) {
   WgradPlan w;
   const int RSC = d->R * d->S * d->C;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  w.bm = d->K >= 128 ? 128 : 64;
-  w.bn = RSC <= 64 ? 64 : 128;              // 1x1 convs on 64 channels: a 128-wide tile would be half empty
+  const bool bd = groups > 1 && d->C % 64 == 0;     // block-diagonal bank: 64 x 64 tiles, of which only those a group touches do any work
+  w.bm = (d->K >= 128 && !bd) ? 128 : 64;
+  w.bn = (RSC <= 64 || bd) ? 64 : 128;      // 1x1 convs on 64 channels: a 128-wide tile would be half empty
   w.it = cdiv(d->K, w.bm);
   w.jt = cdiv(RSC, w.bn);
-  const int tiles = w.it * w.jt;
+  int tiles = w.it * w.jt;
+  if (bd) {                                 // tiles that work: per tap and row tile, the column tiles of the row tile's groups
+    const int cg = d->C / groups, kg = d->K / groups;
+    const int per_row = cdiv((cdiv(w.bm, kg) + 1) * cg, w.bn) + 1;
+    tiles = w.it * d->R * d->S * (per_row < d->C / w.bn ? per_row : d->C / w.bn);
+  }
   // one resident round: 3 workgroups per CU for the 128-row kernels, 4 for the 64-row ones.  Round DOWN - one workgroup more
   // than the chip holds costs a whole second round for the stragglers.
   const int slots = w.bm == 128 ? 768 : 1024;
@@ -1411,12 +1452,13 @@ namespace {
 // forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
 int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
                float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s, const ssv_bn_gate* gate = nullptr,
-               int add_H2 = 0, int add_W2 = 0) {
+               int add_H2 = 0, int add_W2 = 0, int groups = 0) {
   ConvKP p = make_kp(d);
   p.add_H2 = add_H2; p.add_W2 = add_W2;
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
+  if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
-  const bool wide = d->K >= 128;
+  const bool wide = d->K >= 128 && groups <= 1;               // block-diagonal banks: the 64-column tile sees the fewest foreign groups
   const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
   if (gate) {                                                  // C % 32 == 0 checked by the caller
     p.gate = *gate;
@@ -1467,6 +1509,30 @@ extern "C" int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const floa
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   launch_fwd(d, x, w, bias, addend, y, nullptr, nullptr, nullptr, nullptr, s);
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd");
+  return SSV_OK;
+}
+
+// Grouped convolutions (conv3x3(groups = 32) of the ResNeXt bottlenecks, networks/resnet.py:8-10,57) on their DENSE block-diagonal filter bank
+// (ssv_group_expand): the same kernels, but every output-column tile contracts only over the channels of the groups it falls into -
+// C / 64 (forward, stride-1 data gradient), K / 64 (strided data gradient) times fewer k-tiles than the dense product; exact, the skipped
+// products are all against zero weights.  groups must divide C and K.
+namespace {
+int check_groups(const ssv_conv_desc* d, int groups, const char* who) {
+  SSV_REQUIRE(groups >= 1 && d->C % groups == 0 && d->K % groups == 0, "%s: groups = %d must divide C = %d and K = %d", who, groups, d->C, d->K);
+  return SSV_OK;
+}
+}  // namespace
+
+extern "C" int ssv_conv2d_fwd_grouped(const ssv_conv_desc* d, int32_t groups, const float* x, const float* wd, const float* bias,
+                                      const float* addend, float* y, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_fwd_grouped")) return rc;
+  if (int rc = check_groups(d, groups, "ssv_conv2d_fwd_grouped")) return rc;
+  SSV_REQUIRE(x && wd && y, "ssv_conv2d_fwd_grouped: null pointer");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)wd | (uintptr_t)y) & 15) == 0, "ssv_conv2d_fwd_grouped: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  launch_fwd(d, x, wd, bias, addend, y, nullptr, nullptr, nullptr, nullptr, s, nullptr, 0, 0, groups);
+  SSV_CHECK_LAUNCH("ssv_conv2d_fwd_grouped");
   return SSV_OK;
 }
 
@@ -1685,8 +1751,24 @@ extern "C" int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, 
   return SSV_OK;
 }
 
+namespace {
+int dgrad_impl(const ssv_conv_desc* d, int groups, const float* dy, const float* w, const float* addend, float* dx, void* stream);
+}
 extern "C" int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const float* w, const float* addend,
                                 float* dx, void* stream) {
+  return dgrad_impl(d, 0, dy, w, addend, dx, stream);
+}
+
+// the parity-class data gradient of a grouped convolution on its dense block-diagonal bank (see ssv_conv2d_fwd_grouped)
+extern "C" int ssv_conv2d_dgrad_grouped(const ssv_conv_desc* d, int32_t groups, const float* dy, const float* wd, const float* addend,
+                                        float* dx, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_dgrad_grouped")) return rc;
+  if (int rc = check_groups(d, groups, "ssv_conv2d_dgrad_grouped")) return rc;
+  return dgrad_impl(d, groups, dy, wd, addend, dx, stream);
+}
+
+namespace {
+int dgrad_impl(const ssv_conv_desc* d, int groups, const float* dy, const float* w, const float* addend, float* dx, void* stream) {
   if (int rc = check_desc(d, "ssv_conv2d_dgrad")) return rc;
   SSV_REQUIRE(dy && w && dx, "ssv_conv2d_dgrad: null pointer");
   SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0, "ssv_conv2d_dgrad: pointers must be 16-byte aligned");
@@ -1694,12 +1776,13 @@ extern "C" int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const f
   SSV_REQUIRE(d->stride <= 8, "ssv_conv2d_dgrad: stride too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_DGRAD, s);
-  const ConvKP p = make_kp(d);
+  ConvKP p = make_kp(d);
+  if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
   const bool bk32 = d->K % 32 == 0;
   const int st = d->stride;
   const int Hq = cdiv(d->H, st), Wq = cdiv(d->W, st);            // class (0,0) is the largest
   const int64_t Mc = (int64_t)d->N * Hq * Wq;
-  if (d->C >= 128) {
+  if (d->C >= 128 && groups <= 1) {
     const dim3 g((unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128)), st * st);
     if (bk32) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32>), g, dim3(256), 0, s, p, dy, w, addend, dx);
     else      hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 16>), g, dim3(256), 0, s, p, dy, w, addend, dx);
@@ -1711,6 +1794,7 @@ extern "C" int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const f
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad");
   return SSV_OK;
 }
+}  // namespace
 
 extern "C" int64_t ssv_conv2d_dgrad_gate_groups(const ssv_conv_desc* d) {
   if (!d || d->C <= 0 || d->stride <= 0) return 0;
@@ -1753,6 +1837,12 @@ extern "C" size_t ssv_conv2d_wgrad_workspace_bytes(const ssv_conv_desc* d) {
   return (size_t)w.nsplit * d->K * d->R * d->S * d->C * sizeof(float);
 }
 
+extern "C" size_t ssv_conv2d_wgrad_grouped_workspace_bytes(const ssv_conv_desc* d, int32_t groups) {
+  if (!d || d->K <= 0 || d->C <= 0 || groups < 1 || d->C % groups || d->K % groups) return 0;
+  const WgradPlan w = plan_wgrad(d, groups);
+  return (size_t)w.nsplit * d->K * d->R * d->S * d->C * sizeof(float);
+}
+
 extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dw,
                                 int accumulate, void* ws, size_t ws_bytes, void* stream) {
   return ssv_conv2d_wgrad_bnrelu_in(d, x, nullptr, nullptr, dy, dw, accumulate, ws, ws_bytes, stream);
@@ -1760,7 +1850,15 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
 
 namespace {
 int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy, const ssv_bn_dyin* dyin,
-               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream, int groups = 0);
+}
+// Weight gradient of a grouped convolution in the layout of its dense block-diagonal bank, dwd [K][R][S][C]: ONLY the diagonal blocks (the entries
+// ssv_group_extract reads) are defined - tiles that no group touches are skipped and their entries are whatever the workspace held.
+extern "C" int ssv_conv2d_wgrad_grouped(const ssv_conv_desc* d, int32_t groups, const float* x, const float* dy, float* dwd, int accumulate,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_desc(d, "ssv_conv2d_wgrad_grouped")) return rc;
+  if (int rc = check_groups(d, groups, "ssv_conv2d_wgrad_grouped")) return rc;
+  return wgrad_impl(d, x, nullptr, nullptr, dy, nullptr, dwd, accumulate, ws, ws_bytes, stream, groups);
 }
 extern "C" int ssv_conv2d_wgrad_bnrelu_in(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy,
                                           float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
@@ -1779,7 +1877,7 @@ extern "C" int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, con
 
 namespace {
 int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy, const ssv_bn_dyin* dyin,
-               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream, int groups) {
   if (int rc = check_desc(d, "ssv_conv2d_wgrad")) return rc;
   SSV_REQUIRE(x && dy && dw && ws, "ssv_conv2d_wgrad: null pointer");
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0, "ssv_conv2d_wgrad: pointers must be 16-byte aligned");
@@ -1787,7 +1885,7 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   SSV_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "ssv_conv2d_wgrad: in_scale / in_shift must both be given or both NULL");
   const bool xf = in_scale != nullptr;
   SSV_REQUIRE(!xf || d->C % 4 == 0, "ssv_conv2d_wgrad: a fused input needs C %% 4 == 0 (got C=%d)", d->C);
-  const WgradPlan wp = plan_wgrad(d);
+  const WgradPlan wp = plan_wgrad(d, groups);
   const size_t need = (size_t)wp.nsplit * d->K * d->R * d->S * d->C * sizeof(float);
   if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
@@ -1795,6 +1893,7 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   ConvKP p = make_kp(d);
   p.xf_scale = in_scale; p.xf_shift = in_shift;
   if (dyin) { p.dyin_x = dyin->x; p.dyin_coef = dyin->coef; }
+  if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
   const bool vecb = d->C % 4 == 0;
   const int tiles = wp.it * wp.jt;
   const dim3 grid((unsigned)(tiles * wp.nsplit));

@@ -68,14 +68,19 @@ def _sub(t, n0, n1):
     return None if t is None else t[n0:n1]
 
 
-def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None):
+def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None, groups=1):
+    """``groups`` > 1: w is the DENSE block-diagonal bank of a grouped convolution (group_expand); every column tile then contracts over the
+    channels of its own groups only."""
     _lib._dev(x, w, bias, addend)
     w, wshape = _ohwi(w)
     d = conv_desc(x.shape, wshape, stride, pad)
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
     for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K)):
         dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad)
-        call("ssv_conv2d_fwd", C.byref(dc), ptr(x[n0:n1]), ptr(w), ptr(bias), ptr(_sub(addend, n0, n1)), ptr(y[n0:n1]), stream())
+        if groups > 1:
+            call("ssv_conv2d_fwd_grouped", C.byref(dc), int(groups), ptr(x[n0:n1]), ptr(w), ptr(bias), ptr(_sub(addend, n0, n1)), ptr(y[n0:n1]), stream())
+        else:
+            call("ssv_conv2d_fwd", C.byref(dc), ptr(x[n0:n1]), ptr(w), ptr(bias), ptr(_sub(addend, n0, n1)), ptr(y[n0:n1]), stream())
     return y
 
 
@@ -267,13 +272,16 @@ def _gate_sub(gate, n0, n1):
                      scale=gate.scale, shift=gate.shift, second=None if gate.x2 is None else (gate.x2[n0:n1], gate.mean2, gate.invstd2))
 
 
-def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=None):
+def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=None, groups=1):
     """dx = conv_transpose(dy, w) (+ addend).  Stride-1 layers (every Linear, every 1x1 and 3x3 stride-1 convolution) are computed
     as the FORWARD convolution of dy with the transposed, 180-degree rotated filter: both GEMM operands are then k-contiguous
     rows for ds_read_b128, which the dgrad kernel (weights read in place, k-major) cannot have - measured 5-15 % faster.
     ``gate`` (BnGateCtx): dx is the gradient w.r.t. a BatchNorm + ReLU output and this call is its LAST contribution - the epilogue
     stores the relu-gated gradient and the partial sums of the BatchNorm backward; they come back as ``dx._gate_partials``
-    (psum_g, psum_gx, groups).  Silently ungated when the shape is outside the gated kernels' preconditions."""
+    (psum_g, psum_gx, groups).  Silently ungated when the shape is outside the gated kernels' preconditions.
+    ``groups`` > 1: w is the dense block-diagonal bank of a grouped convolution (plain data gradient only: no gate, no formed-on-load operand)."""
+    if groups > 1 and (gate is not None or isinstance(dy, LazyGrad) or isinstance(addend, StridedGrad)):
+        raise _lib.SsvError("conv2d_dgrad: the grouped data gradient takes no gate / lazy operand")
     lazy = dy if isinstance(dy, LazyGrad) else None
     if lazy is not None:
         dy = lazy.g
@@ -300,7 +308,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
         gate = None
     lib = _lib.load()
     n = dy.shape[0]
-    if (lazy is None and addend is None and out is None and (gate is None or gate.x2 is None)
+    if (lazy is None and addend is None and out is None and (gate is None or gate.x2 is None) and groups == 1
             and use_winograd((c, k, r, s_), stride, pad, dy.shape, False)):
         return wino_conv2d_dgrad(dy, w, gate=gate)
     chunks = _batch_chunks(n, (dy[0].numel(), dx[0].numel()))
@@ -339,6 +347,8 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
                 st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy, second)
                 call("ssv_conv2d_fwd_gated", C.byref(d), ptr(dyc), ptr(wt), ptr(adc), ptr(dxc), C.byref(st), stream())
                 parts.append(part)
+            elif groups > 1:          # the transposed bank is block-diagonal too (input and output channels of a group change places)
+                call("ssv_conv2d_fwd_grouped", C.byref(d), int(groups), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
             else:
                 call("ssv_conv2d_fwd", C.byref(d), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
         else:
@@ -348,6 +358,8 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
                 st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
                 call("ssv_conv2d_dgrad_gated", C.byref(d), ptr(dyc), ptr(w), ptr(adc), ptr(dxc), C.byref(st), stream())
                 parts.append(part)
+            elif groups > 1:
+                call("ssv_conv2d_dgrad_grouped", C.byref(d), int(groups), ptr(dyc), ptr(w), ptr(adc), ptr(dxc), stream())
             else:
                 call("ssv_conv2d_dgrad", C.byref(d), ptr(dyc), ptr(w), ptr(adc), ptr(dxc), stream())
     if parts:
@@ -358,10 +370,23 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     return dx
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None):
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None, groups=1):
     """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI).  ``in_affine = (scale, shift)``: x is a raw conv output and
     the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation).  ``wino_v``: the transformed
-    input the Winograd forward of this convolution kept - the weight gradient is then 16 batched GEMMs on it (x / in_affine are not read)."""
+    input the Winograd forward of this convolution kept - the weight gradient is then 16 batched GEMMs on it (x / in_affine are not read).
+    ``groups`` > 1: ``dw`` is the dense block-diagonal layout of a grouped convolution's bank and ONLY its diagonal blocks are defined afterwards
+    (what group_extract reads); tiles no group touches are skipped."""
+    if groups > 1:
+        if isinstance(dy, LazyGrad) or in_affine is not None or wino_v is not None:
+            raise _lib.SsvError("conv2d_wgrad: the grouped weight gradient takes plain operands")
+        _lib._dev(x, dy, dw)
+        _, wshape = _ohwi(w_like)
+        lib = _lib.load()
+        for i, (n0, n1) in enumerate(_batch_chunks(x.shape[0], (x[0].numel(), dy[0].numel()))):
+            d = conv_desc(x[n0:n1].shape, wshape, stride, pad)
+            ws = workspace.get(lib.ssv_conv2d_wgrad_grouped_workspace_bytes(C.byref(d), int(groups)), x.device)
+            call("ssv_conv2d_wgrad_grouped", C.byref(d), int(groups), ptr(x[n0:n1]), ptr(dy[n0:n1]), ptr(dw), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
+        return dw
     if wino_v is not None and not isinstance(dy, LazyGrad):
         return wino_conv2d_wgrad(wino_v, dy, w_like, dw, accumulate=accumulate)
     lazy = dy if isinstance(dy, LazyGrad) else None

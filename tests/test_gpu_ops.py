@@ -80,6 +80,56 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     close(nchw(yb.cpu()), y + bias.cpu().view(1, -1, 1, 1), what="conv fwd bias")
 
 
+GROUPED_CASES = [
+    # N, H, W, C, K, groups, stride       (3x3, padding 1: conv3x3(groups = 32) of the ResNeXt bottlenecks, networks/resnet.py:8-10,57)
+    (4, 12, 12, 128, 128, 32, 1),      # 32x4d layer1: 4 channels per group
+    (3, 10, 10, 256, 256, 32, 2),      # first unit of layer2: stride 2 (parity-class data gradient)
+    (2, 7, 7, 512, 512, 32, 1),        # 16 per group
+    (2, 6, 6, 1024, 1024, 32, 1),      # 32 per group
+    (2, 9, 9, 128, 256, 32, 1),        # 4 in, 8 out per group: the spans differ
+    (2, 8, 8, 192, 192, 3, 1),         # groups that straddle the 64-column tiles
+]
+
+
+@pytest.mark.parametrize("case", GROUPED_CASES)
+def test_grouped_conv_on_its_block_diagonal_bank(dev, case):
+    """The group-aware entry points (every tile contracts over the channels of its own groups only) against torch's grouped convolution in fp64,
+    and against the plain dense kernels on the same block-diagonal bank: forward and data gradient bit for bit (the skipped products are
+    exact zeros), weight gradient on the diagonal blocks (the only entries the grouped form defines)."""
+    from ssv_amd import ops
+    n, h, w, c, k, g, st = case
+    cg = c // g
+    x = seeded_randn(41, n, c, h, w).double().requires_grad_()
+    wg = (seeded_randn(42, k, cg, 3, 3) / (cg * 9) ** 0.5).double().requires_grad_()
+    y = F.conv2d(x, wg, stride=st, padding=1, groups=g)
+    dy = seeded_randn(43, *y.shape).double()
+    y.backward(dy)
+    xd, dyd = nhwc(x.detach().float()).to(dev), nhwc(dy.float()).to(dev)
+    wgd = wg.detach().float().contiguous(memory_format=torch.channels_last).to(dev)
+    bank = ops.group_expand(wgd, g)
+    assert tuple(bank.shape) == (k, c, 3, 3)
+    yg, yd = ops.conv2d_fwd(xd, bank, st, 1, groups=g), ops.conv2d_fwd(xd, bank, st, 1)
+    close(nchw(yg.cpu()), y, what="grouped fwd")
+    assert torch.equal(yg, yd)
+    add = seeded_randn(44, *xd.shape).to(dev)
+    dxg = ops.conv2d_dgrad(dyd, bank, xd.shape, st, 1, addend=add, groups=g)
+    dxd = ops.conv2d_dgrad(dyd, bank, xd.shape, st, 1, addend=add)
+    close(nchw(dxg.cpu()), x.grad + nchw(add.cpu()).double(), what="grouped dgrad")
+    assert torch.equal(dxg, dxd)
+    dbank = torch.full_like(bank, float("nan"))             # whatever the skipped tiles leave behind must never be read
+    ops.conv2d_wgrad(xd, dyd, bank, dbank, st, 1, accumulate=False, groups=g)
+    dwg = torch.zeros_like(wgd)
+    ops.group_extract(dbank, dwg, g, accumulate=False)
+    close(dwg.cpu(), wg.grad, what="grouped wgrad")
+    ddense = torch.zeros_like(bank)
+    ops.conv2d_wgrad(xd, dyd, bank, ddense, st, 1, accumulate=False)
+    dwg2 = torch.zeros_like(wgd)
+    ops.group_extract(ddense, dwg2, g, accumulate=False)
+    close(dwg, dwg2.cpu(), rtol=1e-5, what="grouped vs dense wgrad")
+    with pytest.raises(Exception):
+        ops.conv2d_fwd(xd, bank, st, 1, groups=7)           # groups must divide C and K
+
+
 @pytest.mark.parametrize("case", [(2, 20, 20, 3, 64, 7, 2, 3), (3, 12, 12, 3, 64, 3, 1, 1), (2, 11, 13, 3, 64, 7, 2, 3)])
 def test_stem_conv_generic_gather(dev, case):
     from ssv_amd import ops
