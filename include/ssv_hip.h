@@ -162,6 +162,11 @@ int ssv_conv2d_dgrad(const ssv_conv_desc* d, const float* dy, const float* w, co
 size_t ssv_conv2d_wgrad_workspace_bytes(const ssv_conv_desc* d);
 int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dw,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* weight AND bias gradient of a Linear / 1x1 / stride-1 / unpadded layer in one pass over dy (nn.Linear backward: dw (+)= dy^T x, dbias (+)= column sums
+ * of dy): the weight-gradient workgroups of column tile 0 also sum the dy rows they stage; fixed-order reduction.  C % 4 == 0, K % 4 == 0. */
+size_t ssv_conv2d_wgrad_bias_workspace_bytes(const ssv_conv_desc* d);
+int ssv_conv2d_wgrad_bias(const ssv_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* ---- the 3-channel image stem on the unpadded image (networks/resnet.py:96-99,147: conv7x7/2 or conv3x3/1 on [B,3,H,W]) -------------------------
  * Row-taps form: for one filter row the S taps x 3 channels of an output pixel are 3 S contiguous floats of the NHWC image row, so the

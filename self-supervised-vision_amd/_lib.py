@@ -76,6 +76,8 @@ SIGNATURES = {
     "ssv_conv2d_wgrad_grouped_workspace_bytes": (_sz, [_cd, _i32]),
     "ssv_conv2d_wgrad_grouped": (C.c_int, [_cd, _i32, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_conv2d_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_conv2d_wgrad_bias_workspace_bytes": (_sz, [_cd]),
+    "ssv_conv2d_wgrad_bias": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_stem_conv_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_stem_conv_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_stem_conv_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _sz, _vp]),

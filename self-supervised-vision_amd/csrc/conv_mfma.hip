@@ -1108,7 +1108,9 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // XF: x is the producer's RAW conv output; the X operand is relu(x * xf_scale[c] + xf_shift[c]) (the activation the forward never
 //     materialised), formed on the way into LDS.  A thread's four channels are loop constants, so are its scale / shift registers.
 // DYF (LIN gather only): the dY operand is formed on load from (g, x of the BatchNorm behind this convolution, coefficients) - see conv_fwd_k.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false>
+// BIAS (LIN gather): the workgroups of column tile 0 also sum the dY rows they stage - the bias gradient's column sums, one partial row per split
+//       (p.aux_out [nsplit][K]), reduced with the weight gradient's slabs in the same fixed order: the stand-alone column-sum pass over dY disappears.
+template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false, bool BIAS = false>
 __global__ void __launch_bounds__(256)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -1163,6 +1165,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * p.C * 4u);
   int mcur = ms;
   f32x4 ra[AP];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};          // BIAS: this thread's four dY columns summed over the rows it stages
   f32x4 rbv[VECB ? BP : 1];
   float rbs[VECB ? 1 : BP];
   int avoff[AP], bvoff[BP];
@@ -1320,6 +1323,12 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
+    if constexpr (BIAS) {
+      if (jt == 0) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) bsum += ra[i];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       if constexpr (GATHER == 3) {
@@ -1331,6 +1340,21 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   };
   k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
 
+  if constexpr (BIAS) {
+    static_assert(STAGE >= (256 / (BM / 4)) * BM, "the bias partials are folded through the stage buffer");
+    if (jt == 0) {               // uniform: fold the ARP row groups of each column in fixed order, one partial row per split
+      __syncthreads();
+      *reinterpret_cast<f32x4*>(&smem[arow * BM + acol]) = bsum;
+      __syncthreads();
+      if (tid < BM && i0 + tid < p.K) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < ARP; ++r) t += smem[r * BM + tid];
+        p.aux_out[(size_t)split * p.K + i0 + tid] = t;
+      }
+      __syncthreads();
+    }
+  }
   float* out = partial + (size_t)split * p.K * NCOL;
   if ((NCOL & 3) == 0) {       // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
     const int rbase = i0 + wr0;
@@ -1850,7 +1874,23 @@ extern "C" int ssv_conv2d_wgrad(const ssv_conv_desc* d, const float* x, const fl
 
 namespace {
 int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy, const ssv_bn_dyin* dyin,
-               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream, int groups = 0);
+               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream, int groups = 0, float* dbias = nullptr);
+}
+// Weight AND bias gradient of a Linear / 1x1 / stride-1 / unpadded layer in one pass over dY (nn.Linear backward: dW = dY^T X, db = column sums
+// of dY): the weight-gradient workgroups of column tile 0 sum the dY rows they stage anyway.  C % 4 == 0, K % 4 == 0.
+extern "C" size_t ssv_conv2d_wgrad_bias_workspace_bytes(const ssv_conv_desc* d) {
+  if (!d || d->K <= 0 || d->C <= 0) return 0;
+  const WgradPlan w = plan_wgrad(d);
+  return (size_t)w.nsplit * d->K * ((size_t)d->R * d->S * d->C + 1) * sizeof(float);
+}
+extern "C" int ssv_conv2d_wgrad_bias(const ssv_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(d && dbias, "ssv_conv2d_wgrad_bias: null pointer");
+  SSV_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K % 4 == 0 && d->C % 4 == 0,
+              "ssv_conv2d_wgrad_bias: a 1x1 / stride-1 / unpadded layer with K %% 4 == 0 and C %% 4 == 0 (got R=%d stride=%d pad=%d K=%d C=%d)",
+              d->R, d->stride, d->pad, d->K, d->C);
+  SSV_REQUIRE(((uintptr_t)dbias & 15) == 0, "ssv_conv2d_wgrad_bias: pointers must be 16-byte aligned");
+  return wgrad_impl(d, x, nullptr, nullptr, dy, nullptr, dw, accumulate, ws, ws_bytes, stream, 0, dbias);
 }
 // Weight gradient of a grouped convolution in the layout of its dense block-diagonal bank, dwd [K][R][S][C]: ONLY the diagonal blocks (the entries
 // ssv_group_extract reads) are defined - tiles that no group touches are skipped and their entries are whatever the workspace held.
@@ -1877,7 +1917,7 @@ extern "C" int ssv_conv2d_wgrad_dyin(const ssv_conv_desc* d, const float* x, con
 
 namespace {
 int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* dy, const ssv_bn_dyin* dyin,
-               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream, int groups) {
+               float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream, int groups, float* dbias) {
   if (int rc = check_desc(d, "ssv_conv2d_wgrad")) return rc;
   SSV_REQUIRE(x && dy && dw && ws, "ssv_conv2d_wgrad: null pointer");
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0, "ssv_conv2d_wgrad: pointers must be 16-byte aligned");
@@ -1886,7 +1926,8 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   const bool xf = in_scale != nullptr;
   SSV_REQUIRE(!xf || d->C % 4 == 0, "ssv_conv2d_wgrad: a fused input needs C %% 4 == 0 (got C=%d)", d->C);
   const WgradPlan wp = plan_wgrad(d, groups);
-  const size_t need = (size_t)wp.nsplit * d->K * d->R * d->S * d->C * sizeof(float);
+  const size_t slabs = (size_t)wp.nsplit * d->K * d->R * d->S * d->C * sizeof(float);
+  const size_t need = slabs + (dbias ? (size_t)wp.nsplit * d->K * sizeof(float) : 0);      // bias partials [nsplit][K] behind the slabs
   if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_WGRAD, s);
@@ -1894,6 +1935,7 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   p.xf_scale = in_scale; p.xf_shift = in_shift;
   if (dyin) { p.dyin_x = dyin->x; p.dyin_coef = dyin->coef; }
   if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
+  if (dbias) p.aux_out = (float*)((char*)ws + slabs);
   const bool vecb = d->C % 4 == 0;
   const int tiles = wp.it * wp.jt;
   const dim3 grid((unsigned)(tiles * wp.nsplit));
@@ -1908,7 +1950,12 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
 #define WG_GATHER(BM_, BN_, WM_, WN_, X_) \
   do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 1, X_); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 2, X_); \
        else WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 0, X_); } while (0)
-  if (dyin) {                                      // preconditions checked by ssv_conv2d_wgrad_dyin: LIN gather, float4 columns
+#define WG_BIAS(BM_, BN_, WM_, WN_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false, false, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+  if (dbias) {                                     // preconditions checked by ssv_conv2d_wgrad_bias: LIN gather, float4 columns
+    if (wp.bm == 128) { if (wp.bn == 64) WG_BIAS(128, 64, 2, 2); else WG_BIAS(128, 128, 2, 2); }
+    else              { if (wp.bn == 64) WG_BIAS(64, 64, 2, 2);  else WG_BIAS(64, 128, 1, 4); }
+  } else if (dyin) {                                      // preconditions checked by ssv_conv2d_wgrad_dyin: LIN gather, float4 columns
     if (wp.bm == 128) {
       if (wp.bn == 64) { if (xf) WG_DYIN(128, 64, 2, 2, true); else WG_DYIN(128, 64, 2, 2, false); }
       else             { if (xf) WG_DYIN(128, 128, 2, 2, true); else WG_DYIN(128, 128, 2, 2, false); }
@@ -1929,11 +1976,16 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   }
 #undef WG_GATHER
 #undef WG_DYIN
+#undef WG_BIAS
 #undef WG_LAUNCH
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(partial)");
   const int64_t n = (int64_t)d->K * p.RSC;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, accumulate);
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(reduce)");
+  if (dbias) {
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(d->K, 64)), dim3(256), 0, s, (const float*)p.aux_out, wp.nsplit, (int64_t)d->K, dbias, accumulate);
+    SSV_CHECK_LAUNCH("ssv_conv2d_wgrad_bias(reduce)");
+  }
   return SSV_OK;
 }
 }  // namespace

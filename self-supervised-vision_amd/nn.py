@@ -387,9 +387,8 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
         wino_v = y.__dict__.pop("_wino_v", None)       # Winograd forward: its transformed input is the weight gradient's operand
 
         def bwd(dy, existing):
-            ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine, wino_v=wino_v)
-            if bias is not None:
-                ops.colsum(dy, grad_of(bias, slot), accumulate=True)
+            ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine, wino_v=wino_v,
+                             dbias=None if bias is None else grad_of(bias, slot))
             if not need_dx:
                 return (None,)
             ex = existing[0]
@@ -637,9 +636,7 @@ def linear(tape, x, weight, bias, addend=None):
 
         def bwd(dy, existing):
             dy4 = dy.view(b, 1, 1, -1)
-            ops.conv2d_wgrad(x4, dy4, weight, grad_of(weight, slot), 1, 0, accumulate=True)
-            if bias is not None:
-                ops.colsum(dy, grad_of(bias, slot), accumulate=True)
+            ops.conv2d_wgrad(x4, dy4, weight, grad_of(weight, slot), 1, 0, accumulate=True, dbias=None if bias is None else grad_of(bias, slot))
             dadd = None if addend is None else _accum(existing[1], dy)      # pass-through (dy is not needed again by its producer)
             if not need_dx:
                 return (None, dadd)
@@ -688,12 +685,10 @@ def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
 
         def bwd(dy, existing):
             dy4 = dy.view(m, 1, 1, -1)
-            ops.conv2d_wgrad(act.view(m, 1, 1, inter), dy4, w2, grad_of(w2, slot), 1, 0, accumulate=True)
-            ops.colsum(dy, grad_of(b2, slot), accumulate=True)
+            ops.conv2d_wgrad(act.view(m, 1, 1, inter), dy4, w2, grad_of(w2, slot), 1, 0, accumulate=True, dbias=grad_of(b2, slot))
             dh = ops.linear_dgrad_gelu(dy, w2, h)
             x4, dh4 = x.view(m, 1, 1, din), dh.view(m, 1, 1, inter)
-            ops.conv2d_wgrad(x4, dh4, w1, grad_of(w1, slot), 1, 0, accumulate=True)
-            ops.colsum(dh, grad_of(b1, slot), accumulate=True)
+            ops.conv2d_wgrad(x4, dh4, w1, grad_of(w1, slot), 1, 0, accumulate=True, dbias=grad_of(b1, slot))
             dadd = None if addend is None else _accum(existing[1], dy)
             if not need_dx:
                 return (None, dadd)

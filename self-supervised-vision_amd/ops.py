@@ -370,12 +370,33 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     return dx
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None, groups=1):
+FUSE_BIAS_GRAD = os.environ.get("SSV_NO_BIAS_GRAD_FUSION", "0") != "1"      # diagnostic switch: bias gradients by the stand-alone column-sum pass
+
+
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None, groups=1, dbias=None):
     """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI).  ``in_affine = (scale, shift)``: x is a raw conv output and
     the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation).  ``wino_v``: the transformed
     input the Winograd forward of this convolution kept - the weight gradient is then 16 batched GEMMs on it (x / in_affine are not read).
     ``groups`` > 1: ``dw`` is the dense block-diagonal layout of a grouped convolution's bank and ONLY its diagonal blocks are defined afterwards
-    (what group_extract reads); tiles no group touches are skipped."""
+    (what group_extract reads); tiles no group touches are skipped.
+    ``dbias``: the layer's bias gradient, (+)= the column sums of dy - taken from the same pass over dy when the layer is a Linear / 1x1 / stride-1
+    one (the weight-gradient workgroups of column tile 0 sum the rows they stage), by the stand-alone column-sum kernel otherwise."""
+    if dbias is not None:
+        _, wsh = _ohwi(w_like)
+        fused = (FUSE_BIAS_GRAD and groups == 1 and wino_v is None and in_affine is None and not isinstance(dy, LazyGrad)
+                 and wsh[2] == 1 and wsh[3] == 1 and stride == 1 and pad == 0 and wsh[0] % 4 == 0 and wsh[1] % 4 == 0)
+        if isinstance(dy, LazyGrad):
+            raise _lib.SsvError("conv2d_wgrad: a bias gradient needs the materialised output gradient (a biased convolution is never followed by a fused BatchNorm)")
+        if not fused:
+            colsum(dy, dbias, accumulate=accumulate)
+            return conv2d_wgrad(x, dy, w_like, dw, stride, pad, accumulate, in_affine, wino_v, groups)
+        _lib._dev(x, dy, dw, dbias)
+        lib = _lib.load()
+        for i, (n0, n1) in enumerate(_batch_chunks(x.shape[0], (x[0].numel(), dy[0].numel()))):
+            d = conv_desc(x[n0:n1].shape, wsh, stride, pad)
+            ws = workspace.get(lib.ssv_conv2d_wgrad_bias_workspace_bytes(C.byref(d)), x.device)
+            call("ssv_conv2d_wgrad_bias", C.byref(d), ptr(x[n0:n1]), ptr(dy[n0:n1]), ptr(dw), ptr(dbias), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
+        return dw
     if groups > 1:
         if isinstance(dy, LazyGrad) or in_affine is not None or wino_v is not None:
             raise _lib.SsvError("conv2d_wgrad: the grouped weight gradient takes plain operands")

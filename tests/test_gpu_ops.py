@@ -80,6 +80,30 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     close(nchw(yb.cpu()), y + bias.cpu().view(1, -1, 1, 1), what="conv fwd bias")
 
 
+@pytest.mark.parametrize("m,c,k", [(300, 384, 1152), (4100, 64, 128), (130, 1536, 384), (97, 128, 48), (37888, 384, 384)])
+def test_linear_weight_and_bias_gradient_in_one_pass(dev, m, c, k):
+    """nn.Linear backward: dW = dY^T X and db = column sums of dY from ONE pass over dY (ssv_conv2d_wgrad_bias) - against fp64, against the
+    stand-alone column-sum kernel, accumulating, and repeatable bit for bit (fixed-order reduction)."""
+    from ssv_amd import ops
+    x, dy = seeded_randn(51, m, c), seeded_randn(52, m, k)
+    w = torch.empty(k, c, 1, 1).contiguous(memory_format=torch.channels_last).to(dev)
+    xd, dyd = x.to(dev).view(m, 1, 1, c), dy.to(dev).view(m, 1, 1, k)
+    dw, db = torch.zeros_like(w), torch.zeros(k, device=dev)
+    assert ops.FUSE_BIAS_GRAD
+    ops.conv2d_wgrad(xd, dyd, w, dw, 1, 0, accumulate=False, dbias=db)
+    close(dw.view(k, c).cpu(), dy.double().t() @ x.double(), what="dW")
+    close(db.cpu(), dy.double().sum(0), what="db")
+    ref = torch.zeros(k, device=dev)
+    ops.colsum(dyd, ref, accumulate=False)
+    close(db, ref.cpu(), rtol=1e-5, what="db vs column-sum kernel")
+    dw2, db2 = torch.zeros_like(w), torch.zeros(k, device=dev)
+    ops.conv2d_wgrad(xd, dyd, w, dw2, 1, 0, accumulate=False, dbias=db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    ops.conv2d_wgrad(xd, dyd, w, dw2, 1, 0, accumulate=True, dbias=db2)
+    close(db2.cpu(), 2 * dy.double().sum(0), what="db accumulate")
+    close(dw2.view(k, c).cpu(), 2 * (dy.double().t() @ x.double()), what="dW accumulate")
+
+
 GROUPED_CASES = [
     # N, H, W, C, K, groups, stride       (3x3, padding 1: conv3x3(groups = 32) of the ResNeXt bottlenecks, networks/resnet.py:8-10,57)
     (4, 12, 12, 128, 128, 32, 1),      # 32x4d layer1: 4 channels per group
