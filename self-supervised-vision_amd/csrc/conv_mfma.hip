@@ -1483,6 +1483,8 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
   const bool wide = d->K >= 128 && groups <= 1;               // block-diagonal banks: the 64-column tile sees the fewest foreign groups
+  // (1x1 layers with few k-tiles - 64 -> 256 at 56x56 runs at 2.7 TB/s and 69 TFLOP/s, the SUM of its MFMA and HBM times - were tried on a 128 x 64 tile
+  //  at 4 / 5 workgroups per CU and on a 64 x 256 tile writing whole 1 KB rows: no change, r03 x3)
   const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
   if (gate) {                                                  // C % 32 == 0 checked by the caller
     p.gate = *gate;
