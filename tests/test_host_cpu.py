@@ -136,3 +136,39 @@ def test_batch_chunks_alignment_and_its_error():
         ops._batch_chunks(40, (per, per // 2), rows_per_sample=49)           # odd rows per sample: q = 64 > 9
     with pytest.raises(_lib.SsvError, match="single sample"):
         ops._batch_chunks(2, (lim + 5, 10))
+
+
+def test_dispatch_predicates_of_the_round3_paths():
+    """Host logic that decides which kernel family a layer runs on (no compute): Winograd F(2x2, 3x3) only for 3x3 / stride 1 / padding 1 layers with
+    >= 128 channels on both sides and enough tiles (networks/resnet.py:7-10,56-58: conv2 of ten ResNet-50 units), the row-taps stem only for a
+    3-channel input with at most 8 taps per filter row (networks/resnet.py:96-99), the fused Linear backward only for 1x1 / stride-1 layers."""
+    from ssv_amd import ops
+    wino = lambda c, k, r, st, pad, shape: ops.use_winograd((k, c, r, r), st, pad, shape, False)
+    assert wino(128, 128, 3, 1, 1, (512, 28, 28, 128)) and wino(256, 256, 3, 1, 1, (512, 14, 14, 256)) and wino(512, 512, 3, 1, 1, (512, 7, 7, 512))
+    assert not wino(64, 64, 3, 1, 1, (512, 56, 56, 64))            # layer1: HBM-heavy, measured slower (profiles/r03_probe_winograd.txt)
+    assert not wino(128, 128, 3, 2, 1, (512, 56, 56, 128))         # stride 2
+    assert not wino(128, 128, 1, 1, 0, (512, 28, 28, 128))         # 1x1
+    assert not wino(128, 128, 3, 1, 1, (2, 8, 8, 128))             # 32 tiles: not worth three extra launches
+    assert not wino(144, 144, 3, 1, 1, (512, 28, 28, 144))         # a channel count the transforms' lane mapping does not take
+    prev = ops.WINOGRAD
+    ops.WINOGRAD = False
+    try:
+        assert not wino(256, 256, 3, 1, 1, (512, 14, 14, 256))
+    finally:
+        ops.WINOGRAD = prev
+    assert ops.can_row_stem((64, 3, 7, 7)) and ops.can_row_stem((64, 3, 3, 3))
+    assert not ops.can_row_stem((64, 4, 7, 7)) and not ops.can_row_stem((64, 3, 11, 11)) and not ops.can_row_stem((62, 3, 7, 7))
+    assert ops.can_form_closing_sum((64, 256, 1, 1), 1, 0) and not ops.can_form_closing_sum((64, 256, 3, 3), 1, 1)
+    assert not ops.can_form_closing_sum((64, 256, 1, 1), 1, 0, groups=32)
+
+
+def test_host_run_ahead_helpers_are_inert_without_a_gpu():
+    """hnn.early_item / hnn.input_stream (the host runs one step ahead of the GPU) fall back to the plain forms on the CPU: .item(), ambient stream."""
+    from ssv_amd import nn as hnn
+    t = torch.tensor(3.25)
+    e = hnn.early_item(t)
+    assert e.ev is None and e.get() == 3.25
+    with hnn.input_stream(torch.device("cpu")) as ins:
+        assert not ins.enabled
+        ins.publish(t, None, 5)
+    assert hnn.input_stream("cpu").enabled is False
