@@ -476,7 +476,9 @@ def main():
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, %s)" % (os.path.relpath(pmc_path, ROOT) if traffic is not None else "no PMC pass for this workload"),
                 "algorithmic_gb_per_step": family_gb if family_gb is not None else (None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1)),
-                "algorithmic_gb_note": ("every operand stream of the family's kernels moved once, fused BatchNorm operands included (%s)" % family_src) if family_gb is not None
+                "algorithmic_gb_note": ("every operand stream of the family's kernels moved once, fused BatchNorm operands included (%s); the transformed-domain "
+                                        "tensors of the Winograd layers (V, M, transformed gradients: ~150 GB/step at bs 512 - bytes traded for 2.25x fewer multiplies, "
+                                        "DESIGN 4.4) are in `traffic` but NOT in this figure" % family_src) if family_gb is not None
                                        else "conv operands only (x, w, y once per product): the fused BatchNorm streams these kernels also carry are NOT in this figure",
                 "conv_operands_only_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
                 # whole step: PMC traffic of ALL kernels against SURVEY 8(d)'s streaming model (1.067 GB / sample: 12 fp32 accesses per conv-output element)
