@@ -383,7 +383,13 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   if (bias && cok) b4 = *reinterpret_cast<const f32x4*>(bias + gcol);
 
   const bool ADD = addend != nullptr;            // uniform
-  {
+  // The row loop exists twice - with and without the addend loads - and the uniform branch picks one: gfx9 counts loads and stores on ONE in-order
+  // counter, so waiting for ANY load issued after a store also waits for that store to drain.  With the addend test inside the loop the compiler put an
+  // s_waitcnt vmcnt(0) at every join, and an epilogue WITHOUT an addend (every forward convolution, the Winograd products, the weight gradients)
+  // stored four rows, waited for them to reach memory, stored the next four ...  The copy without loads has nothing to wait for (found while looking
+  // for what makes a 64 -> 256 1x1 layer take the SUM of its MFMA and HBM times, r03 x3 - it was not this: the layer times did not move).
+  auto rows = [&](auto add_tag) {
+    constexpr bool ADDC = decltype(add_tag)::value;
     constexpr bool ADD_SAME = std::is_same<AddOff, SameOff>::value;
     const rsrc_t r_add = make_rsrc(ADD ? addend : out, ADD_SAME ? bytes : (unsigned)(add_elems * 4));
     const rsrc_t r_gx = make_rsrc(GATE != 0 ? bn->x : out, bytes);
@@ -413,7 +419,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
             const long long ao = add_off(tm * 32 + (q0 + i) * RPI + r_in);
             aoff = (ao >= 0 && voff[i] != OOB_OFF) ? (int)(ao + gcol) * 4 : OOB_OFF;
           }
-          if (ADD) av[i] = bload4(r_add, aoff, 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (ADDC) av[i] = bload4(r_add, aoff, 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == 2) gv[i] = bload4(r_gate, voff[i], 0);
           if constexpr (GATE != 0) xv[i] = bload4(r_gx, voff[i], 0);
           if constexpr (GMASK) mb[i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[i] == OOB_OFF ? OOB_OFF : voff[i] >> 4, 0, 0);
@@ -461,7 +467,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
         }
       }
     }
-  }
+  };
+  if (ADD) rows(std::true_type{}); else rows(std::false_type{});
 
   if constexpr (STATS) {
 #pragma unroll
@@ -1484,7 +1491,7 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
   const bool wide = d->K >= 128 && groups <= 1;               // block-diagonal banks: the 64-column tile sees the fewest foreign groups
   // (1x1 layers with few k-tiles - 64 -> 256 at 56x56 runs at 2.7 TB/s and 69 TFLOP/s, the SUM of its MFMA and HBM times - were tried on a 128 x 64 tile
-  //  at 4 / 5 workgroups per CU and on a 64 x 256 tile writing whole 1 KB rows: no change, r03 x3)
+  //  at 4 / 5 workgroups per CU, on a 64 x 256 tile writing whole 1 KB rows and as a persistent kernel that loads its next tile under the epilogue: no change, r03 x3)
   const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
   if (gate) {                                                  // C % 32 == 0 checked by the caller
     p.gate = *gate;
