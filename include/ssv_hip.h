@@ -399,6 +399,7 @@ int ssv_layernorm_bwd(int64_t M, int32_t C, const float* dy, const float* x, con
 /* Feedforward.fc1 + nn.GELU in one pass (networks/vit.py:42,45): h = x w^T + bias and act = gelu(h), both written by the GEMM
  * epilogue (h is kept for the backward); and the matching backward of fc2: dx = (dy w) * gelu'(h) (+ addend).  Linear layers only
  * (H = W = R = S = 1); forward: C % 32 == 0, K >= 128; dgrad: K % 32 == 0, C >= 128. */
+/* h == NULL: only act is written (a forward nobody differentiates: the teacher / target passes) */
 int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* h, float* act, void* stream);
 int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, const float* w, const float* h, const float* addend,
                           float* dx, void* stream);

@@ -341,7 +341,8 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 // w.r.t. the OUTPUT of a BatchNorm (+ residual) + ReLU whose input x is bn.x.  The value stored is g = relu'(.) * (acc + addend), and
 // the wave leaves, per column, the two sums the BatchNorm backward needs over its rows - sum g and sum g * xhat - as one partial
 // (bn.psum_g / bn.psum_gx row `group`): the backward's reduction pass over (dy, mask, x) disappears, at the price of reading x here.
-// EPI: 1 = also write gelu(v) to out_act (Linear + GELU forward), 2 = multiply by gelu'(gate) before the addend (its backward).
+// EPI: 1 = also write gelu(v) to out_act (Linear + GELU forward), 2 = multiply by gelu'(gate) before the addend (its backward),
+//      3 = write gelu(v) ONLY (the same forward when no backward will ask for the pre-activation).
 __device__ __forceinline__ void bstore4(rsrc_t rs, int voff_bytes, f32x4 v) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, voff_bytes, 0, 0);
@@ -456,6 +457,10 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
             st_s1 += gvv;
             st_s2 += gvv * ((xv[i] - g_mu) * g_is);
             if constexpr (GX2) st_s3 += gvv * ((xv2[i] - g_mu2) * g_is2);      // an out-of-range row has gvv == 0 (mask byte 0)
+          }
+          if constexpr (EPI == 3) {          // Linear + GELU where only the activation is wanted (a forward without a backward): one store
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
           }
           bstore4(r_out, voff[i], v);
           if constexpr (EPI == 1) {
@@ -1732,7 +1737,7 @@ extern "C" int ssv_conv2d_fwd_bnrelu_in_stats(const ssv_conv_desc* d, const floa
 // epilogue; and its counterpart, dgrad with the GELU derivative applied to the product before the addend.
 extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* h, float* act, void* stream) {
   if (int rc = check_desc(d, "ssv_linear_gelu_fwd")) return rc;
-  SSV_REQUIRE(x && w && h && act, "ssv_linear_gelu_fwd: null pointer");
+  SSV_REQUIRE(x && w && act, "ssv_linear_gelu_fwd: null pointer");      // h == NULL: the pre-activation is not kept (no backward will read it)
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)h | (uintptr_t)act) & 15) == 0, "ssv_linear_gelu_fwd: pointers must be 16-byte aligned");
   SSV_REQUIRE(d->C % 32 == 0 && d->K >= 128 && d->K % 4 == 0, "ssv_linear_gelu_fwd: needs C %% 32 == 0, K >= 128, K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
   hipStream_t s = (hipStream_t)stream;
@@ -1741,7 +1746,8 @@ extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const
   p.aux_out = act;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
   // K-step 32 only: its LDS stage is what the vectorised epilogue (the one that writes the second tensor) needs
-  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 1>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
+  if (h) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 1>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
+  else   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 3>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, act);
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
   return SSV_OK;
 }

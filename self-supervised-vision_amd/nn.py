@@ -676,7 +676,7 @@ def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
     inter = w1.shape[0]
     if din % 32 or inter < 128 or inter % 32 or w2.shape[0] % 32 or b1 is None or b2 is None:
         return linear(tape, gelu(tape, linear(tape, x, w1, b1)), w2, b2, addend)
-    h, act = ops.linear_gelu_fwd(x, w1, b1)
+    h, act = ops.linear_gelu_fwd(x, w1, b1, keep_h=tape is not None)        # the teacher's pass keeps no pre-activation
     a4 = None if addend is None else addend.view(m, 1, 1, -1)
     y = ops.conv2d_fwd(act.view(m, 1, 1, inter), w2, 1, 0, bias=b2, addend=a4).view(m, w2.shape[0])
     if tape is not None:

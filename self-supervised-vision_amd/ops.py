@@ -900,14 +900,15 @@ def queue_push(bank, queue_size, pointer, keys, eps=1e-12):
     return (pointer + keys.shape[0]) % queue_size
 
 
-def linear_gelu_fwd(x, w, bias):
-    """(h, gelu(h)) with h = x w^T + bias, both written by one GEMM epilogue.  x [M, C] dense, w [K, C]."""
+def linear_gelu_fwd(x, w, bias, keep_h=True):
+    """(h, gelu(h)) with h = x w^T + bias, both written by one GEMM epilogue.  x [M, C] dense, w [K, C].  ``keep_h`` False (a forward without
+    a backward): only gelu(h) is written and h comes back as None."""
     _lib._dev(x, w, bias)
     m, c = x.shape
     w, wshape = _ohwi(w)
     d = conv_desc((m, 1, 1, c), wshape, 1, 0)
-    h = _empty((m, wshape[0]), x)
-    act = torch.empty_like(h)
+    act = _empty((m, wshape[0]), x)
+    h = torch.empty_like(act) if keep_h else None
     call("ssv_linear_gelu_fwd", C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(h), ptr(act), stream())
     return h, act
 

@@ -196,6 +196,8 @@ def test_linear_gelu_epilogue_fusions(dev, m, c, k):
     h, act = ops.linear_gelu_fwd(x.to(dev), w.to(dev), b.to(dev))
     _close(h, href, 1e-5, 1e-5)
     _close(act, F.gelu(href), 1e-5, 1e-5)
+    none, act_only = ops.linear_gelu_fwd(x.to(dev), w.to(dev), b.to(dev), keep_h=False)      # a forward nobody differentiates: one store, same bits
+    assert none is None and torch.equal(act_only, act)
     hh = href.clone().requires_grad_()
     (F.gelu(hh) @ w2.double().t()).backward(dy.double())
     got = ops.linear_dgrad_gelu(dy.to(dev), w2.to(dev), h, addend=add.to(dev))
