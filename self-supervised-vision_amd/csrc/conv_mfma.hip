@@ -390,7 +390,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   // stored four rows, waited for them to reach memory, stored the next four ...  The copy without loads has nothing to wait for (found while looking
   // for what makes a 64 -> 256 1x1 layer take the SUM of its MFMA and HBM times, r03 x3 - it was not this: the layer times did not move).
   auto rows = [&](auto add_tag) {
-    constexpr bool ADDC = decltype(add_tag)::value;
+    constexpr int ADDM = decltype(add_tag)::value;      // 0 / 1: no addend / addend (compile time); 2: decided per launch by the uniform test (gated epilogues)
     constexpr bool ADD_SAME = std::is_same<AddOff, SameOff>::value;
     const rsrc_t r_add = make_rsrc(ADD ? addend : out, ADD_SAME ? bytes : (unsigned)(add_elems * 4));
     const rsrc_t r_gx = make_rsrc(GATE != 0 ? bn->x : out, bytes);
@@ -405,32 +405,39 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 #pragma unroll
         for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
       if constexpr (STATS) { if (tm == 0) st_p = *reinterpret_cast<const f32x4*>(&ep[c4 * 4]); }     // pivot: first row of the group
+      // Rows go through in steps of HB: a step issues its loads (addend, gate operands: in flight together), then computes and stores.  (Issuing the NEXT
+      // step's loads before this step's stores - so that waiting for them does not also wait for the stores on gfx9's single in-order counter - was
+      // measured level in the step, r03 e11, and is not built.)
+      constexpr int HP = HB;
+      constexpr int NSTEP = NP / HP;
+      int voff[1][HP];
+      f32x4 av[1][HP], xv[1][HP], gv[1][HP], xv2[1][GX2 ? HP : 1];
+      unsigned mb[1][HP];
+      auto issue = [&](int st, int sl) {
 #pragma unroll
-      for (int q0 = 0; q0 < NP; q0 += HB) {
-        __builtin_amdgcn_sched_barrier(0);       // one batch of rows in flight at a time (register budget of 3 workgroups per CU)
-        int voff[HB];
-        f32x4 av[HB], xv[HB], gv[HB], xv2[GX2 ? HB : 1];
-        unsigned mb[HB];
-#pragma unroll
-        for (int i = 0; i < HB; ++i) {
-          const long long off = row_off(tm * 32 + (q0 + i) * RPI + r_in);
-          voff[i] = (off >= 0 && cok) ? (int)(off + gcol) * 4 : OOB_OFF;        // tensors stay below 2^29 elements (check_desc)
-          int aoff = voff[i];
+        for (int i = 0; i < HP; ++i) {
+          const long long off = row_off(tm * 32 + (st * HP + i) * RPI + r_in);
+          voff[sl][i] = (off >= 0 && cok) ? (int)(off + gcol) * 4 : OOB_OFF;        // tensors stay below 2^29 elements (check_desc)
+          int aoff = voff[sl][i];
           if constexpr (!ADD_SAME) {
-            const long long ao = add_off(tm * 32 + (q0 + i) * RPI + r_in);
-            aoff = (ao >= 0 && voff[i] != OOB_OFF) ? (int)(ao + gcol) * 4 : OOB_OFF;
+            const long long ao = add_off(tm * 32 + (st * HP + i) * RPI + r_in);
+            aoff = (ao >= 0 && voff[sl][i] != OOB_OFF) ? (int)(ao + gcol) * 4 : OOB_OFF;
           }
-          if constexpr (ADDC) av[i] = bload4(r_add, aoff, 0); else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (EPI == 2) gv[i] = bload4(r_gate, voff[i], 0);
-          if constexpr (GATE != 0) xv[i] = bload4(r_gx, voff[i], 0);
-          if constexpr (GMASK) mb[i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[i] == OOB_OFF ? OOB_OFF : voff[i] >> 4, 0, 0);
-          if constexpr (GX2) xv2[i] = bload4(r_gx2, voff[i], 0);
+          if constexpr (ADDM == 2) { if (ADD) av[sl][i] = bload4(r_add, aoff, 0); else av[sl][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          else if constexpr (ADDM == 1) av[sl][i] = bload4(r_add, aoff, 0);
+          else av[sl][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == 2) gv[sl][i] = bload4(r_gate, voff[sl][i], 0);
+          if constexpr (GATE != 0) xv[sl][i] = bload4(r_gx, voff[sl][i], 0);
+          if constexpr (GMASK) mb[sl][i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[sl][i] == OOB_OFF ? OOB_OFF : voff[sl][i] >> 4, 0, 0);
+          if constexpr (GX2) xv2[sl][i] = bload4(r_gx2, voff[sl][i], 0);
         }
+      };
+      auto finish = [&](int st, int sl) {
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-          const int r = (q0 + i) * RPI + r_in;
+        for (int i = 0; i < HP; ++i) {
+          const int r = (st * HP + i) * RPI + r_in;
           f32x4 v = *reinterpret_cast<const f32x4*>(&ep[r * LDE + c4 * 4]);
-          const bool ok = voff[i] != OOB_OFF;
+          const bool ok = voff[sl][i] != OOB_OFF;
           if constexpr (STATS) {
             f32x4 dv = v - st_p;
             dv[0] = ok ? dv[0] : 0.f; dv[1] = ok ? dv[1] : 0.f; dv[2] = ok ? dv[2] : 0.f; dv[3] = ok ? dv[3] : 0.f;
@@ -439,41 +446,52 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
           v += b4;
           if constexpr (EPI == 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(gv[i][e]);
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(gv[sl][i][e]);
           }
-          v += av[i];
+          v += av[sl][i];
           if constexpr (GATE != 0) {
             if constexpr (GATE == 1) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[i][e], g_sc[e], g_sh[e]) > 0.f ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[sl][i][e], g_sc[e], g_sh[e]) > 0.f ? v[e] : 0.f;
             } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (mb[i] >> e) & 1u ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = (mb[sl][i] >> e) & 1u ? v[e] : 0.f;
             }
             // an out-of-range row / column contributes nothing: its v is garbage but its mask byte read as 0 (GATE 2) or its x as 0
             // (GATE 1: the gate is then shift > 0, so force the product to zero explicitly)
             f32x4 gvv = v;
             if constexpr (GATE == 1) { gvv[0] = ok ? v[0] : 0.f; gvv[1] = ok ? v[1] : 0.f; gvv[2] = ok ? v[2] : 0.f; gvv[3] = ok ? v[3] : 0.f; }
             st_s1 += gvv;
-            st_s2 += gvv * ((xv[i] - g_mu) * g_is);
-            if constexpr (GX2) st_s3 += gvv * ((xv2[i] - g_mu2) * g_is2);      // an out-of-range row has gvv == 0 (mask byte 0)
+            st_s2 += gvv * ((xv[sl][i] - g_mu) * g_is);
+            if constexpr (GX2) st_s3 += gvv * ((xv2[sl][i] - g_mu2) * g_is2);      // an out-of-range row has gvv == 0 (mask byte 0)
           }
           if constexpr (EPI == 3) {          // Linear + GELU where only the activation is wanted (a forward without a backward): one store
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
           }
-          bstore4(r_out, voff[i], v);
+          bstore4(r_out, voff[sl][i], v);
           if constexpr (EPI == 1) {
             f32x4 a;
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] = gelu_f(v[e]);
-            bstore4(r_act, voff[i], a);
+            bstore4(r_act, voff[sl][i], a);
           }
+        }
+      };
+      {
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+          __builtin_amdgcn_sched_barrier(0);       // one step of rows in flight at a time (register budget of 3 workgroups per CU)
+          issue(st, 0);
+          finish(st, 0);
         }
       }
     }
   };
-  if (ADD) rows(std::true_type{}); else rows(std::false_type{});
+  // (the gated / gelu' epilogues always load: one copy with the uniform test inside - two copies of THAT loop cost 224-300 B / lane of scratch)
+  if constexpr (GATE != 0 || EPI == 2) rows(std::integral_constant<int, 2>{});
+  else if (ADD) rows(std::integral_constant<int, 1>{});
+  else rows(std::integral_constant<int, 0>{});
 
   if constexpr (STATS) {
 #pragma unroll
