@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py - images/sec of the SimCLR (default; --algo byol|barlow for the siblings) ResNet-50 two-view training step on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N ranks itself, one process per GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (the same ranks started by an outer launcher)
 
 One "step" = the reference train_step (models/simclr.py:86-95) on one per-GPU batch: two views ->
 ResNet-50 (std 7x7/2 stem) + projector forward with per-view BatchNorm -> NT-Xent over the GLOBAL batch
@@ -16,10 +16,17 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # `python bench.py --gpus N` with N > 1 and no process group in the environment: this process becomes the waiting parent of N ranks
+    # (python -m torch.distributed.run ... bench.py <same arguments>) and exits with their code.  Standard library only up to here -
+    # the parent never imports torch, never touches HIP (ssv_amd/launch.py says why).
+    from ssv_amd import launch as _launch
+    _launch.maybe_spawn_ranks(os.path.abspath(__file__), sys.argv[1:], _launch.gpus_flag(sys.argv[1:]))
+
+import torch  # noqa: E402
 
 # rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh); newest kernel state first
 PMC_FILES = {"simclr": ("r03_simclr_b%d_pmc_hbm_traffic.json", "r02_simclr_b%d_pmc_hbm_traffic.json", "r01_n_pmc_hbm_traffic_b%d.json"),
@@ -324,10 +331,11 @@ def main():
     from ssv_amd import _lib, distributed as hdist
     rank, world = hdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s): launch with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s): an outer launcher must start exactly --gpus ranks "
+                         f"(python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...), "
+                         f"or run plain `python bench.py --gpus {args.gpus}` and let it start them")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+        raise SystemExit(f"bench.py needs an MI355X: no HIP device visible (rank {rank} of {world})")
     device = torch.device("cuda", torch.cuda.current_device())
     _lib.load()
 
@@ -378,22 +386,27 @@ def main():
     dist_info = None
     if world > 1:
         import torch.distributed as dist
-        mine = torch.tensor([dt], device=device, dtype=torch.float64)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank = [float(v.item()) for v in every]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, float(dt))
         dt = max(per_rank)                                         # MAX over ranks: the step is as slow as its slowest rank
         # what the exchange costs: extra steps (after the timed region) with an event pair around every collective, on the stream it runs on
         hdist.comm_timing(True)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        comm = torch.tensor([hdist.comm_timing(False) / 2], device=device, dtype=torch.float64)
-        dist.all_reduce(comm, op=dist.ReduceOp.MAX)
+        comms = [None] * world
+        dist.all_gather_object(comms, hdist.comm_timing(False) / 2)
         sync = getattr(train_step.trainer.optim, "grad_sync", None)
+        props = torch.cuda.get_device_properties(device)
+        mine_dev = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(), "device": device.index, "name": props.name,
+                    "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine_dev)                  # what every rank really ran on: N distinct devices prove one process per GPU
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_gpu": max(1, dist.get_world_size() // max(1, torch.cuda.device_count())),
+                     "launched_by": "bench.py (ssv_amd.launch: child torch.distributed.run)" if os.environ.get("SSV_LAUNCHED_BY") else "outer launcher",
+                     "devices": devices,
                      "ms_per_step_min_over_ranks": round(min(per_rank) / args.steps * 1e3, 3), "ms_per_step_max_over_ranks": round(max(per_rank) / args.steps * 1e3, 3),
-                     "comm_ms_per_step": round(float(comm.item()), 3),
+                     "comm_ms_per_step": round(max(comms), 3),
                      "comm_note": "device time between HIP events around every collective (embedding / LSE all-gathers, per-bucket gradient all-reduces on the "
                                   "exchange stream), max over ranks, 2 extra steps; the bucketed all-reduces overlap the backward pass, so this is not additive to ms_per_step",
                      "gradient_buckets": None if sync is None else [[n, (hi - lo) * 4] for n, lo, hi in sync.buckets]}

@@ -3,7 +3,8 @@
 The flag surface is the reference's (main.py:11-12,38-43), verbatim: -c/--config, -m/--arch, -a/--algo, -t/--task,
 -o/--output, -l/--load with the same choices, so scripts written for the reference keep working.  Algorithms outside the
 accelerated two-view path (pirl, deep_cluster, swav, sela) stay on the
-surface and raise NotImplementedError.  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N main.py ...`.
+surface and raise NotImplementedError.  Multi-GPU: `SSV_GPUS=N python main.py ...` (the repo-root script starts its N ranks itself,
+ssv_amd/launch.py) or `python -m torch.distributed.run --nproc-per-node N main.py ...`.
 """
 import argparse
 import importlib

@@ -362,3 +362,53 @@ def test_cli_two_ranks_train_on_disjoint_shards(tmp_path):
     out = tmp_path / d0
     log = (out / "trainlogs.txt").read_text()
     assert log.count("[TRAIN] Epoch    1/   2") == 1 and (out / "best_model.pt").exists()      # one writer
+
+
+def _plain_env(**extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", WANDB_MODE="disabled", **extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "SSV_DIST_FORCE"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_2_starts_its_two_ranks_itself():
+    """The driver's invocation for N > 1, `python bench.py --gpus 2 ...` with NO launcher around it: the parent (which never imports torch,
+    tests/test_launch_cpu.py) starts two ranks as child processes and rank 0's JSON line comes back through it.  gloo, because RCCL refuses
+    two ranks on the test box's one GPU; on an N-GPU node the same path runs with the default backend "nccl" (= RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+                          "--no-cpu-baseline", "--prof-steps", "0"], env=_plain_env(SSV_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                        # ONE line, from rank 0
+    out = json.loads(lines[0])
+    d = out["distributed"]
+    assert out["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo" and d["launched_by"].startswith("bench.py")
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and abs(out["value"] - 32 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3     # whole-job images/s over the max-over-ranks time
+    assert d["gradient_buckets"] and d["comm_ms_per_step"] > 0
+    assert 0 < out["config"]["last_loss"] < 10
+
+
+def test_main_ssv_gpus_2_starts_two_ranks(tmp_path):
+    """`SSV_GPUS=2 python main.py <the reference's flags>`: two ranks train on disjoint shards, one run directory, one writer."""
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "self-supervised-vision_amd", "configs", "simclr.yaml")))
+    cfg["epochs"], cfg["eval_every"] = 1, 1
+    cfg["data"]["batch_size"] = 16
+    cfg["data"]["synthetic"] = {"num_train": 64, "num_test": 40, "image_size": [32, 32], "num_classes": 10}
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.dump(cfg, sort_keys=False))
+    res = subprocess.run([sys.executable, os.path.join(root, "main.py"), "-c", str(path), "-a", "simclr", "-m", "resnet18", "-t", "train", "-o", "run"],
+                         env=_plain_env(SSV_GPUS="2", SSV_DIST_BACKEND="gloo"), cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = tmp_path / "outputs" / "simclr" / "resnet18" / "run"
+    log = (out / "trainlogs.txt").read_text()
+    assert log.count("[TRAIN] Epoch    1/   1") == 1 and (out / "best_model.pt").exists()

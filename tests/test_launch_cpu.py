@@ -1,0 +1,71 @@
+"""CPU: `python bench.py --gpus N` / `SSV_GPUS=N python main.py` start their N ranks themselves (ssv_amd/launch.py) - and the parent that
+does so never imports torch, so it can never have touched HIP when it starts GPU workers."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_FAKE_TORCH = '''import os, sys
+sys.stderr.write("FAKE_TORCH_IMPORTED pid=%d argv=%r\\n" % (os.getpid(), sys.argv))
+raise ImportError("fake torch: this process imported torch")
+'''
+
+
+def _no_gpu_env(**extra):
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", **extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "SSV_GPUS"):
+        if k not in extra:
+            env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("script,argv,extra", [("bench.py", ["--gpus", "2", "--steps", "1", "--warmup", "0"], {}),
+                                               ("main.py", ["-c", "x.yaml", "-m", "resnet18", "-a", "simclr", "-t", "train"], {"SSV_GPUS": "2"})])
+def test_parent_starts_the_launcher_without_importing_torch(tmp_path, script, argv, extra):
+    """A poisoned `torch` package first on PYTHONPATH reports who imports it: only the CHILD (`-m torch.distributed.run ... <script>`)
+    may - the parent reaches the spawn with the standard library alone and hands on the child's exit code."""
+    fake = tmp_path / "fake" / "torch"
+    fake.mkdir(parents=True)
+    (fake / "__init__.py").write_text(_FAKE_TORCH)
+    env = _no_gpu_env(PYTHONPATH=str(tmp_path / "fake"), **extra)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, script), *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out, err = p.communicate(timeout=120)
+    marks = [ln for ln in err.splitlines() if ln.startswith("FAKE_TORCH_IMPORTED")]
+    assert marks, err[-2000:]                                           # the launcher child was started and tried to import torch
+    assert all(f"pid={p.pid} " not in ln for ln in marks), marks       # ... the parent never did
+    assert all("torch.distributed.run" in ln or "torch/distributed/run" in ln or "-m" in ln for ln in marks), marks
+    assert p.returncode != 0                                            # the child's failure is the parent's exit code
+
+
+def test_spawn_ranks_refuses_once_torch_is_imported_and_builds_the_documented_command():
+    import torch  # noqa: F401
+    from ssv_amd import launch
+    with pytest.raises(RuntimeError, match="before torch is imported"):
+        launch.spawn_ranks("bench.py", ["--gpus", "2"], 2)
+    cmd = launch.rank_command("/x/bench.py", ["--gpus", "4", "--steps", "3"], 4, port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29511",
+                       "/x/bench.py", "--gpus", "4", "--steps", "3"]
+    assert launch.gpus_flag(["--steps", "3", "--gpus=8"]) == 8 and launch.gpus_flag(["--gpus", "2"]) == 2 and launch.gpus_flag([]) == 1
+
+
+def test_inside_a_process_group_nothing_is_spawned(monkeypatch):
+    from ssv_amd import launch
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    assert launch.maybe_spawn_ranks("bench.py", [], 2) is None          # the outer launcher's rank runs in-process (would sys.exit otherwise)
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.delenv("RANK")
+    assert launch.maybe_spawn_ranks("bench.py", [], 1) is None
+
+
+def test_bench_gpus_2_reaches_two_ranks_of_a_process_group():
+    """Without a GPU the two ranks stop at bench.py's device check - after joining a world of TWO: the plain `python bench.py --gpus 2`
+    invocation (the driver's form) no longer dies on the world-size check (round 3: bench.py:326-329)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--prof-steps", "0"],
+                         env=_no_gpu_env(), capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert "no HIP device visible (rank 0 of 2)" in res.stderr and "no HIP device visible (rank 1 of 2)" in res.stderr, res.stderr[-3000:]
+    assert "the process group has" not in res.stderr
