@@ -26,5 +26,5 @@ from .nets import (  # noqa: F401
 )
 from .losses import ntxent_loss, barlow_loss, byol_mse_loss, l2_normalize  # noqa: F401
 from .optim import sgd_nesterov_step, seeded_lr, ema_update, byol_tau  # noqa: F401
-from .step import SimCLROracle, BYOLOracle, BarlowOracle  # noqa: F401
+from .step import SimCLROracle, BYOLOracle, BarlowOracle, twin64, snapshot  # noqa: F401
 from . import evalknn  # noqa: F401,E402

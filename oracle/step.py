@@ -153,3 +153,33 @@ class BYOLOracle(_Base):
             for part, d in net.items():
                 out.update(_prefixed(f"{name}.{part}.", d))
         return out
+
+
+def twin64(make):
+    """An fp64 copy of an oracle trainer with the SAME (fp32-drawn) initial weights: the centre both fp32 evaluations - this CPU oracle and
+    the HIP path - are measured against where two fp32 runs of a chaotic trajectory cannot be compared with each other."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        m64 = make()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    src = make()
+
+    def copy(dst, s_):
+        for k in dst:
+            if isinstance(dst[k], dict):
+                copy(dst[k], s_[k])
+            elif dst[k].dtype.is_floating_point:
+                dst[k].data = s_[k].detach().double()
+    for attr in ("encoder", "proj_head", "online", "target"):
+        if hasattr(m64, attr):
+            copy(getattr(m64, attr), getattr(src, attr))
+    return m64
+
+
+def snapshot(m):
+    """Weights, momentum buffers (and BYOL's target weights) of an oracle trainer: what a step starts from."""
+    snap = {"params": [p.detach().clone() for p in m.params], "bufs": [None if b is None else b.detach().clone() for b in m.bufs]}
+    if hasattr(m, "target_params"):
+        snap["target"] = [p.detach().clone() for p in m.target_params]
+    return snap

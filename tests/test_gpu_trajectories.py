@@ -216,8 +216,7 @@ def test_byol_resnet50_224_step_matches_oracle(dev):
     want2 = o.train_step(a1, a2, step=1)["loss"]
     # one update later, batch 6 at lr 0.02: ill-posed for any two fp32 evaluations (ResNet-50 at 224) - size class, measured against
     # an fp64 twin of the oracle on the same two steps: no further from it than 3x the fp32 CPU oracle is, + 2e-2
-    from bench import _twin64
-    o64 = _twin64(make)
+    o64 = oracle.twin64(make)
     o64.train_step(*(v.double() for v in _views(3000, b, 224)), step=0)
     want64 = o64.train_step(a1.double(), a2.double(), step=1)["loss"]
     assert abs(got2 - want64) <= 3 * abs(want2 - want64) + 2e-2 * abs(want64), f"step 1: hip {got2} cpu32 {want2} fp64 {want64}"
