@@ -28,11 +28,12 @@ if __name__ == "__main__":
 
 import torch  # noqa: E402
 
-# rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh); newest kernel state first
-PMC_FILES = {"simclr": ("r03_simclr_b%d_pmc_hbm_traffic.json", "r02_simclr_b%d_pmc_hbm_traffic.json", "r01_n_pmc_hbm_traffic_b%d.json"),
-             "dino": ("r03_dino_b%d_pmc_hbm_traffic.json", "r02_dino_b%d_pmc_hbm_traffic.json", "r01_l_pmc_hbm_traffic_dino_b%d.json")}
-CONV_LAYER_FILES = ("r03_conv_layers_b%d.csv",)     # tools/bench_conv.py: per-layer operand-stream bytes of the variants the step launches
-PMC_MFMA_FILES = {"simclr": ("r03_simclr_b%d_pmc_mfma.json", "r02_simclr_b%d_pmc_mfma.json"), "dino": ("r03_dino_b%d_pmc_mfma.json", "r02_dino_b%d_pmc_mfma.json")}
+# rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh) and the per-layer operand-stream table of
+# tools/bench_conv.py.  Each file records the build it was measured on (src_sha16 = ssv_source_sha16() of the profiled library); counters of another
+# build are NOT replayed: the line then carries traffic: null and counters_stale: true.
+PMC_FILES = {"simclr": "r04_simclr_b%d_pmc_hbm_traffic.json", "dino": "r04_dino_b%d_pmc_hbm_traffic.json"}
+CONV_LAYER_FILE = "r04_conv_layers_b%d.csv"
+PMC_MFMA_FILES = {"simclr": "r04_simclr_b%d_pmc_mfma.json", "dino": "r04_dino_b%d_pmc_mfma.json"}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -488,52 +489,72 @@ def main():
         conv_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) / args.prof_steps
         conv_launch = sum(prof[k][1] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) // args.prof_steps
         ach = conv_flop_step / (conv_ms * 1e-3) / 1e12
-        traffic, pmc_path = None, None
-        try:   # HBM bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; corrected as the guide prescribes)
-            if args.algo not in PMC_FILES:
-                raise KeyError(args.algo)                          # PMC passes exist for the headline workload and for DINO
-            pmc_path = next(pth for pth in (os.path.join(ROOT, "profiles", f % b) for f in PMC_FILES[args.algo]) if os.path.exists(pth))
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)["per_step_gb"]
-            traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")), 1)
-            for k, v in pmc.items():
-                if k in classes:
-                    classes[k]["hbm_gb_per_step"] = round(v["fetch"] + v["write"], 1)
-        except (OSError, KeyError, ValueError, StopIteration):
-            pass
-        mfma = None
-        try:   # matrix-pipe utilisation of the same kernels: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/pmc_mfma.py)
-            mpath = next(pth for pth in (os.path.join(ROOT, "profiles", f % b) for f in PMC_MFMA_FILES.get(args.algo, ())) if os.path.exists(pth))
-            with open(mpath) as fh:
-                mfma = json.load(fh)
-            for k, v in mfma["per_class"].items():
-                if k in classes and v.get("mfma_busy_frac") is not None:
-                    classes[k]["mfma_busy_frac"] = v["mfma_busy_frac"]
-            mfma = dict(mfma["summary"], source=os.path.relpath(mpath, ROOT))
-        except (OSError, KeyError, ValueError, StopIteration):
-            mfma = None
+        # counters measured in separate rocprofv3 --pmc runs (they cannot be collected inside this process): replayed from profiles/ ONLY when the file
+        # was measured on the build that is loaded now
+        my_src, my_lib = _lib.source_sha16(), _lib.lib_sha16()
+        stale, used = [], {}
+
+        def committed(fname, kind):
+            pth = os.path.join(ROOT, "profiles", fname)
+            if not os.path.exists(pth):
+                return None
+            if pth.endswith(".csv"):
+                import csv
+                with open(pth, newline="") as fh:
+                    rows_ = list(csv.DictReader(fh))
+                ident = next((r["layer"] for r in rows_ if r["layer"].startswith("BUILD ")), "")
+                src = dict(kv.split("=") for kv in ident.split()[1:]).get("src_sha16") if ident else None
+                data = rows_
+            else:
+                with open(pth) as fh:
+                    data = json.load(fh)
+                src = data.get("src_sha16")
+            if src != my_src:
+                stale.append({"file": os.path.relpath(pth, ROOT), "measured_on_src_sha16": src})
+                return None
+            used[kind] = os.path.relpath(pth, ROOT)
+            return data
+        traffic, whole_traffic, pmc = None, None, None
+        if args.algo in PMC_FILES:       # HBM bytes of the same kernels: rocprofv3 PMC FETCH_SIZE, WRITE_SIZE, corrected as the guide prescribes
+            pmc = committed(PMC_FILES[args.algo] % b, "traffic")
+            if pmc is not None:
+                pmc = pmc["per_step_gb"]
+                traffic = round(sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in pmc), 1)
+                whole_traffic = round(sum(v["fetch"] + v["write"] for v in pmc.values()), 1)
+                for k, v in pmc.items():
+                    if k in classes:
+                        classes[k]["hbm_gb_per_step"] = round(v["fetch"] + v["write"], 1)
+        mfma, executed_gflop = None, None
+        if args.algo in PMC_MFMA_FILES:  # matrix-pipe utilisation: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/pmc_mfma.py)
+            mfma = committed(PMC_MFMA_FILES[args.algo] % b, "mfma")
+            if mfma is not None:
+                for k, v in mfma["per_class"].items():
+                    if k in classes and v.get("mfma_busy_frac") is not None:
+                        classes[k]["mfma_busy_frac"] = v["mfma_busy_frac"]
+                executed_gflop = mfma["summary"].get("conv_family_executed_gflop_per_step")
+                mfma = dict(mfma["summary"], source=used["mfma"])
         # operand streams of the conv family in the variants the step launches (the fused BatchNorm operands - shortcut, BatchNorm input, gate
         # operands, the written activation - are streams of these kernels now): per view from tools/bench_conv.py's per-layer model, x 2 views
         family_gb, family_src = None, None
         if args.algo == "simclr":
-            try:
-                import csv
-                cpath = next(pth for pth in (os.path.join(ROOT, "profiles", f % b) for f in CONV_LAYER_FILES) if os.path.exists(pth))
-                with open(cpath) as fh:
-                    tot = [r for r in csv.DictReader(fh) if r["layer"].startswith("TOTAL")]
-                family_gb, family_src = round(2 * sum(float(r["fwd_GB"]) for r in tot), 1), os.path.relpath(cpath, ROOT)
-            except (OSError, KeyError, ValueError, StopIteration):
-                pass
-        whole_traffic = None
-        try:
-            whole_traffic = round(sum(v["fetch"] + v["write"] for v in pmc.values()), 1)
-        except (NameError, KeyError, TypeError):
-            pass
+            layer_rows = committed(CONV_LAYER_FILE % b, "layers")
+            if layer_rows is not None:
+                tot = [r for r in layer_rows if r["layer"].startswith("TOTAL")]
+                family_gb, family_src = round(2 * sum(float(r["fwd_GB"]) for r in tot), 1), used["layers"]
         attn_ms = prof.get("attn", (0.0, 0))[0] / args.prof_steps
         roof = {"bound": "mfma", "kernel": ("implicit-GEMM family running the Linear layers" if args.algo == "dino" else "conv implicit-GEMM family") +
                                            " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, %s)" % (os.path.relpath(pmc_path, ROOT) if traffic is not None else "no PMC pass for this workload"),
+                # `frac` / `frac_algorithmic` price the reference's ALGORITHMIC FLOPs (direct convolution); the Winograd layers execute
+                # 2.25x fewer multiplies, so the matrix pipe's own utilisation is `executed_frac` = FLOPs the MFMA counters saw / the same family time
+                "frac_algorithmic": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "executed_frac": None if executed_gflop is None else round(executed_gflop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4),
+                "executed_gflop_per_step": executed_gflop,
+                "counters_src_sha16": my_src, "counters_lib_sha16": my_lib, "counters_stale": bool(stale), "counters_rejected": stale or None,
+                "counters_note": "src_sha16 = the sources the LOADED library was compiled from (ssv_source_sha16; hipcc output is not bit-reproducible, so the file hash "
+                                 "lib_sha16 only identifies one build artefact); traffic / mfma_counters / executed_frac / algorithmic_gb_per_step are replayed from "
+                                 "profiles/ only when measured on this src_sha16",
+                "traffic": traffic, "traffic_unit": "GB of HBM traffic per step for this kernel family (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, %s)" % (used.get("traffic") or "no PMC pass measured on this build"),
                 "algorithmic_gb_per_step": family_gb if family_gb is not None else (None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1)),
                 "algorithmic_gb_note": ("every operand stream of the family's kernels moved once, fused BatchNorm operands included (%s); the transformed-domain "
                                         "tensors of the Winograd layers (V, M, transformed gradients: ~150 GB/step at bs 512 - bytes traded for 2.25x fewer multiplies, "

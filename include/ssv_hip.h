@@ -36,6 +36,10 @@ typedef enum ssv_status {
 
 int ssv_version(void);
 const char* ssv_last_error(void);
+/* Build identity: the first 16 hex digits of the sha256 over the sources this binary was compiled from (csrc Makefile: the .hip files in
+ * link order, common.h, this header).  hipcc output is not bit-reproducible, so a hash of the .so file cannot tell "same kernels, rebuilt"
+ * from "other kernels"; this one can.  Profiles record it and bench.py refuses counters measured on another build. */
+const char* ssv_source_sha16(void);
 /* number of CUs of the current device (0 if no device) - host-side helper for grid sizing */
 int ssv_device_cus(void);
 

@@ -44,6 +44,7 @@ _cd = C.POINTER(ConvDesc)
 SIGNATURES = {
     "ssv_version": (C.c_int, []),
     "ssv_last_error": (C.c_char_p, []),
+    "ssv_source_sha16": (C.c_char_p, []),
     "ssv_device_cus": (C.c_int, []),
     "ssv_conv2d_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_pad_channels": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -175,6 +176,21 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def source_sha16():
+    """The loaded library's build identity: sha256[:16] of the sources it was compiled from (include/ssv_hip.h: ssv_source_sha16)."""
+    return load().ssv_source_sha16().decode()
+
+
+def lib_sha16(path=None):
+    """First 16 hex digits of the sha256 of the library file: profiles record it, bench.py compares it with the library it has loaded."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path or LIB_PATH, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
 
 
 def _check(rc, what):

@@ -15,6 +15,10 @@ void ssv_set_error(const char* fmt, ...) {
 
 extern "C" int ssv_version(void) { return 100; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
+#ifndef SSV_SRC_SHA16
+#define SSV_SRC_SHA16 "unknown"
+#endif
+extern "C" const char* ssv_source_sha16(void) { return SSV_SRC_SHA16; }
 
 extern "C" int ssv_device_cus(void) {
   int dev = 0;

@@ -102,7 +102,7 @@ def _drive(lib_path, tmp_path, env_extra=None):
 
 
 # entry points that legitimately succeed on some of the probes (pure host helpers, documented no-ops)
-_HOST_HELPERS = {"ssv_version", "ssv_last_error", "ssv_device_cus", "ssv_prof_enable", "ssv_prof_reset"}
+_HOST_HELPERS = {"ssv_version", "ssv_last_error", "ssv_source_sha16", "ssv_device_cus", "ssv_prof_enable", "ssv_prof_reset"}
 
 
 def _check(result):

@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from ssv_amd import ops  # noqa: E402
+from ssv_amd import _lib, ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 REP = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -190,3 +190,4 @@ if OUT:
         wtr = csv.writer(fh)
         wtr.writerow(hdr)
         wtr.writerows(rows)
+        wtr.writerow([f"BUILD src_sha16={_lib.source_sha16()} lib_sha16={_lib.lib_sha16()}", f"batch {B}"])      # which build these rows were measured on (bench.py checks it)

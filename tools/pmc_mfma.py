@@ -17,7 +17,7 @@ import json
 import sys
 from collections import defaultdict
 
-from pmc_traffic import classify
+from pmc_traffic import classify, build_identity
 
 SIMDS, XCDS = 1024, 8
 
@@ -51,7 +51,7 @@ def main():
         total_cyc = sum(r["kernel_cycles_per_step"] for r in res.values())
         summary["whole_step_mfma_busy_frac"] = round(sum(r["mfma_busy_cycles_per_step"] for r in res.values()) / (total_cyc * SIMDS), 4)
     json.dump({"normalisation": "MFMA busy cycles (sum over SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); executed FLOP = 64 x busy cycles (fp32 32x32x2: 64 cycles, 4096 FLOP)",
-               "steps_in_run": steps, "summary": summary, "per_class": res}, open(out, "w"), indent=1)
+               "steps_in_run": steps, **build_identity(), "summary": summary, "per_class": res}, open(out, "w"), indent=1)
     print(json.dumps({"summary": summary, "per_class": res}, indent=1))
 
 
