@@ -109,8 +109,12 @@ def test_main_sibling_algorithms_train(tmp_path, monkeypatch, algo, first_key):
         np.testing.assert_allclose(norms, 1.0, rtol=1e-4)                         # the queue is full of unit keys after 160 pushes
 
 
-def test_main_simclr_on_resnext50(tmp_path, monkeypatch):
-    """`-m resnext50` (grouped 3x3 convolutions as dense block-diagonal ones) through the CLI."""
+@pytest.mark.parametrize("arch,shapes", [
+    ("resnext50", {"layer1.0.conv2.weight": (128, 4, 3, 3), "layer4.2.conv2.weight": (1024, 32, 3, 3)}),
+    ("wide_resnet50", {"layer1.0.conv2.weight": (128, 128, 3, 3), "layer4.2.conv2.weight": (1024, 1024, 3, 3), "layer4.2.conv3.weight": (2048, 1024, 1, 1)})])
+def test_main_simclr_on_the_other_archs(tmp_path, monkeypatch, arch, shapes):
+    """`-m resnext50` (grouped 3x3 convolutions on group-aware tiles) and `-m wide_resnet50` (doubled inner width: 128 .. 1024-channel 3x3 layers) through
+    the CLI: train, validate, checkpoint with the reference's key layout (main.py:12, networks/resnet.py:174-193)."""
     from ssv_amd import main as cli
     cfg = yaml.safe_load(open(os.path.join(ROOT, "self-supervised-vision_amd", "configs", "simclr.yaml")))
     cfg["epochs"], cfg["eval_every"] = 1, 1
@@ -121,9 +125,10 @@ def test_main_simclr_on_resnext50(tmp_path, monkeypatch):
     path.write_text(yaml.dump(cfg, sort_keys=False))
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("WANDB_MODE", "disabled")
-    model = cli.main(["-c", str(path), "-a", "simclr", "-m", "resnext50", "-t", "train", "-o", "run"])
-    state = torch.load(tmp_path / "outputs" / "simclr" / "resnext50" / "run" / "best_model.pt", map_location="cpu")["encoder"]
-    assert tuple(state["layer1.0.conv2.weight"].shape) == (128, 4, 3, 3) and tuple(state["layer4.2.conv2.weight"].shape) == (1024, 32, 3, 3)
+    model = cli.main(["-c", str(path), "-a", "simclr", "-m", arch, "-t", "train", "-o", "run"])
+    state = torch.load(tmp_path / "outputs" / "simclr" / arch / "run" / "best_model.pt", map_location="cpu")["encoder"]
+    for key, shape in shapes.items():
+        assert tuple(state[key].shape) == shape, key
     assert np.isfinite(model.optim.arena.data.cpu().numpy()).all()
 
 

@@ -407,47 +407,73 @@ def test_ragged_last_batch(dev):
     close(z1, ref["z_1"], rtol=1e-4, atol=1e-4, what="z_1")
 
 
-def test_resnext50_grouped_convs_match_reference(dev, golden):
-    """`-m resnext50`: grouped 3x3 convolutions run as dense block-diagonal ones - init draws, features and every parameter
-    gradient against the reference's own numbers (tests/golden/resnext_level.npz) and an fp64 evaluation of the oracle."""
+def _arch_parity(dev, arch, factory, keys, sums, feats, xseed, dseed, batch):
+    """One forward + backward of an encoder of main.py's --arch list on the HIP path: init draws (RNG-stream parity) and features against the
+    reference's own numbers, features and every parameter gradient calibrated against an fp64 evaluation of the oracle."""
     from ssv_amd.networks import resnet
-    g = golden["resnext_level"]
     torch.manual_seed(420)
-    net = resnet.resnext50_32x4d(reduce_bottom_conv=True)
+    net = getattr(resnet, factory)(reduce_bottom_conv=True)
     sd = net.state_dict()
-    assert [k for k, v in sd.items() if v.dtype.is_floating_point] == [str(k) for k in g["init_keys"]]
-    for k, ref in zip(g["init_keys"], g["init_sums"]):
+    assert [k for k, v in sd.items() if v.dtype.is_floating_point] == [str(k) for k in keys]
+    for k, ref in zip(keys, sums):
         np.testing.assert_allclose(np.array(oracle.tensor_checksum(sd[str(k)].contiguous())), ref, rtol=1e-12, atol=0, err_msg=str(k))
     net = net.to(dev)
-    x, dy = seeded_randn(1400, 4, 3, 32, 32), seeded_randn(1401, 4, 2048)
+    x, dy = seeded_randn(xseed, batch, 3, 32, 32), seeded_randn(dseed, batch, 2048)
     y = net(x.to(dev))
-    # batch 4 through 2x2 / 1x1 feature maps: BatchNorm over 4-16 values per channel amplifies rounding (both sides are fp32)
-    np.testing.assert_allclose(y.detach().cpu().numpy(), g["features"], rtol=2e-3, atol=5e-4)
     y.backward(dy.to(dev))
-    torch.manual_seed(420)
-    p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in oracle.init_resnet("resnext50", True).items()}
-    for k, v in p64.items():
-        if v.dtype.is_floating_point and "running" not in k:
-            v.requires_grad_(True)
-    oracle.resnet_forward(p64, x.double(), "resnext50", True).backward(dy.double())
+
+    def cpu(dtype):
+        torch.manual_seed(420)
+        p = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in oracle.init_resnet(arch, True).items()}
+        for k, v in p.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+        out = oracle.resnet_forward(p, x.to(dtype), arch, True)
+        out.backward(dy.to(dtype))
+        return p, out.detach()
+    p64, y64 = cpu(torch.float64)
+    p32, y32 = cpu(torch.float32)
+    # features: 2x2 / 1x1 maps at this input size put only 4 * batch values into a channel's BatchNorm statistics, which amplifies rounding for any
+    # fp32 evaluation - measured here as the fp32 CPU oracle's own distance to fp64 (e_cpu, 1e-5 .. 2e-4); HIP is held to that size class, and to
+    # the reference's numbers with the same yardstick (the ResNet-18/50 step tests use 1e-4: their e_cpu is 2e-5)
+    e_cpu = float((y32.double() - y64).abs().max())
+    e_hip = float((y.detach().cpu().double() - y64).abs().max())
+    assert e_hip <= 3 * e_cpu + 1e-5, (arch, e_hip, e_cpu)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), feats, rtol=1e-4, atol=max(1e-4, 4 * e_cpu))
     errs = {}
     for name, p in net.named_parameters():
         ref = p64[name].grad
         errs[name] = float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
     # a ReLU whose input is within rounding of zero flips between any two fp32 evaluations and moves the gradients of everything
-    # before it (DESIGN 2); at batch 4 a channel of layer4 sees 16 values, so this is large here - calibrate against what the
+    # before it (DESIGN 2); with 16-32 values per channel in layer4 this is large here - calibrate against what the
     # fp32 CPU oracle itself shows against the same fp64 evaluation
-    torch.manual_seed(420)
-    p32 = oracle.init_resnet("resnext50", True)
-    for k, v in p32.items():
-        if v.dtype.is_floating_point and "running" not in k:
-            v.requires_grad_(True)
-    oracle.resnet_forward(p32, x, "resnext50", True).backward(dy)
-    cpu = np.array([float((p32[k].grad.double() - p64[k].grad).norm() / (p64[k].grad.norm() + 1e-30)) for k in errs])
+    cpu_err = np.array([float((p32[k].grad.double() - p64[k].grad).norm() / (p64[k].grad.norm() + 1e-30)) for k in errs])
     vals = np.array(list(errs.values()))
-    assert np.median(vals) <= 3 * np.median(cpu) + 1e-4 and vals.max() <= 3 * cpu.max() + 1e-3, (float(np.median(vals)), float(np.median(cpu)), float(vals.max()), float(cpu.max()))
+    assert np.median(vals) <= 3 * np.median(cpu_err) + 1e-4 and vals.max() <= 3 * cpu_err.max() + 1e-3, \
+        (arch, float(np.median(vals)), float(np.median(cpu_err)), float(vals.max()), float(cpu_err.max()))
+    return net
+
+
+def test_resnext50_grouped_convs_match_reference(dev, golden):
+    """`-m resnext50`: grouped 3x3 convolutions run on group-aware tiles of the dense block-diagonal bank - init draws, features and every
+    parameter gradient against the reference's own numbers (tests/golden/resnext_level.npz) and an fp64 evaluation of the oracle."""
+    g = golden["resnext_level"]
+    net = _arch_parity(dev, "resnext50", "resnext50_32x4d", g["init_keys"], g["init_sums"], g["features"], 1400, 1401, 4)
     grouped = net.layer1[0].conv2
     assert grouped.groups == 32 and tuple(grouped.weight.shape) == (128, 4, 3, 3)
+
+
+@pytest.mark.parametrize("arch,factory", [("wide_resnet50", "wide_resnet50_2"), ("wide_resnet101", "wide_resnet101_2"), ("resnext101", "resnext101_32x8d")])
+def test_remaining_archs_match_reference(dev, golden, arch, factory):
+    """The rest of main.py's --arch list (`-m wide_resnet50 | wide_resnet101 | resnext101`, networks/resnet.py:174-193): 128 .. 1024-wide 3x3 layers
+    (Winograd and fused-BatchNorm dispatch at widths ResNet-50 never shows) and 32 x 8d grouped layers, against tests/golden/arch_level.npz."""
+    g = golden["arch_level"]
+    net = _arch_parity(dev, arch, factory, g[f"{arch}_init_keys"], g[f"{arch}_init_sums"], g[f"{arch}_features"], 1700, 1701, 8)
+    conv2 = net.layer1[0].conv2
+    if arch == "resnext101":
+        assert conv2.groups == 32 and tuple(conv2.weight.shape) == (256, 8, 3, 3)
+    else:
+        assert conv2.groups == 1 and tuple(conv2.weight.shape) == (128, 128, 3, 3)
 
 
 @pytest.mark.parametrize("arch,rbc,size,b", [("resnet50", False, 64, 6), ("resnet18", True, 32, 20)])

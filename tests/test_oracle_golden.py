@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/) against fixtures produced by the reference itself
 (tests/golden/gen_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 import oracle
@@ -167,5 +168,27 @@ def test_resnext_oracle_matches_reference(golden):
     np.testing.assert_allclose(y.detach().numpy(), g["features"], rtol=1e-4, atol=1e-5)
     y.backward(seeded_randn(1401, 4, 2048))
     for k, ref in zip(g["grad_keys"], g["grad_sums"]):
+        got = oracle.tensor_checksum(p[str(k)].grad)
+        np.testing.assert_allclose(got[1], ref[1], rtol=2e-3, err_msg=str(k))
+
+
+@pytest.mark.parametrize("arch", ["wide_resnet50", "wide_resnet101", "resnext101"])
+def test_remaining_archs_oracle_matches_reference(golden, arch):
+    """The rest of main.py's --arch list (networks/resnet.py:174-193: wide_resnet50_2, wide_resnet101_2, resnext101_32x8d): init draws
+    (RNG-stream parity), features and parameter gradients of the oracle vs the reference's own numbers (tests/golden/arch_level.npz)."""
+    import torch
+    g = golden["arch_level"]
+    torch.manual_seed(420)
+    p = oracle.init_resnet(arch, True)
+    assert [k for k, v in p.items() if v.dtype.is_floating_point] == [str(k) for k in g[f"{arch}_init_keys"]]
+    for k, ref in zip(g[f"{arch}_init_keys"], g[f"{arch}_init_sums"]):
+        np.testing.assert_allclose(np.array(oracle.tensor_checksum(p[str(k)])), ref, rtol=1e-12, atol=0, err_msg=str(k))
+    for k, v in p.items():
+        if v.dtype.is_floating_point and not k.split(".")[-1].startswith("running"):
+            v.requires_grad_(True)
+    y = oracle.resnet_forward(p, seeded_randn(1700, 8, 3, 32, 32), arch, True)
+    np.testing.assert_allclose(y.detach().numpy(), g[f"{arch}_features"], rtol=1e-4, atol=1e-5)
+    y.backward(seeded_randn(1701, 8, 2048))
+    for k, ref in zip(g[f"{arch}_grad_keys"], g[f"{arch}_grad_sums"]):
         got = oracle.tensor_checksum(p[str(k)].grad)
         np.testing.assert_allclose(got[1], ref[1], rtol=2e-3, err_msg=str(k))

@@ -167,6 +167,101 @@ __global__ void __launch_bounds__(256, WGPC) gemm_k(int M, int N, int K, const f
       }
 }
 
+// ---- LDS-DMA staging (round 4): the same 128 x 128 tile and fragment reads, but the operands go global -> LDS directly
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write issue slots).  One wave-instruction writes 1 KiB of LDS contiguously (wave-uniform
+// base + lane * 16 B) = 8 rows of a [row][32 k] image, so the image cannot be padded; bank conflicts of the ds_read_b128 fragment reads are
+// avoided by an XOR swizzle of the 16-byte chunks of a row, applied on the SOURCE address: slot (row, s) holds chunk s ^ ((row >> 1) & 7).
+//   G1  one LDS stage (32 KB), 3 workgroups / CU: load -> wait -> barrier -> MFMAs -> barrier (no overlap inside a workgroup)
+//   G2  two LDS stages (64 KB), 2 workgroups / CU: tile kt+1 lands while tile kt is multiplied, one barrier per k-tile
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+template <int STAGES, int WGPC>
+__global__ void __launch_bounds__(256, WGPC) gemm_glds_k(int M, int N, int K, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C) {
+  constexpr int BK = 32, STAGE = 256 * BK;
+  __shared__ __attribute__((aligned(1024))) float smem[STAGES * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr0 = (wave >> 1) * 64, wc0 = (wave & 1) * 64;
+  const int NT = N / 128;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / NT, nt = bid - mt * NT;
+  const int m0 = mt * 128, n0 = nt * 128;
+  // DMA pass p (0..7) fills stage rows p*32 .. p*32+31 (0..127 = A tile, 128..255 = B tile); wave w takes rows p*32 + 8w .. +7, lane j row j>>3, slot j&7
+  const float* src[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = p * 32 + wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    src[p] = p < 4 ? A + (size_t)(m0 + row) * K + c * 4 : B + (size_t)(n0 + row - 128) * K + c * 4;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto issue = [&](int kt, float* st) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(src[p] + k0), (lds_void_t*)(st + (p * 32 + wave * 8) * BK), 16, 0, 0);
+  };
+  auto frags = [&](Frags& f, const float* st, int ks) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ra = wr0 + t * 32 + l31, rb = 128 + wc0 + t * 32 + l31;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&st[ra * BK + 4 * ((ks * 2 + h) ^ ((ra >> 1) & 7))]);
+      f.a[t][0] = v[0]; f.a[t][1] = v[1]; f.a[t][2] = v[2]; f.a[t][3] = v[3];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(&st[rb * BK + 4 * ((ks * 2 + h) ^ ((rb >> 1) & 7))]);
+      f.b[t][0] = w[0]; f.b[t][1] = w[1]; f.b[t][2] = w[2]; f.b[t][3] = w[3];
+    }
+  };
+  const int nkt = K / BK;
+  Frags fr;
+  if constexpr (STAGES == 1) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      issue(kt, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { frags(fr, smem, ks); mma_frags(fr, acc); }
+      __syncthreads();
+    }
+  } else {
+    issue(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const float* cur = smem + (kt & 1) * STAGE;
+      float* nxt = smem + ((kt + 1) & 1) * STAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      frags(fr, cur, 0);
+      issue(kt + 1 < nkt ? kt + 1 : kt, nxt);        // the last iteration re-loads a valid tile into the spare stage (never read)
+      mma_frags(fr, acc);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) { frags(fr, cur, ks); mma_frags(fr, acc); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col = n0 + wc0 + j * 32 + l31;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 // HBM-bound streaming kernel: y = x * a[c] + b[c] over an [R][C] matrix, 16 B per lane, UNROLL rows in flight per lane
 template <int UNROLL>
 __global__ void __launch_bounds__(256) stream_k(long long n4, const f32x4* __restrict__ x, f32x4* __restrict__ y, float a, float b) {
@@ -203,7 +298,8 @@ int main() {
   hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
   hipEvent_t e0, e1, f0, f1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
   const int grid = (M / 128) * (N / 128);
-  const int REP = 40, SREP = 12;
+  const int REP = 40, SREP = 12, NV = 11;
+  const bool gemm_only = getenv("GEMM_ONLY") != nullptr;      // round 4: only the main-loop table (the co-residency part is round 2's)
 
   auto run_gemm = [&](int v, hipStream_t s) {
     switch (v) {
@@ -215,9 +311,12 @@ int main() {
       case 5: hipLaunchKernelGGL((gemm_k<1, 32, 3, 50>), dim3(grid), dim3(256), 0, s, M, N, K, A, B, C); break;
       case 6: hipLaunchKernelGGL((gemm_k<1, 32, 3, 34>), dim3(grid), dim3(256), 0, s, M, N, K, A, B, C); break;
       case 7: hipLaunchKernelGGL((gemm_k<2, 32, 2, 48>), dim3(grid), dim3(256), 0, s, M, N, K, A, B, C); break;
+      case 8: hipLaunchKernelGGL((gemm_glds_k<1, 3>), dim3(grid), dim3(256), 0, s, M, N, K, A, B, C); break;
+      case 9: hipLaunchKernelGGL((gemm_glds_k<2, 2>), dim3(grid), dim3(256), 0, s, M, N, K, A, B, C); break;
+      case 10: hipLaunchKernelGGL((gemm_glds_k<1, 4>), dim3(grid), dim3(256), 0, s, M, N, K, A, B, C); break;
     }
   };
-  const char* gname[] = {"S1 bk32 3wg/cu (shipped)", "S2 bk32 2wg/cu", "S2 bk16 3wg/cu", "S1 bk32 2wg/cu", "S1 bk16 3wg/cu", "S1 bk32 3wg/cu ~160 regs", "S1 bk32 3wg/cu ~144 regs", "S2 bk32 2wg/cu ~192 regs"};
+  const char* gname[] = {"S1 bk32 3wg/cu (shipped)", "S2 bk32 2wg/cu", "S2 bk16 3wg/cu", "S1 bk32 2wg/cu", "S1 bk16 3wg/cu", "S1 bk32 3wg/cu ~160 regs", "S1 bk32 3wg/cu ~144 regs", "S2 bk32 2wg/cu ~192 regs", "G1 LDS-DMA 1 stage 3wg/cu", "G2 LDS-DMA 2 stages 2wg/cu", "G1 LDS-DMA 1 stage 4wg/cu"};
   auto run_stream = [&](int u, int wgs, hipStream_t s) {
     switch (u) {
       case 1: hipLaunchKernelGGL(stream_k<1>, dim3(wgs), dim3(256), 0, s, n4, (const f32x4*)X, (f32x4*)Y, 1.0001f, 0.5f); break;
@@ -229,15 +328,15 @@ int main() {
 
   // correctness spot check of every GEMM variant against variant 0 (same k order => bitwise equal)
   std::vector<float> ref(4096), got(4096);
-  for (int v = 0; v < 8; ++v) {
+  for (int v = 0; v < NV; ++v) {
     CK(hipMemset(C, 0, (size_t)M * N * 4));
     run_gemm(v, s1); CK(hipStreamSynchronize(s1));
     CK(hipMemcpy(v == 0 ? ref.data() : got.data(), C + (size_t)12345 * N, 4096 * 4, hipMemcpyDeviceToHost));
     if (v > 0) { int bad = 0; for (int i = 0; i < 4096; ++i) bad += ref[i] != got[i]; printf("variant %d vs 0: %d mismatches of 4096\n", v, bad); }
   }
 
-  float tg[8];
-  for (int v = 0; v < 8; ++v) {
+  float tg[NV];
+  for (int v = 0; v < NV; ++v) {
     for (int r = 0; r < 200; ++r) run_gemm(v, s1);          // warm the clocks (~0.1 s)
     CK(hipEventRecord(e0, s1));
     for (int r = 0; r < REP; ++r) run_gemm(v, s1);
@@ -245,6 +344,7 @@ int main() {
     tg[v] = elapsed(e0, e1) / REP;
     printf("GEMM %-26s alone: %.3f ms  %.1f TFLOP/s\n", gname[v], tg[v], gflop / tg[v]);
   }
+  if (gemm_only) return 0;
   const double gb = 2.0 * n4 * 16 / 1e9;
   float ts[9][4097 / 256 + 1] = {};
   for (int u : {1, 2, 4, 8})
