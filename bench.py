@@ -113,7 +113,7 @@ BENCH_CFG = {   # the reference configs' hyper-parameters (configs/{simclr,byol,
 }
 
 
-def build(device, algo, steps_per_epoch=1000, lr_scale=1.0):
+def build(device, algo, steps_per_epoch=1000, lr_scale=1.0, arch="resnet50", reduce_bottom_conv=False):
     """The package's own trainer (ssv_amd.models.<algo>), constructed the way its __init__ does minus dataloaders, output
     directory and wandb; bench steps call its train_step(batch) - the drop-in surface - not a copy of it.  The returned step
     function carries the trainer as ``step.trainer``.  ``lr_scale`` scales the config's learning rate (the parity gate)."""
@@ -123,11 +123,11 @@ def build(device, algo, steps_per_epoch=1000, lr_scale=1.0):
     mod, name = ALGOS[algo]
     cls = getattr(importlib.import_module(mod), name)
     t = object.__new__(cls)
-    t.config = {"epochs": 1000, "encoder": {"reduce_bottom_conv": False}, "scheduler": {"name": "cosine", "warmup_epochs": 10}, **BENCH_CFG[algo]}
+    t.config = {"epochs": 1000, "encoder": {"reduce_bottom_conv": reduce_bottom_conv}, "scheduler": {"name": "cosine", "warmup_epochs": 10}, **BENCH_CFG[algo]}
     t.config["optimizer"] = dict(t.config["optimizer"], lr=t.config["optimizer"]["lr"] * lr_scale)
     t.device, t.train_loader = device, [None] * steps_per_epoch
     torch.manual_seed(420)                                     # identical weights on every rank
-    t._build("vit" if algo == "dino" else "resnet50")
+    t._build("vit" if algo == "dino" else arch)
     t.scheduler, t.warmup_epochs = train_utils.get_scheduler({**t.config["scheduler"], "epochs": 1000}, optimizer=t.optim)   # lr seeded to lr/10
     hdist.attach_grad_sync(t.optim, t._sync_modules())
     state = {"i": 0}
@@ -363,6 +363,50 @@ def parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, bat
     return gate, base
 
 
+def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
+    """BASELINE config 1 / BASELINE.md section 2: the reference's own CPU-runnable case - SimCLR resnet18 (reduce_bottom_conv) on 32 x 32 images at
+    batch 64 with configs/simclr.yaml's hyper-parameters (configs/simclr.yaml:38-39) - as `cpu_steps` timed steps of the CPU oracle on this
+    box's host cores, next to the same step on the HIP path (same views, fresh trainers on both sides; step-0 loss compared)."""
+    import oracle
+    from ssv_amd.utils import augmentations
+    g = torch.Generator(device=device).manual_seed(421)
+    source = torch.randint(0, 256, (batch, 32, 32, 3), generator=g, device=device, dtype=torch.uint8)
+    ids = torch.arange(batch, device=device, dtype=torch.int64)
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in AUG_CFG.items()}
+    cfg["random_resized_crop"] = {"size": [32, 32], "scale": [0.2, 1.0]}
+    cfg["normalize"] = {"mean": [0.4914, 0.4822, 0.4465], "std": [0.2470, 0.2435, 0.2616]}
+    tf = augmentations.get_transform(cfg)
+    views = tf.apply(source, ids, tf.draw(source, ids, 0))
+    v1, v2 = views[0], views[1]
+    hip_step, _ = build(device, "simclr", arch="resnet18", reduce_bottom_conv=True)
+    lr = hip_step.trainer.optim.param_groups[0]["lr"]                  # 2.0 seeded to 1e-12 + 0.2 by get_scheduler, as in the reference
+    hip0 = hip_step({"aug_1": v1, "aug_2": v2})
+    for _ in range(4):
+        hip_step({"aug_1": v1, "aug_2": v2})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(gpu_steps):
+        hip_step({"aug_1": v1, "aug_2": v2})
+    torch.cuda.synchronize()
+    gpu_dt = (time.perf_counter() - t0) / gpu_steps
+    del hip_step
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    m = oracle.SimCLROracle("resnet18", True, 128, lr=lr, weight_decay=1e-4)
+    c1, c2 = v1.cpu().contiguous(), v2.cpu().contiguous()
+    cpu0 = m.train_step(c1, c2)["loss"]                               # warm-up = step 0
+    t0 = time.perf_counter()
+    for _ in range(cpu_steps):
+        m.train_step(c1, c2)
+    cpu_dt = (time.perf_counter() - t0) / cpu_steps
+    return {"workload": f"SimCLR resnet18 (reduce_bottom_conv) 32x32, batch {batch}, configs/simclr.yaml hyper-parameters (lr seeded to {lr:.3g}), synthetic uint8 source -> GPU two-view augmentation",
+            "cpu": {"value": round(batch / cpu_dt, 1), "unit": "images/sec", "ms_per_step": round(cpu_dt * 1e3, 2), "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": f"{cpu_steps} timed steps (1 warm-up) of the oracle, torch fp32 CPU"},
+            "gpu": {"value": round(batch / gpu_dt, 1), "unit": "images/sec", "ms_per_step": round(gpu_dt * 1e3, 3),
+                    "sample": f"{gpu_steps} timed steps (5 warm-up) of the HIP trainer on the same views, loss read every step; at this size the step is bound by the "
+                              "host's kernel enqueue (tools/bench_cifar.py: bs 512 of the same network runs 35.8 k images/s)"},
+            "loss_step0": {"hip": round(hip0, 7), "cpu": round(cpu0, 7), "rel_err": float(f"{abs(hip0 - cpu0) / abs(cpu0):.2e}")}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,6 +442,7 @@ def main():
     source = torch.randint(0, 256, (b, s, s, 3), generator=g, device=device, dtype=torch.uint8)
     sample_ids = torch.arange(rank * b, (rank + 1) * b, device=device, dtype=torch.int64)
     rows = torch.arange(b, device=device, dtype=torch.int64)
+    hnn.data_ready(device)                                            # the generated source images: input_stream blocks wait for this event
     cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in AUG_CFG.items()}
     cfg["random_resized_crop"] = {"size": [s, s], "scale": [0.2, 1.0]}
     tf = augmentations.get_transform(cfg)
@@ -600,6 +645,8 @@ def main():
             out["parity_gate"] = parity_gate_dino(device, dino_cpu_losses)
         else:
             out["parity_gate"], out["cpu_baseline"] = parity_gate_and_cpu_baseline(device, args.algo, tf, source, sample_ids, rows)
+            if args.algo == "simclr":
+                out["config1"] = config1_line(device)
     elif rank == 0:
         out["cpu_baseline"], out["parity_gate"] = None, None
     if rank == 0:

@@ -146,7 +146,7 @@ class BucketedGradSync:
             if not spans:
                 return None
             lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
-            if sum(n for _, n in spans) != hi - lo or any(lo <= b[1] < hi or lo < b[2] <= hi for b in self.buckets):
+            if sum(n for _, n in spans) != hi - lo or any(lo < b[2] and b[1] < hi for b in self.buckets):
                 return None                 # not one contiguous, disjoint run of the arena: left to finish()
             self.buckets.append([name, lo, hi])
             self.index[key] = len(self.buckets) - 1
@@ -174,11 +174,17 @@ class BucketedGradSync:
         return (id(module), stage) in self.index
 
     def expect(self, module):
-        for b in self.of_module.get(id(module), ()):
+        """One more backward pass (through the outer module ``module``) will report these buckets; returns them - the pass hands the set back
+        to ``ready`` so that only a pass that was counted for a bucket can count it down."""
+        mine = tuple(self.of_module.get(id(module), ()))
+        for b in mine:
             self.pending[b] = self.pending.get(b, 0) + 1
+        return frozenset(mine)
 
-    def ready(self, module, stage):
+    def ready(self, module, stage, expected=None):
         b = self.index[(id(module), stage)]
+        if expected is not None and b not in expected:
+            return                           # a staged sub-module reached through a module that never expect()ed this bucket: not this pass's to report
         if b in self.launched or self.pending.get(b, 0) <= 0:
             return
         grad = self.arena.grad

@@ -45,8 +45,17 @@ def current_slot():
     return _SLOT
 
 
+def _dev_key(device):
+    """One key per physical device: 'cuda', 'cuda:0' and torch.device('cuda', 0) must not get separate stream pairs."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def join_view_streams(device):
     """Make the ambient stream wait for both view streams (kernels enqueued by Function.backward on them)."""
+    device = _dev_key(device)
     if device in _STREAMS:
         cur = torch.cuda.current_stream(device)
         for st in _STREAMS[device]:
@@ -60,6 +69,7 @@ class parallel_views:
     each node on the stream of its forward and joins the streams at the end of backward()."""
 
     def __init__(self, device, enabled=None):
+        device = _dev_key(device)
         self.device, self.enabled = device, (_VIEW_STREAMS if enabled is None else enabled) and device.type == "cuda"
 
     def __enter__(self):
@@ -107,9 +117,24 @@ class _ViewCtx:
 
 _INPUT_STREAM = os.environ.get("SSV_NO_INPUT_STREAM", "0") != "1"     # diagnostic switch: the next batch's augmentation on the ambient stream
 _INPUT_STREAMS = {}
+_DATA_READY = {}       # device -> event recorded behind the latest producer of resident input data (data_ready)
+
+
+def data_ready(device, stream=None):
+    """Producers of data that ``input_stream`` blocks will read - a loader's upload of its dataset, a source tensor generated on the device -
+    call this once the producing work is ENQUEUED (on ``stream``, default: the ambient stream): every later ``input_stream`` block waits for it.
+    Without it only the very first block of a process is ordered behind the ambient stream, and a second loader or a dataset uploaded with
+    ``non_blocking`` could be read before it is complete."""
+    device = _dev_key(device)
+    if device.type != "cuda":
+        return
+    ev = torch.cuda.Event()
+    ev.record(stream if stream is not None else torch.cuda.current_stream(device))
+    _DATA_READY[device] = ev
 
 
 def _view_stream_pair(device):
+    device = _dev_key(device)
     if device not in _STREAMS:
         _STREAMS[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
     return _STREAMS[device]
@@ -119,12 +144,12 @@ class input_stream:
     """with input_stream(device) as ins:  batch = <augmentation kernels>;  ins.publish(*tensors)
     The kernels inside run on a stream of their own, so the NEXT batch's views are built while the previous step's backward is still
     executing (the ambient stream is ordered behind that backward by the optimizer's join; with ``early_item`` the host gets here long before
-    it has run).  Everything they read must already be complete - static, resident data (the first entry waits for the ambient stream once) or
-    tensors created inside the block.  ``publish`` tells the caching allocator which other streams will read the outputs; on exit the ambient
+    it has run).  Everything they read must be resident data whose producer called ``data_ready`` (every entry waits for the latest such event; the
+    first entry also waits for the ambient stream once) or tensors created inside the block.  ``publish`` tells the caching allocator which other streams will read the outputs; on exit the ambient
     stream waits for the block's kernels.  Disabled (or on the CPU) the block simply runs on the ambient stream."""
 
     def __init__(self, device):
-        self.device = torch.device(device)
+        self.device = _dev_key(device)
         self.enabled = _INPUT_STREAM and _VIEW_STREAMS and self.device.type == "cuda"
 
     def __enter__(self):
@@ -134,6 +159,9 @@ class input_stream:
             if side is None:
                 side = _INPUT_STREAMS[self.device] = torch.cuda.Stream(self.device)
                 side.wait_stream(self.main)               # whatever built the dataset on the ambient stream
+            ready = _DATA_READY.get(self.device)
+            if ready is not None:
+                side.wait_event(ready)                    # EVERY entry: the latest producer of resident data (a no-op once it has completed)
             self.side = side
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
@@ -191,7 +219,8 @@ def stage_mark(tape, module, stage):
     ``module``'s stage ``stage`` has been enqueued by this pass.  Call it BEFORE running the stage's forward ops."""
     sync = None if tape is None else tape.sync
     if sync is not None and sync.has(module, stage):
-        tape.mark(lambda: sync.ready(module, stage))
+        expected = getattr(tape, "expected", None)
+        tape.mark(lambda: sync.ready(module, stage, expected))
 
 
 class Tape:
@@ -205,6 +234,7 @@ class Tape:
         self.root_needs_grad = root_needs_grad
         self.slot = _SLOT                     # which gradient slab this pass accumulates into
         self.sync = None                      # data parallel: the gradient exchange that wants to hear when a bucket is complete
+        self.expected = None                  # ... and the buckets this pass was counted for (BucketedGradSync.expect)
         self.uses = {}                        # id(input) -> number of recorded ops that read it
         self.last = ()                        # during backward: per input of the running op, "no other op will add to its gradient"
 
@@ -367,11 +397,11 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
     if y is not None:
         pass
     elif lazy is not None:
-        y, part = ops.conv2d_fwd_fused(src, weight, stride, pad, in_affine=affine, want_stats=want, keep_v=tape is not None)
+        y, part = ops.conv2d_fwd_fused(src, weight, stride, pad, in_affine=affine, want_stats=want, keep_v=tape is not None and _WINO_KEEP_V)
         if part is not None:
             y._bn_partials = part
     else:
-        fused = ops.conv2d_fwd_stats(src, weight, stride, pad, keep_v=tape is not None) if want else None
+        fused = ops.conv2d_fwd_stats(src, weight, stride, pad, keep_v=tape is not None and _WINO_KEEP_V) if want else None
         if fused is not None:
             y = fused[0]
             y._bn_partials = tuple(fused[1:])
@@ -403,6 +433,10 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
     return y
 
 
+# Memory switch: the Winograd forward keeps its transformed input V (16 x tiles x C floats = 4x the convolution's input, 5.2x on 7x7 maps: ~10 GB per
+# step at bs 512 over the ten Winograd layers and two views) for the weight gradient.  SSV_WINOGRAD_KEEP_V=0 drops it: the weight gradient of those
+# layers then runs on the direct implicit-GEMM kernel (about 2x slower per layer), everything else unchanged.
+_WINO_KEEP_V = os.environ.get("SSV_WINOGRAD_KEEP_V", "1") != "0"
 _ROW_STEM = os.environ.get("SSV_NO_ROW_STEM", "0") != "1"          # diagnostic switch: the 3-channel stem with both operands padded to 4 channels
 
 
@@ -840,7 +874,7 @@ class _Bridge(torch.autograd.Function):
         sync = getattr(module, "_grad_sync", None)
         if tape is not None and sync is not None:
             tape.sync = sync
-            sync.expect(module)                  # one more backward pass will report this module's gradient buckets
+            tape.expected = sync.expect(module)  # one more backward pass will report this module's gradient buckets
             stage_mark(tape, module, "rest")     # parameters outside any staged sub-module: complete when the whole tape has run
         y = module._run(tape, xin)
         ctx.tape, ctx.y, ctx.module = tape, y, module            # the tape keys the output by this object (it may be a LazySum)

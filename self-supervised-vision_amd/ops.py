@@ -289,7 +289,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     if compact is not None:
         _, wsh = _ohwi(w)
         fits = (gate is not None and gate.mask is not None and stride == 1 and wsh[2] == 1 and wsh[3] == 1 and pad == 0 and wsh[1] >= 128
-                and wsh[0] % 32 == 0 and tuple(gate.x.shape) == tuple(x_shape) and dy[0].numel() * dy.shape[0] < _MAX_ELEMS
+                and wsh[0] % 32 == 0 and wsh[1] % 4 == 0 and tuple(gate.x.shape) == tuple(x_shape) and dy[0].numel() * dy.shape[0] < _MAX_ELEMS
                 and x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] < _MAX_ELEMS)
         if not fits:
             addend, compact = compact.materialize(), None

@@ -115,6 +115,9 @@ class GpuTwoViewLoader:
             self.host = None
             self.images = host.to(device)                                    # uint8 [N,H,W,3] resident in HBM
         self.labels = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(device)
+        if torch.device(device).type == "cuda":
+            from .. import nn as hnn
+            hnn.data_ready(device)                                           # the uploads above: every later input_stream block is ordered behind them
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self._rank, self._world = rank, world
         self._setup_transforms(transforms)

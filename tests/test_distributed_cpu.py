@@ -224,6 +224,41 @@ def _bucketed_exchange_checks(rank, world, hdist):
     assert not sync.launched
     sync.finish()
     assert torch.equal(third.arena.grad, ref.arena.grad)
+    # a staged sub-module that is ALSO reachable through another outer module (aliasing): the pass through that other module never expect()ed the
+    # sub-module's buckets, so its report must not count them down (it would launch the all-reduce before the owner's second view has accumulated)
+    fourth = SimpleNamespace(arena=_FakeArena(params, rank, 3))
+    sync = hdist.BucketedGradSync(fourth, [net], bucketed=True)
+    mine = sync.expect(net)
+    assert mine == frozenset(range(4))
+    sync.expect(net)
+    sync.ready(net, 2, expected=frozenset())                              # a pass that was not counted for bucket 2 reports it: ignored
+    sync.ready(net, 2, expected=mine)
+    assert not sync.launched                                              # still one counted pass outstanding
+    sync.ready(net, 2, expected=mine)
+    assert sync.launched == {2}
+    sync.finish()
+    # a run of parameters lying strictly INSIDE an existing bucket is not a second bucket (interval intersection, not end-point containment)
+    class _Inner(torch.nn.Module):
+        def __init__(self, outer):
+            super().__init__()
+            self.inner = outer.s1                                         # s1's span (128, 384) lies inside a bucket made of s0..s2
+
+        def grad_stages(self):
+            return [list(self.inner.parameters())]
+
+    class _Wide(torch.nn.Module):
+        def __init__(self, outer):
+            super().__init__()
+            self.outer = outer
+
+        def grad_stages(self):
+            return [list(self.outer.s0.parameters()) + list(self.outer.s1.parameters()) + list(self.outer.s2.parameters())]
+    wide, inner = _Wide(net), _Inner(net)
+    fifth = SimpleNamespace(arena=_FakeArena(params, rank, 4))
+    sync = hdist.BucketedGradSync(fifth, [wide, inner], bucketed=True)
+    spans = sorted((lo, hi) for _, lo, hi in sync.buckets)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), spans     # disjoint
+    assert (0, 768) in spans and (128, 384) not in spans
 
 
 def _worker(rank, world, port, out):

@@ -333,6 +333,26 @@ def test_input_stream_and_early_loss_read_change_no_bit(dev):
     assert torch.equal(p0, p1)
 
 
+def test_input_stream_is_ordered_behind_the_latest_producer_of_resident_data(dev):
+    """A second producer in the same process (another loader, a dataset generated on the device): data enqueued on the ambient stream AFTER the side
+    stream exists must still be complete when an input_stream block reads it - every entry waits for the latest hnn.data_ready event, not only the
+    first one for the ambient stream.  And every spelling of a device shares one stream pair."""
+    from ssv_amd import nn as hnn
+    with hnn.input_stream(dev):
+        pass                                                            # the side stream exists from here on (its one-time wait is spent)
+    src = torch.empty(64 << 20, device=dev)
+    for i in range(24):                                                 # ~6 GB of fills queued on the ambient stream: still running when the block below is enqueued
+        src.fill_(float(i))
+    hnn.data_ready(dev)
+    with hnn.input_stream(dev) as ins:
+        got = src[::4099].clone()
+        ins.publish(got)
+    torch.cuda.synchronize()
+    assert bool((got == 23.0).all()), got[:8]
+    assert hnn._view_stream_pair("cuda") is hnn._view_stream_pair(torch.device("cuda", torch.cuda.current_device())) is hnn._view_stream_pair(dev)
+    assert hnn.input_stream("cuda").device == hnn.input_stream(dev).device
+
+
 def test_barlow_r18_steps_match_reference(dev, golden):
     from ssv_amd.models.barlow import BarlowTwins
     g = golden["step_level"]
