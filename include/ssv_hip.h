@@ -262,8 +262,11 @@ int ssv_bn_bwd_coef(int64_t M, int32_t C, const float* gamma, const float* save_
  * pixel, ReLU gate recomputed) inside the BatchNorm backward's reduction and apply passes - bit-identical to ssv_maxpool3x3s2_bwd followed by
  * ssv_bn_train_bwd, without the two full-resolution intermediates.  Workspace: ssv_bn_workspace_bytes(N*H*W, C). */
 int ssv_bn_relu_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* y, const float* scale, const float* shift,
-                            float* out, uint8_t* argmax, void* stream);
-int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dpool, const uint8_t* argmax, const float* y,
+                            float* out, uint8_t* argmax, float* xmax, void* stream);
+/* xmax (optional, [N][Ho][Wo][C] like out): the forward also leaves the RAW conv output y at every window's arg-max pixel; given back to the backward,
+ * its reduction pass (sum g, sum g * xhat) runs over the pooled positions - reading dpool and xmax instead of walking the full-resolution y.  Same terms,
+ * grouped per window instead of per pixel: equal to the full-resolution reduction to rounding; NULL on either side = the full-resolution walk. */
+int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dpool, const uint8_t* argmax, const float* y, const float* xmax,
                             const float* gamma, const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
                             float* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* out[c] (+)= sum_m x[m][c]   (bias gradient of nn.Linear); same workspace size as BN */

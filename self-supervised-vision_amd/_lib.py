@@ -96,8 +96,8 @@ SIGNATURES = {
     "ssv_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ssv_bn_train_fwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_bn_train_bwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
-    "ssv_bn_relu_maxpool_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ssv_bn_relu_maxpool_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "ssv_bn_relu_maxpool_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_bn_relu_maxpool_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_colsum": (C.c_int, [_i64, _i32, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_maxpool3x3s2_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ssv_maxpool3x3s2_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

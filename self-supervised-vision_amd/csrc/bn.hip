@@ -660,7 +660,7 @@ extern "C" int ssv_bn_bwd_coef(int64_t M, int32_t C, const float* gamma, const f
 namespace {
 __global__ void __launch_bounds__(256)
 bn_relu_maxpool_fwd_k(int N, int H, int W, int C, int Ho, int Wo, const float* __restrict__ y, const float* __restrict__ scale,
-                      const float* __restrict__ shift, float* __restrict__ out, uint8_t* __restrict__ am) {
+                      const float* __restrict__ shift, float* __restrict__ out, uint8_t* __restrict__ am, float* __restrict__ xmax) {
   const int C4 = C / 4;
   const int64_t total = (int64_t)N * Ho * Wo * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -671,6 +671,7 @@ bn_relu_maxpool_fwd_k(int N, int H, int W, int C, int Ho, int Wo, const float* _
     const int n = (int)(t / Ho);
     const f32x4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 braw = {0.f, 0.f, 0.f, 0.f};                       // the raw conv output at the arg-max pixel (xmax: the backward's reduction reads it)
     int bi[4] = {0, 0, 0, 0};
     bool first[4] = {true, true, true, true};
 #pragma unroll
@@ -681,17 +682,19 @@ bn_relu_maxpool_fwd_k(int N, int H, int W, int C, int Ho, int Wo, const float* _
       for (int s_ = 0; s_ < 3; ++s_) {
         const int wi = wo * 2 - 1 + s_;
         if ((unsigned)wi >= (unsigned)W) continue;
-        f32x4 v = fma4(ld4(y + (((size_t)n * H + hi) * W + wi) * C + 4 * c4), sc, sh);
+        const f32x4 raw = ld4(y + (((size_t)n * H + hi) * W + wi) * C + 4 * c4);
+        f32x4 v = fma4(raw, sc, sh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = fmaxf(v[e], 0.f);                                                     // the ReLU of bn_apply_k
-          if (first[e] || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s_; first[e] = false; }   // ties: first, like ATen
+          if (first[e] || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; braw[e] = raw[e]; bi[e] = r * 3 + s_; first[e] = false; }   // ties: first, like ATen
         }
       }
     }
     st4(out + (size_t)i * 4, best);
     uchar4 a; a.x = (uint8_t)bi[0]; a.y = (uint8_t)bi[1]; a.z = (uint8_t)bi[2]; a.w = (uint8_t)bi[3];
     reinterpret_cast<uchar4*>(am)[i] = a;
+    if (xmax) st4(xmax + (size_t)i * 4, braw);
   }
 }
 
@@ -769,7 +772,7 @@ bn_pool_bwd_k(int64_t M, int C, int CT, int RT, int rpb, int H, int W, int Ho, i
 }  // namespace
 
 extern "C" int ssv_bn_relu_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* y, const float* scale, const float* shift,
-                                       float* out, uint8_t* argmax, void* stream) {
+                                       float* out, uint8_t* argmax, float* xmax, void* stream) {
   SSV_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ssv_bn_relu_maxpool_fwd: bad shape (C %% 4 == 0 required)");
   SSV_REQUIRE(y && scale && shift && out && argmax, "ssv_bn_relu_maxpool_fwd: null pointer");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -778,12 +781,12 @@ extern "C" int ssv_bn_relu_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t 
   const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(bn_relu_maxpool_fwd_k, dim3((unsigned)blocks), dim3(256), 0, s, N, H, W, C, Ho, Wo, y, scale, shift, out, argmax);
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_k, dim3((unsigned)blocks), dim3(256), 0, s, N, H, W, C, Ho, Wo, y, scale, shift, out, argmax, xmax);
   SSV_CHECK_LAUNCH("ssv_bn_relu_maxpool_fwd");
   return SSV_OK;
 }
 
-extern "C" int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dpool, const uint8_t* argmax, const float* y,
+extern "C" int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dpool, const uint8_t* argmax, const float* y, const float* xmax,
                                        const float* gamma, const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
                                        float* dy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   const int64_t M = (int64_t)N * H * W;
@@ -801,9 +804,23 @@ extern "C" int ssv_bn_relu_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t 
   float* k1 = psgx + (size_t)p.nblk * C;
   float* k2 = k1 + C;
   const dim3 grid(p.nblk, p.GY);
-  hipLaunchKernelGGL((bn_pool_bwd_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, H, W, Ho, Wo, dpool, argmax, y, gamma, save_mean, save_invstd,
-                     scale, shift, (const float*)nullptr, (const float*)nullptr, psg, psgx, (float*)nullptr);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, p.nblk, (const float*)psg, (const float*)psgx,
+  int nred = p.nblk;
+  if (xmax && bn_plan((int64_t)N * Ho * Wo, C).nblk > p.nblk) xmax = nullptr;      // the pooled plan's partials must fit the workspace laid out above (they do but for tiny maps)
+  if (xmax) {
+    // Reduction at the POOLED resolution (round 4): sum g and sum g * xhat over the 112^2 map are sums over the pooled positions - a pixel's g is the sum of
+    // the dpool of the windows whose arg-max it is, gated by the ReLU bit of that pixel, and the forward kept the raw conv output of every window's arg-max
+    // pixel (xmax) - so the pass reads dpool and xmax (2 x 1/4 of the map) instead of walking the full-resolution conv output: the generic reduction
+    // kernel with the recomputed gate, on [N*Ho*Wo][C].  Same terms as the full-resolution walk, grouped per window instead of per pixel (rounding-level).
+    const int64_t Mp = (int64_t)N * Ho * Wo;
+    const BnPlan pp = bn_plan(Mp, C);
+    nred = pp.nblk;
+    hipLaunchKernelGGL((bn_bwd_reduce_k<2>), dim3(pp.nblk, pp.GY), dim3(256), 0, s, Mp, C, pp.CT, pp.RT, pp.rpb, dpool, (const float*)nullptr,
+                       (const uint8_t*)nullptr, xmax, save_mean, save_invstd, scale, shift, psg, psgx);
+  } else {
+    hipLaunchKernelGGL((bn_pool_bwd_k<false>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, H, W, Ho, Wo, dpool, argmax, y, gamma, save_mean, save_invstd,
+                       scale, shift, (const float*)nullptr, (const float*)nullptr, psg, psgx, (float*)nullptr);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, FIN_C)), dim3(256), 0, s, M, C, nred, (const float*)psg, (const float*)psgx,
                      dgamma, dbeta, accumulate, k1, k2);
   hipLaunchKernelGGL((bn_pool_bwd_k<true>), grid, dim3(256), 0, s, M, C, p.CT, p.RT, p.rpb, H, W, Ho, Wo, dpool, argmax, y, gamma, save_mean, save_invstd,
                      scale, shift, (const float*)k1, (const float*)k2, (float*)nullptr, (float*)nullptr, dy);

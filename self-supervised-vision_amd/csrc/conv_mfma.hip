@@ -39,11 +39,38 @@
 #else
 #define SSV_CONV_ATTR
 #endif
+#ifndef SSV_WHATIF
+#define SSV_WHATIF 0        // diagnostic builds only (TIMING what-ifs, results are wrong): bit 0 = the forward kernel's main loop issues no MFMAs, bit 1 = its
+#endif                      // epilogue stores nothing, bit 2 = its activation operand is read through an empty descriptor (every load returns zero, no traffic)
+#ifndef SSV_EXP_WGPRIO
+#define SSV_EXP_WGPRIO 0    // diagnostic builds only: 1 = every workgroup of the forward kernel takes a STATIC issue priority from its arrival order on its CU
+#endif                      // (consecutive arrivals get 0, 1, 2 -> s_setprio 0, 1, 3): does asymmetry between the residents break their lock-step?
+#ifndef SSV_EXP_PRIO
+#define SSV_EXP_PRIO 0      // diagnostic builds only: s_setprio level of a wave while it is in the MFMA part of a k-tile (0 = never raised, the shipped behaviour)
+#endif
 #ifndef SSV_CONV_WGPC
 #define SSV_CONV_WGPC 3     // resident workgroups per CU the forward / data-gradient kernels are compiled for
 #endif
 
 namespace {
+
+#if SSV_EXP_WGPRIO
+__device__ unsigned g_cu_arrivals[4096];
+__device__ __forceinline__ void wg_static_priority() {
+  __shared__ int s_prio;
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // HW_REG_XCC_ID [3:0]
+    const unsigned idx = ((xcc & 15) << 8) | ((hw >> 8) & 0xff);
+    s_prio = (int)(atomicAdd(&g_cu_arrivals[idx & 4095], 1u) % 3u);
+  }
+  __syncthreads();
+  const int pr = s_prio;
+  if (pr == 2) __builtin_amdgcn_s_setprio(3);
+  else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+#endif
 
 constexpr int GBK = 16;   // K-step of the generic (scalar gather) path and the granularity of wgrad row chunks
 
@@ -223,6 +250,15 @@ __device__ __forceinline__ void load_frags(Frags<TM, TN>& f, const float* __rest
 
 template <int TM, int TN>
 __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+#if SSV_WHATIF & 1
+  // what-if: the fragments are still read from LDS (kept alive by one add per fragment), no matrix instruction is issued
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[tm][tn][t] += f.a[tm][t] + f.b[tn][t];
+#else
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -230,6 +266,7 @@ __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][t], f.b[tn][t], acc[tm][tn], 0, 0, 0);
+#endif
 }
 
 // compile-time interleave of one MFMA group with N memory instructions of kind `mask` (LLVM sched groups:
@@ -289,6 +326,7 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
     Frags<TM, TN> fr;
     for (int kt = 0; kt < nkt; ++kt) {
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SSV_EXP_PRIO > 0) __builtin_amdgcn_s_setprio(SSV_EXP_PRIO);
       load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr, As, Bs, wr0, wc0, lane, 0);
       load_tile();
       mma_frags<TM, TN>(fr, acc);
@@ -302,6 +340,7 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
         load_frags<TM, TN, A_ROWK, B_ROWK, LDA, LDB>(fr, As, Bs, wr0, wc0, lane, ks);
         mma_frags<TM, TN>(fr, acc);
       }
+      if constexpr (SSV_EXP_PRIO > 0) __builtin_amdgcn_s_setprio(0);
       __syncthreads();
       if (kt + 1 < nkt) { xform_tile(); store_tile(0); __syncthreads(); }
     }
@@ -313,6 +352,46 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
     }
 #endif
 #undef STAMP
+  }
+}
+
+// Two LDS stages, ONE barrier per k-tile (round 4 experiment S2, plain GEMM-shaped launches with long k-loops only): tile kt is multiplied out of stage
+// kt & 1 while tile kt + 1 goes registers -> the other stage (its readers passed the last barrier) and tile kt + 2 global -> registers; the ds_writes are
+// interleaved one per MFMA of the first substep, the buffer loads one per MFMA of the second.  2 x 36.9 KB of LDS: 2 workgroups per CU.
+template <int TM, int TN, int LDT, int BK, int NLD, int STAGE_FLOATS, class LoadTile, class StoreTile>
+__device__ __forceinline__ void k_loop2(int nkt, const float* As, const float* Bs, int wr0, int wc0, int lane,
+                                        f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile) {
+  if (nkt <= 0) return;
+  constexpr int NS = BK / 8;
+  constexpr int NM = 4 * TM * TN;
+  static_assert(NS >= 2, "two substeps carry the staging traffic");
+  load_tile();
+  store_tile(0);
+  load_tile();
+  __syncthreads();
+  Frags<TM, TN> fr;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* a = As + (kt & 1) * STAGE_FLOATS;
+    const float* b = Bs + (kt & 1) * STAGE_FLOATS;
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<TM, TN, true, true, LDT, LDT>(fr, a, b, wr0, wc0, lane, 0);
+    store_tile((kt + 1) & 1);                 // registers of tile kt + 1 (zeros past the last tile: never read)
+    mma_frags<TM, TN>(fr, acc);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    SSV_INTERLEAVE(NM, NLD, 0x200);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<TM, TN, true, true, LDT, LDT>(fr, a, b, wr0, wc0, lane, 1);
+    load_tile();                              // tile kt + 2 -> registers
+    mma_frags<TM, TN>(fr, acc);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    SSV_INTERLEAVE(NM, NLD, 0x20);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 2; ks < NS; ++ks) {
+      load_frags<TM, TN, true, true, LDT, LDT>(fr, a, b, wr0, wc0, lane, ks);
+      mma_frags<TM, TN>(fr, acc);
+    }
+    __syncthreads();
   }
 }
 
@@ -345,6 +424,9 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
 //      3 = write gelu(v) ONLY (the same forward when no backward will ask for the pre-activation).
 __device__ __forceinline__ void bstore4(rsrc_t rs, int voff_bytes, f32x4 v) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+#if SSV_WHATIF & 2
+  if (v[0] == 1.2345e38f)      // what-if: (practically) never true - the value stays live, no store reaches memory
+#endif
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, voff_bytes, 0, 0);
 }
 
@@ -534,12 +616,12 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false, bool S2 = false>
 // Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
 // 28x28 layers); the two-target gate (GATE 3) needs 218.  (kernel_resources.py lists every variant; r03_experiments_step_time.txt the A/Bs.)
-__global__ void __launch_bounds__(256, (OPM == 2 || GATE == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC)) SSV_CONV_ATTR
+__global__ void __launch_bounds__(256, (OPM == 2 || GATE == 3 || S2) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC)) SSV_CONV_ATTR
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -549,7 +631,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   constexpr bool DYF = OPM == 1, SUM = OPM == 2;
   static_assert(OPM == 0 || (VEC && C4 == 0 && !XF), "the formed-on-load operands are the float4 path");
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);     // the vectorised epilogue's staging area (one 32-row slab per wave)
-  constexpr int SMEM = (VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE;
+  static_assert(!S2 || (VEC && C4 == 0 && !XF && OPM == 0), "the two-stage loop serves the plain float4 path");
+  constexpr int SMEM = S2 ? 2 * STAGE : ((VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE);
+  static_assert(!S2 || 2 * STAGE >= EP_FLOATS, "epilogue staging must fit the two stages");
   __shared__ __attribute__((aligned(16))) float smem[SMEM + SSV_EXP_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
   float* As = smem;
@@ -564,6 +648,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
+#if SSV_EXP_WGPRIO
+  wg_static_priority();
+#endif
 
   if constexpr (VEC && C4 == 2) {
     // ---- the image stem on the UNPADDED 3-channel input: for one filter row r the S taps x 3 channels of an output pixel are 3 S CONTIGUOUS
@@ -574,7 +661,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     static_assert(BK == 24 && BM == 256, "one staged output row per thread, six float4 per row");
     constexpr int CHN = BK / 4;
     constexpr int BF = (BN * CHN + 255) / 256;                     // weight float4s per thread
-    const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * 12u);
+    const rsrc_t rx = make_rsrc(x, (SSV_WHATIF & 4) ? 0u : (unsigned)p.N * p.H * p.W * 12u);
     const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.R * BK * 4u);
     int hi0, rowbase;
     unsigned wmask = 0;                                            // bit px: tap column px of this output pixel lies inside the image row
@@ -695,7 +782,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     const int chunk = (tid % CH) * 4, rsub = tid / CH;
     // Loader state per staged row: byte offset of (n, hi0, wi0, chunk) in x, top-left input coordinate.  Per tile the
     // tap adds ONE uniform offset; invalid rows / taps get the out-of-range offset and come back as zeros.
-    const rsrc_t rx = make_rsrc(x, (unsigned)p.N * p.H * p.W * p.C * 4u);
+    const rsrc_t rx = make_rsrc(x, (SSV_WHATIF & 4) ? 0u : (unsigned)p.N * p.H * p.W * p.C * 4u);
     const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.RSC * 4u);
     int hi0[AP], wi0[AP], aoff[AP];
 #pragma unroll
@@ -823,12 +910,14 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       }
     };
     auto store_tile = [&](int buf) {
+      const int so = S2 ? buf * STAGE : 0;
 #pragma unroll
-      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = ra[i];
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[so + (rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
-      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + chunk]) = rb[i];
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[so + (rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
+    if constexpr (S2) k_loop2<TM, TN, LDT, BK, AP + BP, STAGE>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+    else k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
     static_assert(BK == GBK, "generic path is BK=16");
@@ -1542,6 +1631,12 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   } else if (d->C == 4) {                                      // image stems (3 channels padded to 4): tap-vector gather
     FWD_TILE(32, false, true, false);
   } else if (d->C % 32 == 0) {
+#ifdef SSV_EXP_S2      // diagnostic builds only: two-stage main loop for wide plain launches with at least SSV_EXP_S2 k-tiles
+    if (wide && groups <= 1 && p.RSC / 32 >= SSV_EXP_S2) {
+      hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 0, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y);
+      return SSV_OK;
+    }
+#endif
     FWD_TILE(32, false, false, false);
   } else if (d->C % 16 == 0) {
     FWD_TILE(16, false, false, false);
@@ -1764,6 +1859,12 @@ extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const
   p.aux_out = act;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
   // K-step 32 only: its LDS stage is what the vectorised epilogue (the one that writes the second tensor) needs
+#ifdef SSV_EXP_S2
+  if (p.RSC / 32 >= SSV_EXP_S2) {
+    if (h) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 1, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
+    else   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 3, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, act);
+  } else
+#endif
   if (h) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 1>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
   else   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 3>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, act);
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
@@ -1803,6 +1904,11 @@ extern "C" int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, 
   ConvKP p = make_kp(d);
   p.aux_in = h;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+#ifdef SSV_EXP_S2
+  if (p.RSC / 32 >= SSV_EXP_S2)
+    hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  else
+#endif
   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   SSV_CHECK_LAUNCH("ssv_linear_fwd_gelugrad");
   return SSV_OK;

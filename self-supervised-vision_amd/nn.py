@@ -614,6 +614,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False, defer=False):
 
 
 _FUSE_STEM_POOL = os.environ.get("SSV_NO_STEM_POOL_FUSION", "0") != "1"    # diagnostic switch
+_POOLED_STEM_REDUCE = os.environ.get("SSV_NO_POOLED_STEM_REDUCE", "0") != "1"    # diagnostic switch: the stem BatchNorm backward's sums from a walk over the full-resolution map
 
 
 def bn_relu_maxpool(tape, x, bn):
@@ -631,12 +632,14 @@ def bn_relu_maxpool(tape, x, bn):
     mean, invstd, scale, shift = ops.bn_stats_finalize(m, c, partials, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                                        eps=bn.eps, momentum=bn.momentum)
     _bn_order_record(bn, x)
-    y, am = ops.bn_relu_maxpool_fwd(x, scale, shift)
+    keep = tape is not None and _POOLED_STEM_REDUCE
+    y, am, *rest = ops.bn_relu_maxpool_fwd(x, scale, shift, keep_xmax=keep)
     if tape is not None:
         slot = tape.slot
+        xmax = rest[0] if keep else None            # the conv output at every window's arg-max: the backward's reduction reads 2 x 1/4 of the map instead of all of it
 
         def bwd(dy, existing):
-            dx = ops.bn_relu_maxpool_bwd(dy, am, x, bn.weight, mean, invstd, scale, shift, grad_of(bn.weight, slot), grad_of(bn.bias, slot))
+            dx = ops.bn_relu_maxpool_bwd(dy, am, x, bn.weight, mean, invstd, scale, shift, grad_of(bn.weight, slot), grad_of(bn.bias, slot), xmax=xmax)
             return (_accum(existing[0], dx),)
         tape.record((x,), y, bwd)
     return y

@@ -534,24 +534,27 @@ def colsum(x, out, accumulate=True):
     return out
 
 
-def bn_relu_maxpool_fwd(y, scale, shift):
-    """maxpool3x3s2(relu(y * scale + shift)) of a raw conv output [N,H,W,C] in one pass: returns (pooled, argmax slots)."""
+def bn_relu_maxpool_fwd(y, scale, shift, keep_xmax=False):
+    """maxpool3x3s2(relu(y * scale + shift)) of a raw conv output [N,H,W,C] in one pass: returns (pooled, argmax slots[, xmax]).
+    ``keep_xmax``: also the raw conv output at every window's arg-max pixel - what lets the backward reduce at the pooled resolution."""
     _lib._dev(y, scale, shift)
     n, h, w, c = y.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     out = _empty((n, ho, wo, c), y)
     am = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=y.device)
-    call("ssv_bn_relu_maxpool_fwd", n, h, w, c, ptr(y), ptr(scale), ptr(shift), ptr(out), ptr(am), stream())
-    return out, am
+    xmax = _empty((n, ho, wo, c), y) if keep_xmax else None
+    call("ssv_bn_relu_maxpool_fwd", n, h, w, c, ptr(y), ptr(scale), ptr(shift), ptr(out), ptr(am), ptr(xmax), stream())
+    return (out, am, xmax) if keep_xmax else (out, am)
 
 
-def bn_relu_maxpool_bwd(dpool, am, y, gamma, mean, invstd, scale, shift, dgamma, dbeta, accumulate=True):
-    """Gradient w.r.t. the raw conv output y through maxpool, ReLU and BatchNorm, plus dgamma / dbeta."""
-    _lib._dev(dpool, am, y)
+def bn_relu_maxpool_bwd(dpool, am, y, gamma, mean, invstd, scale, shift, dgamma, dbeta, accumulate=True, xmax=None):
+    """Gradient w.r.t. the raw conv output y through maxpool, ReLU and BatchNorm, plus dgamma / dbeta.  ``xmax`` (from the forward): the
+    reduction pass runs over the pooled positions instead of the full-resolution map (equal to rounding)."""
+    _lib._dev(dpool, am, y, xmax)
     n, h, w, c = y.shape
     dy = torch.empty_like(y)
     ws = workspace.get(_lib.load().ssv_bn_workspace_bytes(n * h * w, c), y.device)
-    call("ssv_bn_relu_maxpool_bwd", n, h, w, c, ptr(dpool), ptr(am), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+    call("ssv_bn_relu_maxpool_bwd", n, h, w, c, ptr(dpool), ptr(am), ptr(y), ptr(xmax), ptr(gamma), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
          ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream())
     return dy
 

@@ -559,27 +559,50 @@ def test_batchnorm_backward_reduced_in_the_conv_epilogue_matches_the_two_pass_fo
     assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"
 
 
+@pytest.mark.parametrize("pooled", [False, True])
 @pytest.mark.parametrize("arch,rbc,size,b", [("resnet50", False, 64, 5), ("resnet18", True, 32, 12), ("resnet50", False, 70, 3)])
-def test_fused_stem_batchnorm_relu_maxpool_is_bitwise_the_three_kernel_form(dev, arch, rbc, size, b):
+def test_fused_stem_batchnorm_relu_maxpool_against_the_three_kernel_form(dev, arch, rbc, size, b, pooled):
     """The image stem's maxpool(relu(bn1(conv1(x)))) as ONE pass forward (pooled map + argmax slots out of the raw conv output) and
-    one reduce + one apply pass backward (the full-resolution activation and its gradient are never written): identical bits to
-    BatchNorm -> MaxPool -> their two backward kernels, odd sizes (35 x 35 feature map, ragged windows) included."""
+    one reduce + one apply pass backward (the full-resolution activation and its gradient are never written), odd sizes (35 x 35 feature
+    map, ragged windows) included.  With the reduction walking the full-resolution map (pooled = False, SSV_NO_POOLED_STEM_REDUCE=1): identical
+    bits to BatchNorm -> MaxPool -> their two backward kernels.  With the shipped reduction over the POOLED positions (dpool and the conv output
+    kept at every window's arg-max): the forward is identical, the stem's gradients are the same sums grouped per window instead of per pixel -
+    equal to rounding."""
     from ssv_amd import nn as hnn
     a1, a2 = seeded_randn(1700, b, 3, size, size), seeded_randn(1701, b, 3, size, size)
     outs = []
-    for fuse in (True, False):
-        prev, hnn._FUSE_STEM_POOL = hnn._FUSE_STEM_POOL, fuse
-        try:
-            m = _Step(dev, arch, rbc)
-            loss, z1, z2 = m.step(a1, a2)
-            torch.cuda.synchronize()
-            outs.append((loss, z1.cpu(), z2.cpu(), m.grads.cpu().clone(), m.optim.arena.data.cpu().clone()))
-        finally:
-            hnn._FUSE_STEM_POOL = prev
+    prev_p, hnn._POOLED_STEM_REDUCE = hnn._POOLED_STEM_REDUCE, pooled
+    try:
+        for fuse in (True, False):
+            prev, hnn._FUSE_STEM_POOL = hnn._FUSE_STEM_POOL, fuse
+            try:
+                m = _Step(dev, arch, rbc)
+                loss, z1, z2 = m.step(a1, a2)
+                torch.cuda.synchronize()
+                outs.append((loss, z1.cpu(), z2.cpu(), m.grads.cpu().clone(), m.optim.arena.data.cpu().clone(), m))
+            finally:
+                hnn._FUSE_STEM_POOL = prev
+    finally:
+        hnn._POOLED_STEM_REDUCE = prev_p
     f, u = outs
     assert f[0] == u[0] and torch.equal(f[1], u[1]) and torch.equal(f[2], u[2])
-    assert torch.equal(f[3], u[3]), f"gradients differ: max {float((f[3] - u[3]).abs().max()):.3e}"
-    assert torch.equal(f[4], u[4])
+    if not pooled:
+        assert torch.equal(f[3], u[3]), f"gradients differ: max {float((f[3] - u[3]).abs().max()):.3e}"
+        assert torch.equal(f[4], u[4])
+        return
+    m = f[5]
+    worst, moved = 0.0, False
+    for p, off in zip(m.params(), m.optim.arena.offsets):
+        a, r = f[3][off:off + p.numel()].double(), u[3][off:off + p.numel()].double()
+        if float(r.norm()) < 1e-5:
+            assert float(a.abs().max()) < 1e-5
+            continue
+        e = float((a - r).norm() / r.norm())
+        moved = moved or e > 0
+        worst = max(worst, e)
+    # only the stem's own tensors (conv1.weight, bn1.weight, bn1.bias) see the regrouped sums; everything behind the pooling layer is untouched
+    assert worst < 1e-5, f"worst per-tensor gradient difference {worst:.2e}"
+    assert moved or size < 40, "the pooled reduction did not run"
 
 
 @pytest.mark.parametrize("arch,size,b", [("resnet50", 64, 6), ("resnet50", 96, 3)])
