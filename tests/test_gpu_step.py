@@ -508,6 +508,9 @@ def test_fused_batchnorm_chain_is_bitwise_the_materialised_one(dev, arch, rbc, s
     # the projection shortcut's backward sums come from the gate epilogue only when that BatchNorm is folded (i.e. in the fused run): a
     # different summation order, covered by its own test - here both runs reduce it in its own pass so that the comparison stays bit for bit
     prev_gate, hnn._FUSE_SHORTCUT_GATE = hnn._FUSE_SHORTCUT_GATE, False
+    # likewise the stem: its fused BatchNorm + ReLU + MaxPool (fused run only) reduces over the pooled positions by default - the same sums grouped per
+    # window (test_fused_stem_batchnorm_relu_maxpool_against_the_three_kernel_form); here it walks the full-resolution map like the three-kernel form
+    prev_pool, hnn._POOLED_STEM_REDUCE = hnn._POOLED_STEM_REDUCE, False
     try:
         for fuse in (True, False):
             prev, hnn._FUSE_BN_APPLY = hnn._FUSE_BN_APPLY, fuse
@@ -521,6 +524,7 @@ def test_fused_batchnorm_chain_is_bitwise_the_materialised_one(dev, arch, rbc, s
                 hnn._FUSE_BN_APPLY = prev
     finally:
         hnn._FUSE_SHORTCUT_GATE = prev_gate
+        hnn._POOLED_STEM_REDUCE = prev_pool
     f, u = outs
     assert f[0] == u[0] and torch.equal(f[1], u[1]) and torch.equal(f[2], u[2])
     assert torch.equal(f[3], u[3]), f"gradients differ: max {float((f[3] - u[3]).abs().max()):.3e}"
