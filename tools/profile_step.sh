@@ -17,6 +17,9 @@ stats() {   # $1 = name, env SSV_SINGLE_STREAM inherited
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof_$1 -- python3 $ARGS > $OUT/_prof_$1.log 2>&1
   f=$(find $OUT/_prof_$1 -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats_$1.csv
+  # per-step sums from the trace itself: the --stats totals include the cold first step of the process (tools/kstats_steady.py)
+  t=$(find $OUT/_prof_$1 -name '*kernel_trace.csv' | head -1)
+  [ "$1" = single_stream ] && [ -n "$t" ] && python3 tools/kstats_steady.py "$t" > $OUT/${TAG}_family_time_per_step.txt
 }
 SSV_SINGLE_STREAM=1 stats single_stream
 SSV_SINGLE_STREAM=0 stats two_streams
