@@ -366,6 +366,27 @@ def parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, bat
     return gate, base
 
 
+def read_committed_counters(profiles_dir, fname):
+    """A counter file committed under profiles/ and the build it says it was measured on: (data, src_sha16 | None, path relative to the repo) - or
+    (None, None, None) when the file does not exist.  JSON files (tools/pmc_traffic.py, tools/pmc_mfma.py) carry `src_sha16`; the per-layer CSV of
+    tools/bench_conv.py carries it in its last row (`BUILD src_sha16=... lib_sha16=...`).  The caller replays the data only when src_sha16 equals the
+    loaded library's ssv_source_sha16(): counters of another build never reach the bench line."""
+    pth = os.path.join(profiles_dir, fname)
+    if not os.path.exists(pth):
+        return None, None, None
+    rel = os.path.relpath(pth, ROOT)
+    if pth.endswith(".csv"):
+        import csv
+        with open(pth, newline="") as fh:
+            rows_ = list(csv.DictReader(fh))
+        ident = next((r["layer"] for r in rows_ if r["layer"].startswith("BUILD ")), "")
+        src = dict(kv.split("=") for kv in ident.split()[1:]).get("src_sha16") if ident else None
+        return rows_, src, rel
+    with open(pth) as fh:
+        data = json.load(fh)
+    return data, data.get("src_sha16"), rel
+
+
 def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
     """BASELINE config 1 / BASELINE.md section 2: the reference's own CPU-runnable case - SimCLR resnet18 (reduce_bottom_conv) on 32 x 32 images at
     batch 64 with configs/simclr.yaml's hyper-parameters (configs/simclr.yaml:38-39) - as `cpu_steps` timed steps of the CPU oracle on this
@@ -543,24 +564,13 @@ def main():
         stale, used = [], {}
 
         def committed(fname, kind):
-            pth = os.path.join(ROOT, "profiles", fname)
-            if not os.path.exists(pth):
+            data, src, rel = read_committed_counters(os.path.join(ROOT, "profiles"), fname)
+            if rel is None:
                 return None
-            if pth.endswith(".csv"):
-                import csv
-                with open(pth, newline="") as fh:
-                    rows_ = list(csv.DictReader(fh))
-                ident = next((r["layer"] for r in rows_ if r["layer"].startswith("BUILD ")), "")
-                src = dict(kv.split("=") for kv in ident.split()[1:]).get("src_sha16") if ident else None
-                data = rows_
-            else:
-                with open(pth) as fh:
-                    data = json.load(fh)
-                src = data.get("src_sha16")
             if src != my_src:
-                stale.append({"file": os.path.relpath(pth, ROOT), "measured_on_src_sha16": src})
+                stale.append({"file": rel, "measured_on_src_sha16": src})
                 return None
-            used[kind] = os.path.relpath(pth, ROOT)
+            used[kind] = rel
             return data
         traffic, whole_traffic, pmc = None, None, None
         if args.algo in PMC_FILES:       # HBM bytes of the same kernels: rocprofv3 PMC FETCH_SIZE, WRITE_SIZE, corrected as the guide prescribes

@@ -69,3 +69,49 @@ def test_bench_gpus_2_reaches_two_ranks_of_a_process_group():
     assert res.returncode != 0
     assert "no HIP device visible (rank 0 of 2)" in res.stderr and "no HIP device visible (rank 1 of 2)" in res.stderr, res.stderr[-3000:]
     assert "the process group has" not in res.stderr
+
+
+def test_bench_replays_counters_only_with_their_build_identity(tmp_path):
+    """bench.py's reader of the committed counter files: the build identity (src_sha16 = ssv_source_sha16() of the profiled library) comes back with the data, from the
+    JSON files of tools/pmc_*.py and from the last row of tools/bench_conv.py's CSV; a file without it, or a missing file, yields None - the caller then prints
+    `traffic: null` / `counters_stale: true` instead of another build's numbers.  The committed round-4 files carry an identity."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    (tmp_path / "a.json").write_text(json.dumps({"src_sha16": "0123456789abcdef", "per_step_gb": {"conv_fwd": {"fetch": 1.0, "write": 2.0}}}))
+    (tmp_path / "old.json").write_text(json.dumps({"per_step_gb": {}}))                       # a round-3 file: no identity
+    (tmp_path / "l.csv").write_text("layer,count,fwd_GB\nTOTAL fwd,,61.5\nBUILD src_sha16=0123456789abcdef lib_sha16=ffff,batch 512\n")
+    (tmp_path / "l_old.csv").write_text("layer,count,fwd_GB\nTOTAL fwd,,61.5\n")
+    data, src, rel = bench.read_committed_counters(str(tmp_path), "a.json")
+    assert src == "0123456789abcdef" and data["per_step_gb"]["conv_fwd"]["write"] == 2.0 and rel.endswith("a.json")
+    assert bench.read_committed_counters(str(tmp_path), "old.json")[1] is None
+    rows, src, _ = bench.read_committed_counters(str(tmp_path), "l.csv")
+    assert src == "0123456789abcdef" and [r for r in rows if r["layer"].startswith("TOTAL")][0]["fwd_GB"] == "61.5"
+    assert bench.read_committed_counters(str(tmp_path), "l_old.csv")[1] is None
+    assert bench.read_committed_counters(str(tmp_path), "missing.json") == (None, None, None)
+    prof = os.path.join(ROOT, "profiles")
+    for fname in (bench.PMC_FILES["simclr"] % 512, bench.PMC_MFMA_FILES["simclr"] % 512, bench.CONV_LAYER_FILE % 512, bench.PMC_FILES["dino"] % 128, bench.PMC_MFMA_FILES["dino"] % 128):
+        _, src, rel = bench.read_committed_counters(prof, fname)
+        assert rel is not None and src and len(src) == 16, fname
+
+
+def test_committed_counters_were_measured_on_the_current_sources():
+    """The build identity is the sha256 over the kernel sources in link order + the two headers (csrc/Makefile: SRC_SHA).  When the sources have moved on since the
+    counters under profiles/ were measured, bench.py prints `counters_stale: true` - this test then SKIPS with the reason (a reminder to re-run tools/profile_step.sh
+    and tools/bench_conv.py), it does not fail: stale counters are withheld, never wrong."""
+    import hashlib
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    csrc = os.path.join(ROOT, "self-supervised-vision_amd", "csrc")
+    srcs = re.search(r"^SRCS\s*:=\s*(.+)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).split()
+    h = hashlib.sha256()
+    for f in [os.path.join(csrc, s) for s in srcs] + [os.path.join(csrc, "common.h"), os.path.join(ROOT, "include", "ssv_hip.h")]:
+        h.update(open(f, "rb").read())
+    now = h.hexdigest()[:16]
+    from ssv_amd import _lib
+    assert _lib.source_sha16() == now, "libssv_hip.so was not rebuilt after the last source change (run make -C self-supervised-vision_amd/csrc)"
+    stale = [f for f in (bench.PMC_FILES["simclr"] % 512, bench.PMC_MFMA_FILES["simclr"] % 512, bench.CONV_LAYER_FILE % 512)
+             if bench.read_committed_counters(os.path.join(ROOT, "profiles"), f)[1] != now]
+    if stale:
+        pytest.skip(f"counters under profiles/ were measured on another build than the current sources ({now}): {stale} - bench.py will print counters_stale")
