@@ -414,7 +414,14 @@ int ssv_conv2d_dgrad_gelu(const ssv_conv_desc* d, const float* dy, const float* 
  * launched - rows of dy with d->C columns (fc2's outputs, % 32), d->K result columns (fc2's inputs = the width of h, % 4, >= 128) */
 int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, const float* wt, const float* h, const float* addend,
                             float* dh, void* stream);
-/* nn.GELU() (erf form; networks/vit.py:38, models/dino.py:30-33) on n floats, n % 4 == 0 */
+/* The same pair with the derivative taken in the forward: fc1's epilogue writes dact = gelu'(h) in the pre-activation's place (nothing in the backward of
+ * fc1 -> GELU -> fc2 reads h itself) and act = gelu(h); the backward is dh = (dy wt^T) * dact (+ addend) - a plain multiply, no erf / exp in its epilogue.
+ * Bit-identical to ssv_linear_gelu_fwd + ssv_linear_fwd_gelugrad (the same cdf / pdf expressions, evaluated once instead of twice). */
+int ssv_linear_gelu_fwd_dact(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* dact, float* act, void* stream);
+int ssv_linear_fwd_mulgrad(const ssv_conv_desc* d, const float* dy, const float* wt, const float* dact, const float* addend,
+                           float* dh, void* stream);
+/* nn.GELU() (erf form; networks/vit.py:38, models/dino.py:30-33) on n floats, n % 4 == 0.  Every GELU of the library (these two, the epilogues above) evaluates erf
+ * by the same fp32 polynomial pair (csrc/common.h::ssv_erf: 1.3e-7 absolute over all x). */
 int ssv_gelu_fwd(int64_t n, const float* x, float* y, void* stream);
 int ssv_gelu_bwd(int64_t n, const float* x, const float* dy, float* dx, void* stream);
 

@@ -134,6 +134,8 @@ SIGNATURES = {
     "ssv_linear_gelu_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_conv2d_dgrad_gelu": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_linear_fwd_gelugrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_linear_gelu_fwd_dact": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_linear_fwd_mulgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_gelu_fwd": (C.c_int, [_i64, _vp, _vp, _vp]),
     "ssv_gelu_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "ssv_attention_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),

@@ -54,3 +54,47 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- nn.GELU() in its erf form (networks/vit.py:38, models/dino.py:30-33) --------------------------------------------------------
+// erf in ~20 VALU instructions (the libm erff costs ~50 and branches): x * P5(x^2) for |x| < 1 (relative error 2e-7), 1 - u P4(u) exp(-x^2) with
+// u = 1 / (1 + 0.932 |x|) beyond (Abramowitz-Stegun 7.1.26's form, coefficients re-fitted: 5e-10 in exact arithmetic); 1.3e-7 absolute in fp32 over
+// all x (tools/probe/fast_erf_check.py) - the rounding class of 0.5 * v * (1 + erf(.)) whatever erf is used.  Every GELU of the library - the
+// stand-alone kernels of vit.hip and the GEMM epilogues of conv_mfma.hip - goes through these, so fused and unfused forms agree bit for bit.
+// -DSSV_LIBM_ERF=1 (diagnostic builds): the libm erff / expf.
+#ifndef SSV_LIBM_ERF
+#define SSV_LIBM_ERF 0
+#endif
+__device__ __forceinline__ float ssv_erf(float x) {
+#if SSV_LIBM_ERF
+  return erff(x);
+#else
+  const float z = x * x, t = __builtin_fabsf(x);
+  float a = -0.0005631421809084713f;
+  a = __builtin_fmaf(a, z, 0.004917551297694445f);
+  a = __builtin_fmaf(a, z, -0.02671131119132042f);
+  a = __builtin_fmaf(a, z, 0.11280179768800735f);
+  a = __builtin_fmaf(a, z, -0.37612324953079224f);
+  a = __builtin_fmaf(a, z, 1.1283791065216064f);
+  a *= x;
+  const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(0.932012140750885f, t, 1.f));
+  float b = 0.3885830342769623f;
+  b = __builtin_fmaf(b, u, -0.9805029630661011f);
+  b = __builtin_fmaf(b, u, 0.5967519283294678f);
+  b = __builtin_fmaf(b, u, 0.47274520993232727f);
+  b = __builtin_fmaf(b, u, 0.529606282711029f);
+  const float e = __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
+  b = __builtin_fmaf(-(b * u), e, 1.f);
+  return t < 1.f ? a : __builtin_copysignf(b, x);
+#endif
+}
+// standard normal cdf and pdf at v
+__device__ __forceinline__ float ssv_norm_cdf(float v) { return 0.5f * (1.f + ssv_erf(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float ssv_norm_pdf(float v) {
+#if SSV_LIBM_ERF
+  return 0.39894228040143267794f * expf(-0.5f * v * v);
+#else
+  return 0.39894228040143267794f * __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f);
+#endif
+}
+__device__ __forceinline__ float ssv_gelu(float v) { return 0.5f * v * (1.f + ssv_erf(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float ssv_gelu_grad(float v) { return ssv_norm_cdf(v) + v * ssv_norm_pdf(v); }

@@ -122,11 +122,9 @@ __device__ __forceinline__ void group_span(int n0, int n1, int og, int ig, int b
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
 
-// exact (erf) GELU and its derivative, as csrc/vit.hip
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float v) {
-  return 0.5f * (1.f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
-}
+// erf-form GELU and its derivative: the shared definitions of common.h (the stand-alone kernels of vit.hip use the same ones)
+__device__ __forceinline__ float gelu_f(float v) { return ssv_gelu(v); }
+__device__ __forceinline__ float gelu_grad_f(float v) { return ssv_gelu_grad(v); }
 
 // Buffer loads: a 128-bit resource descriptor (base, byte size) in SGPRs + a 32-bit per-lane byte offset + a uniform
 // SGPR byte offset.  Anything out of [0, size) reads as ZERO in hardware, so padding taps, ragged tile edges and rows
@@ -421,7 +419,10 @@ __device__ __forceinline__ void k_loop2(int nkt, const float* As, const float* B
 // the wave leaves, per column, the two sums the BatchNorm backward needs over its rows - sum g and sum g * xhat - as one partial
 // (bn.psum_g / bn.psum_gx row `group`): the backward's reduction pass over (dy, mask, x) disappears, at the price of reading x here.
 // EPI: 1 = also write gelu(v) to out_act (Linear + GELU forward), 2 = multiply by gelu'(gate) before the addend (its backward),
-//      3 = write gelu(v) ONLY (the same forward when no backward will ask for the pre-activation).
+//      3 = write gelu(v) ONLY (the same forward when no backward will ask for the pre-activation),
+//      4 = write gelu'(v) to out and gelu(v) to out_act (the forward when a backward WILL run: nothing in the backward of fc1 -> GELU -> fc2 reads the
+//          pre-activation itself, only gelu' of it - taking it here, where the cdf is at hand for gelu(v), leaves the backward a plain multiply),
+//      5 = multiply by the stored factor `gate` (= gelu'(h) written by 4) before the addend.
 __device__ __forceinline__ void bstore4(rsrc_t rs, int voff_bytes, f32x4 v) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 #if SSV_WHATIF & 2
@@ -478,8 +479,8 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
     const rsrc_t r_gx = make_rsrc(GATE != 0 ? bn->x : out, bytes);
     const rsrc_t r_gm = make_rsrc(GMASK ? reinterpret_cast<const float*>(bn->mask) : out, bytes / 16);
     const rsrc_t r_gx2 = make_rsrc(GX2 ? bn->x2 : out, bytes);
-    const rsrc_t r_gate = make_rsrc(EPI == 2 ? gate : out, bytes);
-    const rsrc_t r_act = make_rsrc(EPI == 1 ? out_act : out, bytes);
+    const rsrc_t r_gate = make_rsrc((EPI == 2 || EPI == 5) ? gate : out, bytes);
+    const rsrc_t r_act = make_rsrc((EPI == 1 || EPI == 4) ? out_act : out, bytes);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -508,7 +509,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
           if constexpr (ADDM == 2) { if (ADD) av[sl][i] = bload4(r_add, aoff, 0); else av[sl][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
           else if constexpr (ADDM == 1) av[sl][i] = bload4(r_add, aoff, 0);
           else av[sl][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (EPI == 2) gv[sl][i] = bload4(r_gate, voff[sl][i], 0);
+          if constexpr (EPI == 2 || EPI == 5) gv[sl][i] = bload4(r_gate, voff[sl][i], 0);
           if constexpr (GATE != 0) xv[sl][i] = bload4(r_gx, voff[sl][i], 0);
           if constexpr (GMASK) mb[sl][i] = __builtin_amdgcn_raw_buffer_load_b8(r_gm, voff[sl][i] == OOB_OFF ? OOB_OFF : voff[sl][i] >> 4, 0, 0);
           if constexpr (GX2) xv2[sl][i] = bload4(r_gx2, voff[sl][i], 0);
@@ -530,6 +531,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(gv[sl][i][e]);
           }
+          if constexpr (EPI == 5) v *= gv[sl][i];
           v += av[sl][i];
           if constexpr (GATE != 0) {
             if constexpr (GATE == 1) {
@@ -551,6 +553,16 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
           }
+          if constexpr (EPI == 4) {          // gelu'(v) in v's place, gelu(v) beside it: one cdf serves both
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float cdf = ssv_norm_cdf(v[e]);
+              a[e] = 0.5f * v[e] * (2.f * cdf);                    // = 0.5 * v * (1 + erf(.)): the bits of gelu_f
+              v[e] = cdf + v[e] * ssv_norm_pdf(v[e]);              // the bits of gelu_grad_f
+            }
+            bstore4(r_act, voff[sl][i], a);
+          }
           bstore4(r_out, voff[sl][i], v);
           if constexpr (EPI == 1) {
             f32x4 a;
@@ -571,7 +583,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
     }
   };
   // (the gated / gelu' epilogues always load: one copy with the uniform test inside - two copies of THAT loop cost 224-300 B / lane of scratch)
-  if constexpr (GATE != 0 || EPI == 2) rows(std::integral_constant<int, 2>{});
+  if constexpr (GATE != 0 || EPI == 2 || EPI == 5) rows(std::integral_constant<int, 2>{});
   else if (ADD) rows(std::integral_constant<int, 1>{});
   else rows(std::integral_constant<int, 0>{});
 
@@ -1018,7 +1030,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       } else {
         epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                   [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
-                                  EPI == 1 ? p.aux_out : nullptr, EPI == 2 ? p.aux_in : nullptr);
+                                  (EPI == 1 || EPI == 4) ? p.aux_out : nullptr, (EPI == 2 || EPI == 5) ? p.aux_in : nullptr);
       }
       return;
     }
@@ -1911,6 +1923,40 @@ extern "C" int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, 
 #endif
   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   SSV_CHECK_LAUNCH("ssv_linear_fwd_gelugrad");
+  return SSV_OK;
+}
+
+// The pair with the derivative taken in the FORWARD (round 4): fc1's epilogue writes dact = gelu'(h) in the pre-activation's place (and act = gelu(h)); the backward of
+// fc2 then multiplies the product by the stored factor - no erf / exp in the backward epilogue, and the forward's cdf serves both tensors.  Same bits as the pair above.
+extern "C" int ssv_linear_gelu_fwd_dact(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, float* dact, float* act, void* stream) {
+  if (int rc = check_desc(d, "ssv_linear_gelu_fwd_dact")) return rc;
+  SSV_REQUIRE(x && w && dact && act, "ssv_linear_gelu_fwd_dact: null pointer");
+  SSV_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)dact | (uintptr_t)act) & 15) == 0, "ssv_linear_gelu_fwd_dact: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K >= 128 && d->K % 4 == 0, "ssv_linear_gelu_fwd_dact: needs C %% 32 == 0, K >= 128, K %% 4 == 0 (got C=%d K=%d)", d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.aux_out = act;
+  const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
+  SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd_dact");
+  return SSV_OK;
+}
+
+extern "C" int ssv_linear_fwd_mulgrad(const ssv_conv_desc* d, const float* dy, const float* wt, const float* dact, const float* addend,
+                                      float* dh, void* stream) {
+  if (int rc = check_desc(d, "ssv_linear_fwd_mulgrad")) return rc;
+  SSV_REQUIRE(dy && wt && dact && dh, "ssv_linear_fwd_mulgrad: null pointer");
+  SSV_REQUIRE((((uintptr_t)dy | (uintptr_t)wt | (uintptr_t)dact | (uintptr_t)dh | (uintptr_t)addend) & 15) == 0, "ssv_linear_fwd_mulgrad: pointers must be 16-byte aligned");
+  SSV_REQUIRE(d->C % 32 == 0 && d->K % 4 == 0 && d->K >= 128 && d->stride == 1 && d->R == 1 && d->S == 1 && d->pad == 0,
+              "ssv_linear_fwd_mulgrad: a Linear layer with C %% 32 == 0, K %% 4 == 0, K >= 128 (got C=%d K=%d)", d->C, d->K);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(d);
+  p.aux_in = dact;
+  const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
+  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  SSV_CHECK_LAUNCH("ssv_linear_fwd_mulgrad");
   return SSV_OK;
 }
 

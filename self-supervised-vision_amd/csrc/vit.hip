@@ -582,7 +582,7 @@ __global__ void gelu_fwd_k(int64_t n4, const f32x4* __restrict__ x, f32x4* __res
   const f32x4 v = x[i];
   f32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+  for (int e = 0; e < 4; ++e) o[e] = ssv_gelu(v[e]);
   y[i] = o;
 }
 __global__ void gelu_bwd_k(int64_t n4, const f32x4* __restrict__ x, const f32x4* __restrict__ dy, f32x4* __restrict__ dx) {
@@ -592,9 +592,7 @@ __global__ void gelu_bwd_k(int64_t n4, const f32x4* __restrict__ x, const f32x4*
   f32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float cdf = 0.5f * (1.f + erff(v[e] * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * v[e] * v[e]);
-    o[e] = g[e] * (cdf + v[e] * pdf);
+    o[e] = g[e] * ssv_gelu_grad(v[e]);
   }
   dx[i] = o;
 }

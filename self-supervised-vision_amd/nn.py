@@ -713,7 +713,13 @@ def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
     inter = w1.shape[0]
     if din % 32 or inter < 128 or inter % 32 or w2.shape[0] % 32 or b1 is None or b2 is None:
         return linear(tape, gelu(tape, linear(tape, x, w1, b1)), w2, b2, addend)
-    h, act = ops.linear_gelu_fwd(x, w1, b1, keep_h=tape is not None)        # the teacher's pass keeps no pre-activation
+    # with a backward to come the epilogue writes gelu'(h) in the pre-activation's place (nothing downstream reads h itself): the backward multiplies by it;
+    # the teacher's pass keeps neither
+    dact_form = tape is not None and ops.can_gelu_dact(w1.shape, w2.shape)
+    if dact_form:
+        h, act = ops.linear_gelu_fwd_dact(x, w1, b1)
+    else:
+        h, act = ops.linear_gelu_fwd(x, w1, b1, keep_h=tape is not None)
     a4 = None if addend is None else addend.view(m, 1, 1, -1)
     y = ops.conv2d_fwd(act.view(m, 1, 1, inter), w2, 1, 0, bias=b2, addend=a4).view(m, w2.shape[0])
     if tape is not None:
@@ -723,7 +729,7 @@ def ffn_gelu(tape, x, w1, b1, w2, b2, addend=None):
         def bwd(dy, existing):
             dy4 = dy.view(m, 1, 1, -1)
             ops.conv2d_wgrad(act.view(m, 1, 1, inter), dy4, w2, grad_of(w2, slot), 1, 0, accumulate=True, dbias=grad_of(b2, slot))
-            dh = ops.linear_dgrad_gelu(dy, w2, h)
+            dh = ops.linear_dgrad_mul(dy, w2, h) if dact_form else ops.linear_dgrad_gelu(dy, w2, h)
             x4, dh4 = x.view(m, 1, 1, din), dh.view(m, 1, 1, inter)
             ops.conv2d_wgrad(x4, dh4, w1, grad_of(w1, slot), 1, 0, accumulate=True, dbias=grad_of(b1, slot))
             dadd = None if addend is None else _accum(existing[1], dy)

@@ -917,6 +917,37 @@ def linear_gelu_fwd(x, w, bias, keep_h=True):
 
 
 LINEAR_GELUGRAD_ON_FWD = os.environ.get("SSV_NO_GELUGRAD_FWD_KERNEL", "0") != "1"     # diagnostic switch: fc2's data gradient on the dgrad kernel
+GELU_DACT_IN_FWD = os.environ.get("SSV_NO_GELU_DACT", "0") != "1"      # diagnostic switch: the forward keeps the pre-activation and the backward epilogue evaluates gelu' (rounds 1-3)
+
+
+def can_gelu_dact(w1_shape, w2_shape):
+    """fc1 [inter, din] / fc2 [dout, inter] shapes for which the forward can write gelu'(h) and the backward multiply by it on the forward kernel."""
+    inter, dout = w1_shape[0], w2_shape[0]
+    return GELU_DACT_IN_FWD and LINEAR_GELUGRAD_ON_FWD and dout % 32 == 0 and inter % 4 == 0 and inter >= 128
+
+
+def linear_gelu_fwd_dact(x, w, bias):
+    """(gelu'(h), gelu(h)) with h = x w^T + bias, both written by one GEMM epilogue: the derivative is taken where the cdf is at hand."""
+    _lib._dev(x, w, bias)
+    m, c = x.shape
+    w, wshape = _ohwi(w)
+    d = conv_desc((m, 1, 1, c), wshape, 1, 0)
+    act = _empty((m, wshape[0]), x)
+    dact = torch.empty_like(act)
+    call("ssv_linear_gelu_fwd_dact", C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(dact), ptr(act), stream())
+    return dact, act
+
+
+def linear_dgrad_mul(dy, w, dact, addend=None, out=None):
+    """dh = (dy w) * dact (+ addend) with dact = gelu'(h) from linear_gelu_fwd_dact: the forward kernel on the transposed weights."""
+    _lib._dev(dy, w, dact, addend)
+    m = dy.shape[0]
+    w, wshape = _ohwi(w)
+    k, c = wshape[0], wshape[1]
+    dh = out if out is not None else torch.empty_like(dact)
+    dt = conv_desc((m, 1, 1, k), (c, k, 1, 1), 1, 0)
+    call("ssv_linear_fwd_mulgrad", C.byref(dt), ptr(dy), ptr(_transposed_filter(w, wshape)), ptr(dact), ptr(addend), ptr(dh), stream())
+    return dh
 
 
 def linear_dgrad_gelu(dy, w, h, addend=None, out=None):

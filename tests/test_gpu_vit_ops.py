@@ -212,3 +212,31 @@ def test_linear_gelu_epilogue_fusions(dev, m, c, k):
     _close(other, got.double().cpu(), 1e-5, 1e-6)
     with pytest.raises(Exception):
         ops.linear_dgrad_gelu(seeded_randn(1, m, 48).to(dev), seeded_randn(2, 48, k).to(dev), h)      # K % 32 != 0 is refused, not silently unfused
+    # the shipped pair (round 4): the derivative is taken in the FORWARD - gelu'(h) written in h's place - and the backward multiplies by it.  The same cdf / pdf
+    # expressions evaluated once instead of twice: every tensor is bit-identical to the pair above and to the stand-alone GELU kernels on the same h
+    assert ops.can_gelu_dact(tuple(w.shape), tuple(w2.shape))
+    dact, act2 = ops.linear_gelu_fwd_dact(x.to(dev), w.to(dev), b.to(dev))
+    assert torch.equal(act2, act) and torch.equal(act2, ops.gelu_fwd(h))
+    assert torch.equal(dact, ops.gelu_bwd(h, torch.ones_like(h)))
+    hd = h.detach().cpu().double().requires_grad_()                 # gelu' of the pre-activation the GPU actually produced (h itself is 1e-5 from href)
+    F.gelu(hd).sum().backward()
+    _close(dact, hd.grad, 1e-5, 1e-6)
+    got2 = ops.linear_dgrad_mul(dy.to(dev), w2.to(dev), dact, addend=add.to(dev))
+    assert torch.equal(got2, got)
+
+
+def test_gelu_on_a_dense_grid_against_fp64(dev):
+    """The library's erf (csrc/common.h::ssv_erf: two fp32 polynomials, ~20 instructions instead of libm's ~50) over a dense grid of arguments, through the GELU
+    kernels: gelu within 1e-6 relative + 5e-7 absolute of torch fp64 everywhere (including the branch point |v| = sqrt 2 and the saturated tails), gelu' within 5e-7."""
+    from ssv_amd import ops
+    x = torch.cat([torch.linspace(-12, 12, 1 << 20), torch.tensor([0.0, -0.0, 2 ** 0.5, -2 ** 0.5, 1e-30, -1e-30, 40.0, -40.0] * 128)]).float()
+    x = x[:x.numel() // 4 * 4]
+    xr = x.double().requires_grad_()
+    ref = F.gelu(xr)
+    ref.sum().backward()
+    got = ops.gelu_fwd(x.to(dev)).cpu().double()
+    err = (got - ref.detach()).abs()
+    assert float((err - 1e-6 * ref.detach().abs()).max()) <= 5e-7, float(err.max())
+    gotd = ops.gelu_bwd(x.to(dev), torch.ones_like(x).to(dev)).cpu().double()
+    assert float((gotd - xr.grad).abs().max()) <= 5e-7, float((gotd - xr.grad).abs().max())
+    assert torch.isfinite(got).all() and torch.isfinite(gotd).all()
