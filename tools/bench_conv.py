@@ -103,6 +103,9 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     stats_ok = Cx % 32 == 0 and K % 4 == 0
     # what the training step hands these layers (nn.py): dY formed on load behind 1x1 / stride-1 convolutions on maps of >= 28x28, and the
     # closing activation of the previous unit formed and written by conv1 on such maps (every conv1 but the first one, whose input is the pool's)
+    # the step hands a k x k convolution with fewer than 128 output channels a MATERIALISED activation (nn.HipConv2d.can_fuse_input: re-transforming each element
+    # k*k times costs more than the apply pass saves there): layer1's 3x3 runs the plain statistics variant, its gate reads the byte mask
+    lazy_in = kind == "lazy" and ops.can_fuse_conv_input(Cx, K) and not (R > 1 and K < 128)
     big = Ho * Ho >= 784
     dyl = ops.LazyGrad(dy, torch.randn_like(y), torch.randn(4, K, device=dev).contiguous()) if (big and C != 3 and ops.can_lazy_dy(w.shape, s, p)) else None
     sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= 784 and ops.can_form_closing_sum(w.shape, s, p)
@@ -118,7 +121,7 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         wv = "plain" + ("+dy_in" if dyl is not None else "")
         t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True))
         del res
-    elif kind == "lazy" and ops.can_fuse_conv_input(Cx, K):
+    elif lazy_in:
         wino = ops.use_winograd(tuple(w.shape), s, p, x.shape, True)        # stride-1 3x3 layers of the deep stages: Winograd F(2x2, 3x3)
         fv = "stats+bn_in" + ("+winograd" if wino else "")
         t_f = timeit(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True, keep_v=True))
@@ -137,12 +140,12 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         # the data gradient feeds a BatchNorm backward: gated epilogue (recomputed gate for the fused chain, byte mask for a unit output)
         gx = torch.randn_like(x)
         mean, invstd = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
-        if kind == "lazy":
+        if lazy_in:
             gate = ops.BnGateCtx(gx, mean, invstd, scale=aff[0], shift=aff[1])
         else:
             gate = ops.BnGateCtx(gx, mean, invstd, mask=torch.randint(0, 16, (x.numel() // 4,), device=dev, dtype=torch.uint8))
         addend = torch.randn_like(x) if kind == "plain" else None
-        dv = ("winograd" if (addend is None and dyl is None and kind == "lazy" and ops.use_winograd((C, K, R, R), s, p, dy.shape, False)) else
+        dv = ("winograd" if (addend is None and dyl is None and lazy_in and ops.use_winograd((C, K, R, R), s, p, dy.shape, False)) else
               ("fwd-kernel" if s == 1 else "dgrad-kernel")) + "+gate" + ("+addend" if addend is not None else "") + ("+dy_in" if dyl is not None else "")
         t_d = timeit(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate))
         if ".1.conv1" in name and kind == "plain" and s == 1:
@@ -163,7 +166,7 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     else:
         by_d = yout + (yout if dyl is not None else 0) + xin                     # dy (+ BatchNorm input), dx written
         by_d += xin if addend is not None else 0                                 # residual gradient read
-        by_d += xin + (n_in * Cx / 4 if kind != "lazy" else 0)                   # gate: the BatchNorm input (+ byte mask)
+        by_d += xin + (n_in * Cx / 4 if not lazy_in else 0)                      # gate: the BatchNorm input (+ byte mask)
     tf = lambda t: flop / (t * 1e-3) / 1e12
     wgs = grid_fwd(m, K)
     row = [name, cnt, f"{H}x{H}", C, K, f"{R}x{R}", s, round(flop / 1e9, 1), fv, round(t_f, 3), round(tf(t_f), 1), wgs, round(wgs / 768, 2),
