@@ -198,7 +198,24 @@ int ssv_wino_input_transform(int32_t N, int32_t H, int32_t W, int32_t C, const f
                              float* V, void* stream);          /* in_scale / in_shift: x is a raw conv output, operand = relu(x*scale+shift); or both NULL */
 int ssv_wino_dy_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, float* dM, void* stream);
 int ssv_wino_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* M, float* y, float* pmean, float* pm2,
-                              const ssv_bn_gate* gate, void* stream);   /* pmean / pm2 [groups][K] or NULL; gate (mask or scale + shift, no x2) or NULL */
+                              const ssv_bn_gate* gate, void* stream);
+
+/* ---- Winograd F(4x4, 3x3) for the forward and the data gradient of the same layers (csrc/winograd44.hip) ------------------------------
+ * 36 multiplies per channel pair and 4x4 output tile instead of 144 (F(2x2): 64), transformed input 2.25x the input instead of 4x; interpolation points
+ * {0, 1, -1, 1/2, -2, inf}.  Its transforms multiply by constants (F(2x2)'s only add and halve): forward / data gradient are 2-3x the direct kernel's error
+ * against fp64 (profiles/r04_probe_winograd44.txt), the weight gradient through it would be 7-8x and therefore stays on F(2x2) - ssv_wino44_input_transform
+ * can leave that operand (V2, ssv_wino_input_transform's output) from the same pass over x.
+ *   T = ssv_wino44_tiles = N * ceil(H/4) * ceil(W/4); V, M: [36][T][channels]; GEMMs: ssv_gemm_batched(36, T, C, K, V, U, M).
+ *   Output-transform partials: one per ROW of tiles (4 x W pixels) - for the statistics only when H % 4 == 0, else one per image (equal groups required):
+ *   ssv_wino44_groups(N, H, W, stats), ssv_wino44_stats_rows_per_group (the rows_per_group for ssv_bn_stats_finalize). */
+int64_t ssv_wino44_tiles(int32_t N, int32_t H, int32_t W);
+int64_t ssv_wino44_groups(int32_t N, int32_t H, int32_t W, int32_t stats);
+int32_t ssv_wino44_stats_rows_per_group(int32_t N, int32_t H, int32_t W);
+int ssv_wino44_filter_transform(int32_t K, int32_t C, const float* w /*[K][3][3][C]*/, float* U /*[36][K][C]*/, void* stream);
+int ssv_wino44_input_transform(int32_t N, int32_t H, int32_t W, int32_t C, const float* x, const float* in_scale, const float* in_shift,
+                               float* V /*[36][T][C]*/, float* V2 /*[16][ssv_wino_tiles][C] or NULL*/, void* stream);
+int ssv_wino44_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* M /*[36][T][K]*/, float* y, float* pmean, float* pm2,
+                                const ssv_bn_gate* gate, void* stream);   /* pmean / pm2 [groups][K] or NULL; gate (mask or scale + shift, no x2) or NULL */
 /* batched GEMMs on the implicit-GEMM kernels, ONE launch: y[b] = a[b] . w[b]^T   /   dw[b] = dy[b]^T . x[b]   (b < batch) */
 int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
                      float* y /*[batch][rows][K]*/, void* stream);

@@ -1041,9 +1041,101 @@ def use_winograd(wshape, stride, pad, x_shape, want_stats):
     return not want_stats or int(_lib.load().ssv_wino_stats_rows_per_group(n, h, w_)) > 0
 
 
+# F(4x4, 3x3) for the forward and the data gradient of the Winograd layers (csrc/winograd44.hip; the weight gradient stays on F(2x2), whose operand the F(4x4) input
+# transform leaves beside its own).  SSV_WINOGRAD44=0|1 overrides the shipped default.
+WINOGRAD44 = os.environ.get("SSV_WINOGRAD44", "1") == "1"
+# Which product takes F(4x4): by the transformed-domain work it leaves, 36 positions x tiles of 4 against 16 x tiles of 2 (0.5625 on maps that tile evenly - 28x28 -
+# and on 7x7, where both tilings cover 8; 0.735 on 14x14, which F(2x2) tiles exactly and F(4x4) covers with 16).  The forward pays for writing both transformed
+# inputs (its own and the weight gradient's), so it switches only when the work halves; the data gradient already wins at 0.735 (tools/probe/wino44_stages.py,
+# profiles/r04_probe_wino44_stages.txt: 14x14 forward 1.07x, data gradient 1.28x; go / no-go bar 1.25x).
+WINOGRAD44_MAX_RATIO_FWD, WINOGRAD44_MAX_RATIO_DGRAD = 0.6, 0.75
+# ... and only up to the contraction length the numerics bar was measured for: the transformed-domain sums run over the channels and F(4x4)'s error grows with
+# their count like any fp32 sum, but from a 3x higher base - 128 / 256 / 512 channels: 2.97x / 2.84x / 2.85x the direct kernel's error against fp64 (bar: 3x),
+# 1024 channels (wide_resnet's layer4): 3.8x.  Wider layers stay on F(2x2).
+WINOGRAD44_MAX_CHANNELS = 512
+# ... and only for launches with enough tiles: 36 small GEMMs of a few row tiles each buy nothing over 16 (B = 64: 7x7 x 512, 256 tiles: 0.109 vs 0.116 ms) while
+# the larger rounding error stays - small batches keep F(2x2)
+WINOGRAD44_MIN_TILES = 1024
+
+
+def _wino44_ratio(h, w_):
+    return (36.0 * ((h + 3) // 4) * ((w_ + 3) // 4)) / (16.0 * ((h + 1) // 2) * ((w_ + 1) // 2))
+
+
+def _use_wino44(n, h, w_, c, k, max_ratio):
+    return (WINOGRAD44 and max(c, k) <= WINOGRAD44_MAX_CHANNELS and _wino44_ratio(h, w_) <= max_ratio
+            and n * ((h + 3) // 4) * ((w_ + 3) // 4) >= WINOGRAD44_MIN_TILES)
+
+
+def _wino44_filter(w, wshape, transposed=False):
+    """U = G g G^T (6x6 positions) of the filter [K][3][3][C] - or, ``transposed``, of the rotated filter with the channel roles swapped (data gradient)."""
+    key = (w.data_ptr(), stream(), wshape, transposed, 44)
+    hit = _WINO_U.get(key)
+    if hit is not None:
+        return hit[1]
+    k, c, _, _ = wshape
+    src, kk, cc = (w, k, c) if not transposed else (_transposed_filter(w, wshape), c, k)
+    u = torch.empty((36, kk, cc), dtype=torch.float32, device=w.device)
+    call("ssv_wino44_filter_transform", kk, cc, ptr(src), ptr(u), stream())
+    _WINO_U[key] = (w.untyped_storage(), u)
+    return u
+
+
+def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
+    """wino_conv2d_fwd through F(4x4, 3x3): 36 transformed-domain GEMMs over a quarter of the tiles.  ``keep_v``: the input transform also leaves the
+    F(2x2) transformed input (the weight gradient's operand - wino_conv2d_wgrad takes it unchanged).  Statistics partials: one per row of tiles
+    (H % 4 == 0) or per image."""
+    _lib._dev(x, w)
+    w, wshape = _ohwi(w)
+    n, h, w_, c = x.shape
+    k = wshape[0]
+    lib = _lib.load()
+    t = int(lib.ssv_wino44_tiles(n, h, w_))
+    u = _wino44_filter(w, wshape)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    v = torch.empty((36, t, c), dtype=torch.float32, device=x.device)
+    v2 = torch.empty((16, int(lib.ssv_wino_tiles(n, h, w_)), c), dtype=torch.float32, device=x.device) if keep_v else None
+    call("ssv_wino44_input_transform", n, h, w_, c, ptr(x), ptr(sc), ptr(sh), ptr(v), ptr(v2), stream())
+    m = torch.empty((36, t, k), dtype=torch.float32, device=x.device)
+    call("ssv_gemm_batched", 36, t, c, k, ptr(v), ptr(u), ptr(m), stream())
+    y = _empty((n, h, w_, k), x)
+    part = None
+    if want_stats:
+        part = _empty((2, int(lib.ssv_wino44_groups(n, h, w_, 1)), k), x)
+    call("ssv_wino44_output_transform", n, h, w_, k, ptr(m), ptr(y), None if part is None else ptr(part[0]), None if part is None else ptr(part[1]), None, stream())
+    rpg = int(lib.ssv_wino44_stats_rows_per_group(n, h, w_)) if want_stats else 0
+    return y, (None if part is None else (part[0], part[1], rpg)), v2
+
+
+def wino44_conv2d_dgrad(dy, w, gate=None):
+    """wino_conv2d_dgrad through F(4x4, 3x3); the gate's partial sums come one per row of tiles."""
+    _lib._dev(dy, w)
+    w, wshape = _ohwi(w)
+    n, h, w_, k = dy.shape
+    c = wshape[1]
+    lib = _lib.load()
+    t = int(lib.ssv_wino44_tiles(n, h, w_))
+    u = _wino44_filter(w, wshape, transposed=True)                # [36][C][K]
+    v = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
+    call("ssv_wino44_input_transform", n, h, w_, k, ptr(dy), None, None, ptr(v), None, stream())
+    m = torch.empty((36, t, c), dtype=torch.float32, device=dy.device)
+    call("ssv_gemm_batched", 36, t, k, c, ptr(v), ptr(u), ptr(m), stream())
+    dx = _empty((n, h, w_, c), dy)
+    if gate is not None:
+        groups = int(lib.ssv_wino44_groups(n, h, w_, 0))
+        st, part = _gate_struct(gate, groups, c, dy)
+        call("ssv_wino44_output_transform", n, h, w_, c, ptr(m), ptr(dx), None, None, C.byref(st), stream())
+        dx._gate_partials = (part[0], part[1], groups)
+    else:
+        call("ssv_wino44_output_transform", n, h, w_, c, ptr(m), ptr(dx), None, None, None, stream())
+    return dx
+
+
 def wino_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     """y = conv3x3(act(x), w) (stride 1, padding 1) through F(2x2, 3x3).  Returns (y, (pmean, pm2) | None, V | None): the statistics
     partials are one per 16 tiles = 64 output rows (needs even H, W); V is the transformed input, kept for the weight gradient."""
+    if _use_wino44(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], WINOGRAD44_MAX_RATIO_FWD):
+        return wino44_conv2d_fwd(x, w, in_affine, want_stats, keep_v)
     _lib._dev(x, w)
     w, wshape = _ohwi(w)
     n, h, w_, c = x.shape
@@ -1069,6 +1161,8 @@ def wino_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
 def wino_conv2d_dgrad(dy, w, gate=None):
     """dx = conv3x3 data gradient (stride 1, padding 1) through F(2x2, 3x3) on the transposed, rotated filter; ``gate`` (BnGateCtx without
     a second target): dx is gated and its partial sums come back as ``dx._gate_partials`` like conv2d_dgrad's."""
+    if _use_wino44(dy.shape[0], dy.shape[1], dy.shape[2], w.shape[1], dy.shape[3], WINOGRAD44_MAX_RATIO_DGRAD):
+        return wino44_conv2d_dgrad(dy, w, gate)
     _lib._dev(dy, w)
     w, wshape = _ohwi(w)
     n, h, w_, k = dy.shape

@@ -17,6 +17,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def f22_only():
+    """This file pins F(2x2, 3x3) itself: ops.wino_conv2d_* must not hand over to F(4x4) (tests/test_gpu_winograd44.py) here."""
+    from ssv_amd import ops
+    prev, ops.WINOGRAD44 = ops.WINOGRAD44, False
+    yield
+    ops.WINOGRAD44 = prev
+
+
 def rel(a, b):
     return float((a.detach().cpu().double() - b).norm() / (b.norm() + 1e-30))
 

@@ -1,0 +1,156 @@
+"""GPU: Winograd F(4x4, 3x3) (csrc/winograd44.hip + 36 batched implicit-GEMM launches) for the forward and the data gradient of the deep stride-1 3x3 layers
+(networks/resnet.py:7-10, 56-58) against torch fp64 convolutions: forward with the fused input BatchNorm and the statistics epilogue (one partial per row of tiles or per
+image), the F(2x2) operand it leaves for the weight gradient (bitwise the one F(2x2)'s own transform writes), data gradient with the ReLU gate (recomputed and byte-mask)
+and its partial sums, ragged maps, and the per-product dispatch rule.  Error bounds: F(4x4)'s transforms multiply by constants up to 8 and 16/15, so it is 2-3x further
+from fp64 than the direct kernels (profiles/r04_probe_winograd44.txt) - the bound here is 4e-6 where F(2x2)'s is 2e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float((a.detach().cpu().double() - b).norm() / (b.norm() + 1e-30))
+
+
+# (n, h, w, c, k): the three ResNet-50 shapes, ragged maps in both directions, one tile, maps smaller than a tile, wide / narrow channel counts
+SHAPES = [(6, 14, 14, 256, 256), (5, 7, 7, 512, 512), (3, 28, 28, 128, 128), (4, 8, 6, 128, 256), (3, 9, 5, 256, 128), (2, 7, 8, 1024, 128), (2, 4, 4, 128, 2048), (3, 3, 2, 128, 128)]
+
+
+def _case(n, h, w_, c, k, seed=0):
+    x = seeded_randn(seed + 1, n, h, w_, c)
+    w = seeded_randn(seed + 2, k, c, 3, 3) * (2.0 / (9 * c)) ** 0.5
+    dy = seeded_randn(seed + 3, n, h, w_, k)
+    aff = (seeded_randn(seed + 4, c) * 0.3 + 1.0, seeded_randn(seed + 5, c) * 0.2)
+    return x, w, dy, aff
+
+
+@pytest.mark.parametrize("n,h,w_,c,k", SHAPES)
+@pytest.mark.parametrize("affine", [False, True])
+def test_forward_statistics_and_the_f22_operand_it_leaves(dev, n, h, w_, c, k, affine):
+    from ssv_amd import _lib, ops
+    lib = _lib.load()
+    x, w, _, aff = _case(n, h, w_, c, k)
+    a = torch.relu(x.double() * aff[0].double() + aff[1].double()) if affine else x.double()
+    ref = F.conv2d(a.permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    xd, wd = x.to(dev), w.contiguous(memory_format=torch.channels_last).to(dev)
+    affd = (aff[0].to(dev), aff[1].to(dev)) if affine else None
+    y, part, v2 = ops.wino44_conv2d_fwd(xd, wd, in_affine=affd, want_stats=True, keep_v=True)
+    assert rel(y, ref) < (4e-6 if max(c, k) <= 512 else 8e-6), rel(y, ref)        # beyond 512 channels (not dispatched: ops.WINOGRAD44_MAX_CHANNELS) the sums are longer
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), rtol=1e-4, atol=4e-5 * float(ref.abs().max()))
+    # statistics partials: one per row of tiles (4 x W pixels) when H % 4 == 0, else one per image - equal groups either way
+    rpg = 4 * w_ if h % 4 == 0 else h * w_
+    assert part[2] == rpg == int(lib.ssv_wino44_stats_rows_per_group(n, h, w_)) and part[0].shape == (n * h * w_ // rpg, k)
+    gamma, beta = torch.ones(k, device=dev), torch.zeros(k, device=dev)
+    rm, rv, nbt = torch.zeros(k, device=dev), torch.ones(k, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    mean, invstd, _, _ = ops.bn_stats_finalize(n * h * w_, k, part, gamma, beta, rm, rv, nbt)
+    r2 = ref.reshape(-1, k)
+    np.testing.assert_allclose(mean.cpu().double().numpy(), r2.mean(0).numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(invstd.cpu().double().numpy(), (1.0 / torch.sqrt(r2.var(0, unbiased=False) + 1e-5)).numpy(), rtol=1e-4)
+    # the F(2x2) transformed input written beside F(4x4)'s own: the bits of F(2x2)'s own input transform
+    prev, ops.WINOGRAD44 = ops.WINOGRAD44, False
+    try:
+        _, _, v2_ref = ops.wino_conv2d_fwd(xd, wd, in_affine=affd, want_stats=False, keep_v=True)
+    finally:
+        ops.WINOGRAD44 = prev
+    assert tuple(v2.shape) == (16, n * ((h + 1) // 2) * ((w_ + 1) // 2), c) and torch.equal(v2, v2_ref)
+    # ... so the weight gradient from it is F(2x2)'s, to its tolerance
+    wr = w.double().clone().requires_grad_()
+    dy = seeded_randn(77, n, h, w_, k)
+    F.conv2d(a.permute(0, 3, 1, 2), wr, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    dw = torch.zeros_like(wd)
+    ops.wino_conv2d_wgrad(v2, dy.to(dev), wd, dw, accumulate=False)
+    assert rel(dw, wr.grad) < 2e-6
+    # without the statistics and without the kept operand: the same y
+    y2, none, nov = ops.wino44_conv2d_fwd(xd, wd, in_affine=affd, want_stats=False, keep_v=False)
+    assert none is None and nov is None and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("n,h,w_,c,k", SHAPES)
+def test_data_gradient_with_the_relu_gate_epilogue(dev, n, h, w_, c, k):
+    from ssv_amd import ops
+    x, w, dy, aff = _case(n, h, w_, c, k, seed=10)
+    refdx = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    wd, dyd = w.contiguous(memory_format=torch.channels_last).to(dev), dy.to(dev)
+    dx = ops.wino44_conv2d_dgrad(dyd, wd)
+    assert rel(dx, refdx) < (4e-6 if max(c, k) <= 512 else 8e-6), rel(dx, refdx)
+    gx = seeded_randn(20, n, h, w_, c)
+    mean, invstd = seeded_randn(21, c) * 0.1, seeded_randn(22, c).abs() + 0.5
+    bit = (gx * aff[0] + aff[1]) > 0
+    gate = ops.BnGateCtx(gx.to(dev), mean.to(dev), invstd.to(dev), scale=aff[0].to(dev), shift=aff[1].to(dev))
+    g = ops.wino44_conv2d_dgrad(dyd, wd, gate=gate)
+    want = torch.where(bit, refdx, torch.zeros_like(refdx))
+    near = ((gx * aff[0] + aff[1]).abs() < 1e-6)
+    assert int(near.sum()) < 4
+    diff = (g.cpu().double() - want).abs()
+    diff[near] = 0
+    assert float(diff.max()) < 8e-5 * float(refdx.abs().max())
+    bits = bit.reshape(-1, 4).to(torch.uint8)
+    mask = (bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)).to(torch.uint8)
+    g2 = ops.wino44_conv2d_dgrad(dyd, wd, gate=ops.BnGateCtx(gx.to(dev), mean.to(dev), invstd.to(dev), mask=mask.to(dev)))
+    if int(near.sum()) == 0:
+        assert torch.equal(g2, g) and torch.equal(g2._gate_partials[0], g._gate_partials[0]) and torch.equal(g2._gate_partials[1], g._gate_partials[1])
+    sg, sgx, groups = g._gate_partials
+    assert groups == sg.shape[0] == n * ((h + 3) // 4)                 # one partial per row of tiles
+    xhat = (gx.double() - mean.double()) * invstd.double()
+    np.testing.assert_allclose(sg.sum(0).cpu().double().numpy(), want.reshape(-1, c).sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(want.abs().sum(dim=(0, 1, 2)).max()))
+    np.testing.assert_allclose(sgx.sum(0).cpu().double().numpy(), (want * xhat).reshape(-1, c).sum(0).numpy(), rtol=1e-4, atol=1e-4 * float((want * xhat).abs().sum(dim=(0, 1, 2)).max()))
+
+
+def test_which_product_takes_f44(dev):
+    """Per product, by the transformed-domain work F(4x4) leaves (36 x tiles of 4 against 16 x tiles of 2): 28x28 and 7x7 (0.5625) switch forward and data gradient,
+    14x14 (0.735: F(2x2) tiles it exactly) only the data gradient; SSV_WINOGRAD44=0 / ops.WINOGRAD44 = False restores F(2x2) everywhere."""
+    from ssv_amd import ops
+    assert ops.WINOGRAD44
+    assert abs(ops._wino44_ratio(28, 28) - 0.5625) < 1e-9 and abs(ops._wino44_ratio(7, 7) - 0.5625) < 1e-9 and abs(ops._wino44_ratio(14, 14) - 36 * 16 / (16 * 49)) < 1e-9
+    calls = {"f": 0, "d": 0}
+    inner_f, inner_d = ops.wino44_conv2d_fwd, ops.wino44_conv2d_dgrad
+
+    def cf(*a, **k):
+        calls["f"] += 1
+        return inner_f(*a, **k)
+
+    def cd(*a, **k):
+        calls["d"] += 1
+        return inner_d(*a, **k)
+    ops.wino44_conv2d_fwd, ops.wino44_conv2d_dgrad = cf, cd
+    try:
+        for hw, ch, f44, d44 in ((28, 128, 1, 1), (14, 256, 0, 1), (7, 512, 1, 1)):
+            x = seeded_randn(5, 1024 // ((hw + 3) // 4) ** 2 + 1, hw, hw, ch).to(dev)         # just past ops.WINOGRAD44_MIN_TILES tiles
+            w = (seeded_randn(6, ch, ch, 3, 3) * 0.02).contiguous(memory_format=torch.channels_last).to(dev)
+            calls.update(f=0, d=0)
+            ops.wino_conv2d_fwd(x, w, keep_v=True)
+            ops.wino_conv2d_dgrad(x, w)
+            assert (calls["f"], calls["d"]) == (f44, d44), (hw, calls)
+        prev, ops.WINOGRAD44 = ops.WINOGRAD44, False
+        try:
+            calls.update(f=0, d=0)
+            ops.wino_conv2d_fwd(x, w)
+            ops.wino_conv2d_dgrad(x, w)
+            assert calls == {"f": 0, "d": 0}
+        finally:
+            ops.WINOGRAD44 = prev
+        # too few tiles (small batches): F(2x2)
+        calls.update(f=0, d=0)
+        ops.wino_conv2d_fwd(x[:8], w)
+        ops.wino_conv2d_dgrad(x[:8], w)
+        assert calls == {"f": 0, "d": 0}
+        # beyond the channel count the numerics bar was measured for: F(2x2)
+        x = seeded_randn(7, 260, 8, 8, 1024).to(dev)
+        w = (seeded_randn(8, 1024, 1024, 3, 3) * 0.01).contiguous(memory_format=torch.channels_last).to(dev)
+        calls.update(f=0, d=0)
+        ops.wino_conv2d_fwd(x, w)
+        ops.wino_conv2d_dgrad(x, w)
+        assert calls == {"f": 0, "d": 0}
+    finally:
+        ops.wino44_conv2d_fwd, ops.wino44_conv2d_dgrad = inner_f, inner_d
