@@ -210,7 +210,7 @@ int ssv_wino_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, const 
  *   ssv_wino44_groups(N, H, W, stats), ssv_wino44_stats_rows_per_group (the rows_per_group for ssv_bn_stats_finalize). */
 int64_t ssv_wino44_tiles(int32_t N, int32_t H, int32_t W);
 int64_t ssv_wino44_groups(int32_t N, int32_t H, int32_t W, int32_t stats);
-int32_t ssv_wino44_stats_rows_per_group(int32_t N, int32_t H, int32_t W);
+int64_t ssv_wino44_stats_rows_per_group(int32_t N, int32_t H, int32_t W);
 int ssv_wino44_filter_transform(int32_t K, int32_t C, const float* w /*[K][3][3][C]*/, float* U /*[36][K][C]*/, void* stream);
 int ssv_wino44_input_transform(int32_t N, int32_t H, int32_t W, int32_t C, const float* x, const float* in_scale, const float* in_shift,
                                float* V /*[36][T][C]*/, float* V2 /*[16][ssv_wino_tiles][C] or NULL*/, void* stream);

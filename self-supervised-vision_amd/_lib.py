@@ -92,7 +92,7 @@ SIGNATURES = {
     "ssv_wino_output_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
     "ssv_wino44_tiles": (_i64, [_i32, _i32, _i32]),
     "ssv_wino44_groups": (_i64, [_i32, _i32, _i32, _i32]),
-    "ssv_wino44_stats_rows_per_group": (_i32, [_i32, _i32, _i32]),
+    "ssv_wino44_stats_rows_per_group": (_i64, [_i32, _i32, _i32]),
     "ssv_wino44_filter_transform": (C.c_int, [_i32, _i32, _vp, _vp, _vp]),
     "ssv_wino44_input_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_wino44_output_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),

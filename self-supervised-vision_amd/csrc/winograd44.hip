@@ -318,9 +318,9 @@ extern "C" int64_t ssv_wino44_groups(int32_t N, int32_t H, int32_t W, int32_t st
   if (N <= 0 || H <= 0 || W <= 0) return 0;
   return (!stats || H % 4 == 0) ? (int64_t)N * ((H + 3) / 4) : (int64_t)N;
 }
-extern "C" int32_t ssv_wino44_stats_rows_per_group(int32_t N, int32_t H, int32_t W) {
+extern "C" int64_t ssv_wino44_stats_rows_per_group(int32_t N, int32_t H, int32_t W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;
-  return H % 4 == 0 ? 4 * W : H * W;
+  return H % 4 == 0 ? (int64_t)4 * W : (int64_t)H * W;
 }
 
 extern "C" int ssv_wino44_filter_transform(int32_t K, int32_t C, const float* w, float* U, void* stream) {
