@@ -8,7 +8,7 @@ touches, one-off initialisation kernels), bench.py's `roofline.kernel_ms_per_ste
 import csv
 import sys
 
-FAMILY = ("conv_fwd_k", "conv_dgrad_k", "conv_wgrad_k", "wgrad_reduce_k", "wino_")
+FAMILY = ("conv_fwd_k", "conv_dgrad_k", "conv_wgrad_k", "wgrad_reduce_k", "wino_", "wino44_")
 
 
 def main():

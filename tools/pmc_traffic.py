@@ -26,7 +26,7 @@ def build_identity():
 # Winograd transforms belong to the convolution they serve: input / plain or statistics output -> forward (the transformed-domain GEMMs ARE conv_fwd_k
 # launches), gated output (<2>, <3>) -> data gradient side of the forward-kernel family, dy / filter-gradient transforms -> weight gradient
 CLASSES = (("conv_fwd", "conv_fwd_k"), ("conv_dgrad", "conv_dgrad_k"), ("conv_wgrad", "conv_wgrad_k"), ("conv_wgrad", "wgrad_reduce_k"),
-           ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_fwd", "wino_"),
+           ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_fwd", "wino_"), ("conv_fwd", "wino44_"),
            ("bn_fwd", "bn_stats"), ("bn_fwd", "bn_apply"), ("bn_bwd", "bn_bwd"), ("attn", "attn_"), ("norm", "ln_"), ("gelu", "gelu_"))
 
 
