@@ -28,7 +28,7 @@ def timeit(fn, rep=10):
     return e0.elapsed_time(e1) / rep
 
 
-for name, H, Cc in (("28x28x128", 28, 128), ("14x14x256", 14, 256), ("7x7x512", 7, 512)):
+for name, H, Cc in (("56x56x64", 56, 64), ("28x28x128", 28, 128), ("14x14x256", 14, 256), ("7x7x512", 7, 512)):
     x = torch.randn(B, H, H, Cc, device=dev)
     w = (torch.randn(Cc, Cc, 3, 3, device=dev) * 0.02).contiguous(memory_format=torch.channels_last)
     sc, sh = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
