@@ -162,6 +162,38 @@ def test_dispatch_predicates_of_the_round3_paths():
     assert not ops.can_form_closing_sum((64, 256, 1, 1), 1, 0, groups=32)
 
 
+def test_dispatch_predicates_of_the_round4_paths():
+    """Host logic, no compute: which product of a Winograd layer takes F(4x4, 3x3) (by the transformed-domain work it leaves, the contraction length its numerics bar
+    was measured for, and the tile count - networks/resnet.py:7-10,56-58: conv2 of the 28x28 / 14x14 / 7x7 ResNet-50 units), and which feed-forward blocks take
+    their GELU derivative in fc1's forward epilogue (networks/vit.py:46-60)."""
+    from ssv_amd import ops
+    fwd, dgr = ops.WINOGRAD44_MAX_RATIO_FWD, ops.WINOGRAD44_MAX_RATIO_DGRAD
+    assert abs(ops._wino44_ratio(28, 28) - 0.5625) < 1e-12 and abs(ops._wino44_ratio(7, 7) - 0.5625) < 1e-12
+    assert abs(ops._wino44_ratio(14, 14) - 36 * 16 / (16 * 49)) < 1e-12 and ops._wino44_ratio(2, 2) > 1
+    prev = ops.WINOGRAD44
+    ops.WINOGRAD44 = True
+    try:
+        assert ops._use_wino44(512, 28, 28, 128, 128, fwd) and ops._use_wino44(512, 28, 28, 128, 128, dgr)
+        assert not ops._use_wino44(512, 14, 14, 256, 256, fwd) and ops._use_wino44(512, 14, 14, 256, 256, dgr)       # F(2x2) tiles 14x14 exactly: only the data gradient switches
+        assert ops._use_wino44(512, 7, 7, 512, 512, fwd) and ops._use_wino44(512, 7, 7, 512, 512, dgr)
+        assert not ops._use_wino44(512, 7, 7, 1024, 1024, dgr) and not ops._use_wino44(512, 7, 7, 512, 1024, fwd)    # wide_resnet's layer4: past the measured numerics bar
+        assert not ops._use_wino44(64, 7, 7, 512, 512, fwd)                                                          # 256 tiles: 36 small GEMMs buy nothing over 16
+        assert ops._use_wino44(256, 7, 7, 512, 512, fwd) and not ops._use_wino44(255, 7, 7, 512, 512, fwd)           # the boundary is ops.WINOGRAD44_MIN_TILES tiles
+        ops.WINOGRAD44 = False
+        assert not ops._use_wino44(512, 28, 28, 128, 128, dgr)
+    finally:
+        ops.WINOGRAD44 = prev
+    pg, pl = ops.GELU_DACT_IN_FWD, ops.LINEAR_GELUGRAD_ON_FWD
+    ops.GELU_DACT_IN_FWD = ops.LINEAR_GELUGRAD_ON_FWD = True
+    try:
+        assert ops.can_gelu_dact((3072, 768), (768, 3072)) and ops.can_gelu_dact((2048, 256), (256, 2048))           # ViT-B blocks, the DINO head's hidden layers
+        assert not ops.can_gelu_dact((64, 768), (768, 64)) and not ops.can_gelu_dact((3072, 768), (10, 3072))        # too narrow / an output width the GEMM tile does not take
+        ops.GELU_DACT_IN_FWD = False
+        assert not ops.can_gelu_dact((3072, 768), (768, 3072))
+    finally:
+        ops.GELU_DACT_IN_FWD, ops.LINEAR_GELUGRAD_ON_FWD = pg, pl
+
+
 def test_host_run_ahead_helpers_are_inert_without_a_gpu():
     """hnn.early_item / hnn.input_stream (the host runs one step ahead of the GPU) fall back to the plain forms on the CPU: .item(), ambient stream."""
     from ssv_amd import nn as hnn
