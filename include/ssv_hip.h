@@ -412,7 +412,8 @@ int ssv_vit_embed_bwd(int32_t B, int32_t T, int32_t P3, int32_t E, const float* 
 
 /* nn.LayerNorm over the last axis of [M][C] (networks/vit.py:19,40; biased variance, eps inside the sqrt) with a fused
  * addend: y = LN(x) * gamma + beta (+ addend) - the reference's "f(x) + LayerNorm(x)" residual form (:22-31, :43-46).
- * bwd: dx = LN'(dy) (+ dx_addend), dgamma/dbeta (+)= column sums (per-block partials in `ws`, fixed-order final reduce). */
+ * bwd: dx = LN'(dy) (+ dx_addend), dgamma/dbeta (+)= column sums (per-block partials in `ws`, fixed-order final reduce).
+ * C % 4 == 0 and C <= 2048 (a row is held in one wavefront's registers), pointers 16-byte aligned. */
 int ssv_layernorm_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta, const float* addend,
                       float eps, float* y, float* mean, float* invstd, void* stream);
 size_t ssv_layernorm_workspace_bytes(int64_t M, int32_t C);

@@ -42,6 +42,12 @@
 #ifndef SSV_WHATIF
 #define SSV_WHATIF 0        // diagnostic builds only (TIMING what-ifs, results are wrong): bit 0 = the forward kernel's main loop issues no MFMAs, bit 1 = its
 #endif                      // epilogue stores nothing, bit 2 = its activation operand is read through an empty descriptor (every load returns zero, no traffic)
+#ifndef SSV_EXP_STAGGER
+#define SSV_EXP_STAGGER 0   // diagnostic builds only: see conv_fwd_k
+#endif
+#ifndef SSV_EXP_STAGGER_N
+#define SSV_EXP_STAGGER_N 3
+#endif
 #ifndef SSV_EXP_WGPRIO
 #define SSV_EXP_WGPRIO 0    // diagnostic builds only: 1 = every workgroup of the forward kernel takes a STATIC issue priority from its arrival order on its CU
 #endif                      // (consecutive arrivals get 0, 1, 2 -> s_setprio 0, 1, 3): does asymmetry between the residents break their lock-step?
@@ -88,7 +94,7 @@ struct ConvKP {
   int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
   int M;              // fwd/wgrad: N*Ho*Wo
   int RSC;            // R*S*C
-  FastDiv dHoWo, dWo, dC, dS;
+  FastDiv dHoWo, dWo, dC, dS, dWp;   // dWp: W + 2 (the halo loader's records per staged row)
   float* aux_out;     // fused-activation variants only: forward also writes gelu(y) here; statistics variant: pmean
   float* aux_out2;    // statistics variant: pm2
   const float* aux_in;  //                                   dgrad multiplies by gelu'(aux_in) before the addend
@@ -119,6 +125,16 @@ __device__ __forceinline__ void group_span(int n0, int n1, int og, int ig, int b
   lo = glo * ig / bk * bk;
   hi = min(ctot, ((ghi + 1) * ig + bk - 1) / bk * bk);
 }
+
+// The halo loader (conv_fwd_k, C4 == 3): staged records (one pixel x 16 channels, 64 bytes at an 80-byte stride: ds_read_b128 of 16 consecutive pixels' fragments
+// then hit 16 distinct bank quads) a workgroup may hold PER STAGE - its 256 output pixels' rows plus one above and below, each with a padding record left and
+// right - and three records of zeros that out-of-image row taps are pointed at (one per column tap).  464 = 8 rows x 58 records (56 x 56 maps).  Two stages.
+constexpr int HALO_REC = 464;
+constexpr int HALO_RS = 20;                                   // record stride in floats
+constexpr int HALO_STAGE = (HALO_REC + 3) * HALO_RS;          // floats per stage
+constexpr int HALO_FLOATS = 2 * HALO_STAGE;
+// most records a 256-pixel tile of a W-wide map can need (the tile may start anywhere in a row)
+static inline int halo_records(int W) { return ((256 + W - 2) / W + 1 + 2) * (W + 2); }
 
 constexpr int XF_MAXC = 1024;   // input channels an XF forward kernel keeps (scale, shift) in LDS for
 
@@ -633,7 +649,7 @@ template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool 
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
 // 28x28 layers); the two-target gate (GATE 3) needs 218.  (kernel_resources.py lists every variant; r03_experiments_step_time.txt the A/Bs.)
-__global__ void __launch_bounds__(256, (OPM == 2 || GATE == 3 || S2) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC)) SSV_CONV_ATTR
+__global__ void __launch_bounds__(256, (OPM == 2 || GATE == 3 || S2 || C4 == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC)) SSV_CONV_ATTR
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -644,7 +660,8 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   static_assert(OPM == 0 || (VEC && C4 == 0 && !XF), "the formed-on-load operands are the float4 path");
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);     // the vectorised epilogue's staging area (one 32-row slab per wave)
   static_assert(!S2 || (VEC && C4 == 0 && !XF && OPM == 0), "the two-stage loop serves the plain float4 path");
-  constexpr int SMEM = S2 ? 2 * STAGE : ((VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE);
+  static_assert(C4 != 3 || (VEC && BM == 256 && BK == 32 && TM == 2 && !XF && OPM == 0 && !S2 && EP_FLOATS <= HALO_FLOATS), "the halo loader serves the 256-row tile of the plain float4 path");
+  constexpr int SMEM = C4 == 3 ? HALO_FLOATS : (S2 ? 2 * STAGE : ((VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE));
   static_assert(!S2 || 2 * STAGE >= EP_FLOATS, "epilogue staging must fit the two stages");
   __shared__ __attribute__((aligned(16))) float smem[SMEM + SSV_EXP_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
@@ -662,6 +679,14 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   zero_acc<TM, TN>(acc);
 #if SSV_EXP_WGPRIO
   wg_static_priority();
+#endif
+#if SSV_EXP_STAGGER
+  // diagnostic builds only: the workgroups of the first resident round start SSV_EXP_STAGGER x 3.4 us apart (by their position in that round), so that the
+  // workgroups sharing a CU are not in the same phase (prologue / main loop / epilogue) for the rest of the launch
+  if (blockIdx.x < 256u * SSV_EXP_STAGGER_N) {
+    const int ph = (int)(blockIdx.x >> 8) % SSV_EXP_STAGGER_N;
+    for (int i = 0; i < ph * SSV_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 #endif
 
   if constexpr (VEC && C4 == 2) {
@@ -787,6 +812,120 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(rsub + RPP * i) * LDT + tl * 4]) = rb[i];
     };
     k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP>((ntap + CH - 1) / CH, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  } else if constexpr (VEC && C4 == 3) {
+    // ---- 3x3 / stride 1 / padding 1 with C % 32 == 0 on the 256 x 64 tile (networks/resnet.py:7-10,56-58: conv2 of the 64-channel units; its data gradient is the
+    //      same product with the rotated filter): HALO staging.  The generic loader below stages every pixel NINE times per channel chunk (once per tap: 18 k-tiles
+    //      of predicated loads, LDS writes and two barriers each for 64 channels); here the pixels the tile's 256 outputs can see - their image rows plus one above
+    //      and below, a zero record left and right of each row - go to LDS ONCE per 16-channel chunk as 64-byte records, and the nine taps are nine record offsets
+    //      of the same staged data.  Two LDS stages: the next chunk's global loads are issued before the current chunk's 288 MFMAs per wave and written to the
+    //      other stage after them - ONE barrier per chunk, none inside it, and the loads of all resident workgroups spread over the matrix phase instead of
+    //      arriving as one burst (one stage of 32 channels, measured: the chip's workgroups run in lockstep, so their staging bursts and their MFMA phases
+    //      alternated instead of overlapping - 107 TFLOP/s, the generic loader's figure).  A lane's A fragment is the 8 consecutive channels 8 * half .. of its
+    //      pixel's record (two ds_read_b128 at immediate offsets of one address register per row tap), its B fragment the same 8 channels of its output column's
+    //      filter tap, read straight from the (L2-resident) filter into registers - the weights never touch LDS; both are fetched one tap (32 MFMAs) ahead,
+    //      one memory instruction per MFMA.  Rows of a neighbouring image that sit above / below an image's first / last row are real data in LDS (their own
+    //      pixels need them): a lane whose pixel's tap row falls outside its image reads the records of zeros instead. ----
+    const int WP = p.W + 2;
+    const rsrc_t rx = make_rsrc(x, (SSV_WHATIF & 4) ? 0u : (unsigned)p.N * p.H * p.W * p.C * 4u);
+    const rsrc_t rw = make_rsrc(w, (unsigned)p.K * p.RSC * 4u);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int g0 = (int)fdiv((uint32_t)m0, p.dWo);                          // running row index n * H + ho of the tile's first pixel (uniform)
+    const int nrec = ((int)fdiv((uint32_t)(min(m0 + BM, p.M) - 1), p.dWo) - g0 + 3) * WP;      // staged records (<= HALO_REC: checked by the launcher)
+    // per lane and row tap dr: LDS float offset (within a stage) of its pixels' fragment in the centre column, or of the middle zero record where the row is
+    // outside the image; the stage, the column tap and the 16-byte piece are immediate offsets of the ds_read
+    int abase[TM][3];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const uint32_t m = (uint32_t)min(m0 + wr0 + tm * 32 + l31, p.M - 1);  // rows past M repeat the last pixel: never stored nor counted
+      const uint32_t g = fdiv(m, p.dWo), n = fdiv(m, p.dHoWo);
+      const int hrow = (int)(g - n * (uint32_t)p.H);
+      const int P0 = ((int)g - g0 + 1) * WP + (int)(m - g * (uint32_t)p.W) + 1;
+#pragma unroll
+      for (int dr = -1; dr <= 1; ++dr)
+        abase[tm][dr + 1] = (((unsigned)(hrow + dr) < (unsigned)p.H) ? P0 + dr * WP : HALO_REC + 1) * HALO_RS + 8 * half;
+    }
+    int wofs[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int ko = n0 + wc0 + tn * 32 + l31;
+      wofs[tn] = ko < p.K ? (ko * p.RSC + 8 * half) * 4 : OOB_OFF;
+    }
+    constexpr int NLD = (HALO_REC * 4 + 255) / 256;
+    int soff[NLD];                                                          // byte offset of this thread's staged float4s in x (channel chunk 0)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i, rec = e >> 2, slot = e & 3;
+      const int j = (int)fdiv((uint32_t)rec, p.dWp), col = rec - j * WP, g = g0 - 1 + j;
+      const bool ok = (rec < nrec) & (col >= 1) & (col <= p.W) & ((unsigned)g < (unsigned)(p.N * p.H));
+      soff[i] = ok ? ((g * p.W + col - 1) * p.C + slot * 4) * 4 : OOB_OFF;
+    }
+    f32x4 st[NLD];
+    auto issue_stage = [&](int c0) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) st[i] = bload4(rx, soff[i], c0 * 4);
+    };
+    auto write_stage = [&](int stage) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i, rec = e >> 2, slot = e & 3;
+        if (rec < nrec) *reinterpret_cast<f32x4*>(&smem[stage * HALO_STAGE + rec * HALO_RS + slot * 4]) = st[i];
+      }
+    };
+    f32x4 bq[2][TN][2], aq[2][TM][2];
+    auto load_b = [&](f32x4 (&b)[TN][2], int tap, int c0) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[tn][q] = bload4(rw, ((SSV_WHATIF & 8) ? 0 : wofs[tn]) + q * 16, (tap * p.C + c0) * 4);      // (OOB_OFF + 16 is still out of range)
+    };
+    auto load_a = [&](f32x4 (&a)[TM][2], int tap, int stage) {
+      const int dr = tap / 3, dc = tap % 3 - 1;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[tm][q] = *reinterpret_cast<const f32x4*>(&smem[abase[tm][dr] + stage * HALO_STAGE + dc * HALO_RS + 4 * q]);
+    };
+    issue_stage(0);
+    load_b(bq[0], 0, 0);
+    for (int i = tid; i < 2 * 3 * HALO_RS; i += 256) smem[(i / (3 * HALO_RS)) * HALO_STAGE + HALO_REC * HALO_RS + i % (3 * HALO_RS)] = 0.f;
+    write_stage(0);
+    __syncthreads();
+    const int nch = p.C / 16;                                               // even: C % 32 == 0
+#pragma unroll 1
+    for (int ch2 = 0; ch2 < nch; ch2 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                                         // chunk ch2 + u lives in stage u
+        const int c0 = (ch2 + u) * 16;
+        const bool more = ch2 + u + 1 < nch;
+        if (more) issue_stage(c0 + 16);
+        load_a(aq[(u * 9) & 1], 0, u);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          constexpr int NMF = 8 * TM * TN;                                  // MFMAs per tap
+          const int cur = (u * 9 + tap) & 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (tap < 8) { load_b(bq[cur ^ 1], tap + 1, c0); load_a(aq[cur ^ 1], tap + 1, u); }
+          else if (more) load_b(bq[cur ^ 1], 0, c0 + 16);                   // the next chunk's first filter tap (its A fragments wait for the stage)
+#pragma unroll
+          for (int ks = 0; ks < ((SSV_WHATIF & 1) ? 2 : 8); ++ks)          // (timing what-if: a quarter of the MFMAs, every fragment load still consumed)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][tm][(SSV_WHATIF & 1) ? ks : (ks >> 2)][ks & 3], bq[cur][tn][(SSV_WHATIF & 1) ? ks : (ks >> 2)][ks & 3], acc[tm][tn], 0, 0, 0);
+          if (tap < 8 && !(SSV_WHATIF & 1)) {
+#pragma unroll
+            for (int i_ = 0; i_ < 2 * TN; ++i_) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+#pragma unroll
+            for (int i_ = 0; i_ < 2 * TM; ++i_) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x8, NMF - 2 * TN - 2 * TM, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) write_stage(u ^ 1);                                       // its last readers passed the previous chunk's barrier
+        __syncthreads();
+      }
+    }
   } else if constexpr (VEC) {
     // ---- C % BK == 0: every k-tile lies inside one filter tap; float4 staging, BK/4 lanes per row ----
     constexpr int CH = BK / 4, RPP = 256 / CH;
@@ -1558,6 +1697,7 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.dWo = make_fastdiv((uint32_t)d->Wo);
   p.dC = make_fastdiv((uint32_t)d->C);
   p.dS = make_fastdiv((uint32_t)d->S);
+  p.dWp = make_fastdiv((uint32_t)d->W + 2u);
   p.aux_out = nullptr; p.aux_out2 = nullptr; p.aux_in = nullptr; p.xf_scale = nullptr; p.xf_shift = nullptr;
   memset(&p.gate, 0, sizeof(p.gate));
   p.dyin_x = nullptr; p.dyin_coef = nullptr;
@@ -1617,8 +1757,24 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   // (1x1 layers with few k-tiles - 64 -> 256 at 56x56 runs at 2.7 TB/s and 69 TFLOP/s, the SUM of its MFMA and HBM times - were tried on a 128 x 64 tile
   //  at 4 / 5 workgroups per CU, on a 64 x 256 tile writing whole 1 KB rows and as a persistent kernel that loads its next tile under the epilogue: no change, r03 x3)
   const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
+  // 3x3 / stride 1 / padding 1 on the 256 x 64 tile: the halo loader (conv_fwd_k, C4 == 3) when the tile's rows fit its LDS records.  DIAGNOSTIC BUILDS ONLY
+  // (-DSSV_EXP_HALO, round 4): three different main loops for this layer - the generic one, one halo stage of 32 channels, two halo stages of 16 - all land on
+  // 104-109 TFLOP/s, because the kernel already keeps the matrix pipe 0.80-0.82 busy and the chip clocks it at 2.0-2.1 GHz under that load
+  // (profiles/r04_probe_halo_loader.txt); the shipped library keeps the one generic loader.
+#ifdef SSV_EXP_HALO
+  const bool halo = !wide && groups <= 1 && !xf && add_H2 == 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->C % 32 == 0 && d->K % 4 == 0 &&
+                    d->Ho == d->H && d->Wo == d->W && halo_records(d->W) <= HALO_REC;
+#endif
   if (gate) {                                                  // C % 32 == 0 checked by the caller
     p.gate = *gate;
+#ifdef SSV_EXP_HALO
+    if (halo) {
+#define FWDGH(G_) hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, 0, false, 3, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+      if (gate->x2) FWDGH(3); else if (gate->mask) FWDGH(2); else FWDGH(1);
+#undef FWDGH
+      return SSV_OK;
+    }
+#endif
 #define FWDG(BM_, BN_, WM_, WN_, G_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
 #define FWDG_TILE(G_) do { if (wide) FWDG(128, 128, 2, 2, G_); else FWDG(256, 64, 4, 1, G_); } while (0)
@@ -1634,6 +1790,11 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
 #define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
 #define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
+#ifdef SSV_EXP_HALO
+  if (halo) {
+    if (stats) FWD(256, 64, 4, 1, 32, true, 3, false); else FWD(256, 64, 4, 1, 32, false, 3, false);
+  } else
+#endif
   if (stats && d->C == 4) {                                    // the padded image stem with the statistics epilogue
     FWD_TILE(32, true, true, false);
   } else if (stats || xf) {                                    // C % 32 == 0 checked by the callers

@@ -448,39 +448,78 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// one wavefront per row; lane owns columns 4*lane + 256*it
+// One wavefront per row, lane owns columns 4*lane + 256*it, the row held in registers: x is read from memory ONCE (rounds 1-3 walked it three times - mean, variance,
+// output - and every walk paid a memory latency with one row per wave in flight: 2.3-2.9 TB/s on ViT-S shapes).  Each wave takes LNF_R rows at a time and issues every
+// load of the group (x and the addend) before the first reduction, so two rows' worth of bytes per wave are in flight.  Arithmetic and summation order are those of the
+// three-pass form (two-pass variance about the mean), so the results are the same bits.
+constexpr int LNF_R = 2;               // rows per wave and trip
+constexpr int LNF_TRIPS = 2;           // trips per wave: 16 rows per workgroup
+
+template <int NIT>
 __global__ void __launch_bounds__(256) ln_fwd_k(int64_t M, int C, const float* __restrict__ x, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const float* __restrict__ addend, float eps,
                                                 float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= M) return;
-  const float* xr = x + r * C;
-  float s = 0.f;
-  for (int i = lane * 4; i < C; i += 256) { const f32x4 v = *(const f32x4*)(xr + i); s += (v[0] + v[1]) + (v[2] + v[3]); }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
-  for (int i = lane * 4; i < C; i += 256) {
-    const f32x4 v = *(const f32x4*)(xr + i);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[NIT], bb[NIT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane * 4 + 256 * it;
+    g[it] = f32x4{0.f, 0.f, 0.f, 0.f}; bb[it] = g[it];
+    if (i < C) { g[it] = *(const f32x4*)(gamma + i); bb[it] = *(const f32x4*)(beta + i); }
   }
-  const float invstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
-  float* yr = y + r * C;
-  const float* ar = addend ? addend + r * C : nullptr;
-  for (int i = lane * 4; i < C; i += 256) {
-    const f32x4 v = *(const f32x4*)(xr + i), g = *(const f32x4*)(gamma + i), bb = *(const f32x4*)(beta + i);
-    f32x4 o;
+#pragma unroll 1
+  for (int trip = 0; trip < LNF_TRIPS; ++trip) {
+    const int64_t r0 = (((int64_t)blockIdx.x * LNF_TRIPS + trip) * 4 + wave) * LNF_R;
+    if (r0 >= M) return;
+    f32x4 v[LNF_R][NIT], a[LNF_R][NIT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * invstd * g[e] + bb[e];
-    if (ar) { const f32x4 a = *(const f32x4*)(ar + i); o += a; }
-    *(f32x4*)(yr + i) = o;
+    for (int k = 0; k < LNF_R; ++k) {
+      const int64_t r = min(r0 + k, M - 1);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = lane * 4 + 256 * it;
+        v[k][it] = f32x4{0.f, 0.f, 0.f, 0.f}; a[k][it] = v[k][it];
+        if (i < C) {
+          v[k][it] = *(const f32x4*)(x + r * C + i);
+          if (addend) a[k][it] = *(const f32x4*)(addend + r * C + i);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LNF_R; ++k) {
+      const int64_t r = r0 + k;
+      if (r >= M) break;
+      float s = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) s += (v[k][it][0] + v[k][it][1]) + (v[k][it][2] + v[k][it][3]);       // columns past C hold zeros
+      const float mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (lane * 4 + 256 * it < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[k][it][e] - mean; q += d * d; }
+        }
+      const float invstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = lane * 4 + 256 * it;
+        if (i < C) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (v[k][it][e] - mean) * invstd * g[it][e] + bb[it][e];
+          if (addend) o += a[k][it];
+          *(f32x4*)(y + r * C + i) = o;
+        }
+      }
+      if (lane == 0) { mean_out[r] = mean; invstd_out[r] = invstd; }
+    }
   }
-  if (lane == 0) { mean_out[r] = mean; invstd_out[r] = invstd; }
 }
 
 constexpr int LN_ROWS = 32;            // rows per block in the backward (4 waves x 8 rows): ~3000 workgroups on ViT-S shapes instead of ~400 (the kernel was latency-bound at 1.5 workgroups per CU)
 
+// The next row's dy / x / statistics / addend are loaded before the current row's two reductions (round 4: one row per wave in flight left the pass at ~2.5 TB/s).
 template <int NIT>
 __global__ void __launch_bounds__(256) ln_bwd_k(int64_t M, int C, const float* __restrict__ dy, const float* __restrict__ x,
                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -497,23 +536,40 @@ __global__ void __launch_bounds__(256) ln_bwd_k(int64_t M, int C, const float* _
     if (i < C) gm[it] = *(const f32x4*)(gamma + i);
   }
   const int64_t r0 = (int64_t)blockIdx.x * LN_ROWS + wave * (LN_ROWS / 4);
+  struct Row { f32x4 d[NIT], v[NIT], a[NIT]; float mu, is; };
+  auto fetch = [&](Row& w, int64_t r) {
+    r = min(r, M - 1);
+    w.mu = mean[r]; w.is = invstd[r];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = lane * 4 + 256 * it;
+      w.d[it] = f32x4{0.f, 0.f, 0.f, 0.f}; w.v[it] = w.d[it]; w.a[it] = w.d[it];
+      if (i < C) {
+        w.d[it] = *(const f32x4*)(dy + r * C + i); w.v[it] = *(const f32x4*)(x + r * C + i);
+        if (dx_addend) w.a[it] = *(const f32x4*)(dx_addend + r * C + i);
+      }
+    }
+  };
+  Row cur, nxt;
+  fetch(cur, r0);
+#pragma unroll 1
   for (int rr = 0; rr < LN_ROWS / 4; ++rr) {
     const int64_t r = r0 + rr;
     if (r >= M) break;
-    const float mu = mean[r], is = invstd[r];
+    if (rr + 1 < LN_ROWS / 4) fetch(nxt, r + 1);
+    const float mu = cur.mu, is = cur.is;
     f32x4 gv[NIT], xh[NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = lane * 4 + 256 * it;
       if (i < C) {
-        const f32x4 d = *(const f32x4*)(dy + r * C + i), v = *(const f32x4*)(x + r * C + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[it][e] = (v[e] - mu) * is;
-          gv[it][e] = d[e] * gm[it][e];
+          xh[it][e] = (cur.v[it][e] - mu) * is;
+          gv[it][e] = cur.d[it][e] * gm[it][e];
           s1 += gv[it][e]; s2 += gv[it][e] * xh[it][e];
-          ag[it][e] += d[e] * xh[it][e]; ab[it][e] += d[e];
+          ag[it][e] += cur.d[it][e] * xh[it][e]; ab[it][e] += cur.d[it][e];
         }
       }
     }
@@ -525,10 +581,11 @@ __global__ void __launch_bounds__(256) ln_bwd_k(int64_t M, int C, const float* _
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = is * (gv[it][e] - s1 - xh[it][e] * s2);
-        if (dx_addend) { const f32x4 a = *(const f32x4*)(dx_addend + r * C + i); o += a; }
+        if (dx_addend) o += cur.a[it];
         *(f32x4*)(dx + r * C + i) = o;
       }
     }
+    cur = nxt;
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
@@ -689,11 +746,14 @@ extern "C" int ssv_attention_bwd(int32_t B, int32_t T, int32_t heads, int32_t dh
 
 extern "C" int ssv_layernorm_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta, const float* addend,
                                  float eps, float* y, float* mean, float* invstd, void* stream) {
-  SSV_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && x && gamma && beta && y && mean && invstd, "ssv_layernorm_fwd: bad arguments (C %% 4 == 0)");
+  SSV_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 2048 && x && gamma && beta && y && mean && invstd, "ssv_layernorm_fwd: bad arguments (C %% 4 == 0, C <= 2048)");
   SSV_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)addend | (uintptr_t)y) & 15) == 0, "ssv_layernorm_fwd: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_NORM, s);
-  hipLaunchKernelGGL(ln_fwd_k, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, s, M, C, x, gamma, beta, addend, eps, y, mean, invstd);
+  const dim3 grid((unsigned)cdiv64(M, 4 * LNF_R * LNF_TRIPS));
+  if (C <= 512) hipLaunchKernelGGL(ln_fwd_k<2>, grid, dim3(256), 0, s, M, C, x, gamma, beta, addend, eps, y, mean, invstd);
+  else if (C <= 1024) hipLaunchKernelGGL(ln_fwd_k<4>, grid, dim3(256), 0, s, M, C, x, gamma, beta, addend, eps, y, mean, invstd);
+  else hipLaunchKernelGGL(ln_fwd_k<8>, grid, dim3(256), 0, s, M, C, x, gamma, beta, addend, eps, y, mean, invstd);
   SSV_CHECK_LAUNCH("ln_fwd_k");
   return SSV_OK;
 }

@@ -21,7 +21,7 @@ def _close(got, want, rtol, atol, msg=""):
     np.testing.assert_allclose(got.detach().cpu().double().numpy(), want.detach().double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
 
 
-@pytest.mark.parametrize("m,c", [(7, 384), (130, 384), (65, 512), (9, 1024), (5, 1536)])
+@pytest.mark.parametrize("m,c", [(7, 384), (130, 384), (1237, 384), (65, 512), (33, 772), (9, 1024), (5, 1536), (3, 2048)])
 def test_layernorm_fwd_bwd(dev, m, c):
     from ssv_amd import ops
     x, g, b, add, dy = (seeded_randn(10 + i, *s) for i, s in enumerate(((m, c), (c,), (c,), (m, c), (m, c))))
@@ -36,6 +36,16 @@ def test_layernorm_fwd_bwd(dev, m, c):
     _close(dx, xr.grad + dxa.double(), 1e-4, 1e-5)
     _close(dg, gr.grad + 1.0, 1e-4, 1e-4)
     _close(db, br.grad - 2.0, 1e-4, 1e-4)
+    # without the addends (the kernels skip those loads), gradients overwritten instead of accumulated
+    y0, mean0, invstd0 = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev))
+    _close(y0, ref - add.double(), 1e-5, 1e-5)
+    assert torch.equal(mean0, mean) and torch.equal(invstd0, invstd)
+    _close(mean, x.double().mean(1), 1e-5, 1e-6)
+    _close(invstd, 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5), 1e-5, 1e-6)
+    dx0 = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, invstd, dg, db, dx_addend=None, accumulate=False)
+    _close(dx0, xr.grad, 1e-4, 1e-5)
+    _close(dg, gr.grad, 1e-4, 1e-4)
+    _close(db, br.grad, 1e-4, 1e-4)
 
 
 def test_gelu_fwd_bwd(dev):
