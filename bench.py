@@ -582,14 +582,17 @@ def main():
                 for k, v in pmc.items():
                     if k in classes:
                         classes[k]["hbm_gb_per_step"] = round(v["fetch"] + v["write"], 1)
-        mfma, executed_gflop = None, None
+        mfma, executed_gflop, family_clock = None, None, None
         if args.algo in PMC_MFMA_FILES:  # matrix-pipe utilisation: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/pmc_mfma.py)
             mfma = committed(PMC_MFMA_FILES[args.algo] % b, "mfma")
             if mfma is not None:
                 for k, v in mfma["per_class"].items():
                     if k in classes and v.get("mfma_busy_frac") is not None:
                         classes[k]["mfma_busy_frac"] = v["mfma_busy_frac"]
+                        if v.get("effective_clock_ghz") is not None:
+                            classes[k]["effective_clock_ghz"] = v["effective_clock_ghz"]
                 executed_gflop = mfma["summary"].get("conv_family_executed_gflop_per_step")
+                family_clock = mfma["summary"].get("conv_family_effective_clock_ghz")
                 mfma = dict(mfma["summary"], source=used["mfma"])
         # operand streams of the conv family in the variants the step launches (the fused BatchNorm operands - shortcut, BatchNorm input, gate
         # operands, the written activation - are streams of these kernels now): per view from tools/bench_conv.py's per-layer model, x 2 views
@@ -608,6 +611,10 @@ def main():
                 "frac_algorithmic": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "executed_frac": None if executed_gflop is None else round(executed_gflop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4),
                 "executed_gflop_per_step": executed_gflop,
+                # the clock the chip held while the family's kernels ran in the counter pass (GRBM_GUI_ACTIVE / 8 XCDs / kernel time: DVFS under the fp32 MFMA
+                # load, MI355X_MICROARCH.md); `peak` above is the guide's figure at 2.4 GHz, so executed_frac ~= matrix-pipe busy fraction x clock / 2.4
+                "effective_clock_ghz": family_clock,
+                "executed_frac_of_peak_at_that_clock": None if (executed_gflop is None or not family_clock) else round(executed_gflop / conv_ms / (FP32_MFMA_PEAK_TFLOPS * family_clock / 2.4), 4),
                 "counters_src_sha16": my_src, "counters_lib_sha16": my_lib, "counters_stale": bool(stale), "counters_rejected": stale or None,
                 "counters_note": "src_sha16 = the sources the LOADED library was compiled from (ssv_source_sha16; hipcc output is not bit-reproducible, so the file hash "
                                  "lib_sha16 only identifies one build artefact); traffic / mfma_counters / executed_frac / algorithmic_gb_per_step are replayed from "

@@ -311,6 +311,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 // ds_read_b128), which afterwards takes the wave's dQ partial (register-major, so that the reduction reads one b128 per wave and group).
 // 5 products instead of 7 per tile pair; delta = rowsum(O * dO) is formed while the query rows are staged (no extra pass, DELTA is still
 // written for callers that want it).  Per query tile: two barriers (all partials written -> reduce + restage -> next tile).
+#ifdef SSV_STAMP_ATTN   // diagnostic build only (tools/stamp_attn.py): cycles of one wave per phase of a query tile.  Never in the shipped library.
+__device__ unsigned long long g_attn_stamps[16];
+#define ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); tph[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define ASTAMP(i) do {} while (0)
+#endif
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 1 : 2, 2))) attn_bwd_fused_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, int ld, float scale,
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
                                                             float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int ldg) {
   __shared__ __attribute__((aligned(16))) float sK[NW * 32 * TS];      // every key row of this (image, head)
   __shared__ __attribute__((aligned(16))) float sq[32 * TS], sd[32 * TS];
-  __shared__ float sstat[2][32];                                        // lse (log2 units) | delta of the staged query rows
+  __shared__ __attribute__((aligned(16))) float sstat[2][32];           // lse (log2 units) | delta of the staged query rows
   __shared__ __attribute__((aligned(16))) float scr[NW][2048];          // per wave: dS^T staging (32 x 36), then its dQ partial (32 registers x 64 lanes)
   constexpr int N4 = 512 / (NW * 64);                                   // float4 per thread per staged 32 x 64 tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
@@ -345,8 +352,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
   load_row32(V + (tok0 + krow) * ld + h * DH + half * 32, vreg, 1.f);
   f32x16 dk_lo = zero16(), dk_hi = zero16(), dv_lo = zero16(), dv_hi = zero16();
   // staging of one query tile: Q and dO rows to registers, delta = sum_d O * dO reduced over the 16 lanes that share a row
-  f32x4 ra[N4], rb[N4];
-  float rdelta[N4], rlse[N4];
+  // load_tile only ISSUES the loads (nothing in it depends on a loaded value, so the wave does not wait for them there - the round-3 form computed delta inside it
+  // and paid the global latency once per query tile: 9 % of the tile's cycles, tools/stamp_attn.py); delta is formed when the rows are written to LDS.
+  // Workgroups of two waves (T <= 64: four float4 per thread and tensor) do not prefetch: the 48 staging registers spilled, and every reload of a spilled
+  // value waits for ALL outstanding loads (s_waitcnt vmcnt(0)) - the prefetch was paid in the middle of the MFMA loops instead of hidden under them.
+  constexpr bool PREFETCH = NW > 2;
+  f32x4 ra[N4], rb[N4], ro[N4];
+  float rlse[N4];
   auto load_tile = [&](int q0) {
 #pragma unroll
     for (int i = 0; i < N4; ++i) {
@@ -354,11 +366,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
       const int64_t row = min(q0 + r, T - 1);
       ra[i] = *(const f32x4*)(qbase + row * ld + c4);
       rb[i] = *(const f32x4*)(dobase + row * ldo + c4);
-      const f32x4 ov = *(const f32x4*)(obase + row * ldo + c4);
-      float d = ov[0] * rb[i][0] + ov[1] * rb[i][1] + ov[2] * rb[i][2] + ov[3] * rb[i][3];
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-      rdelta[i] = d;
-      rlse[i] = LSE[stat + row] * LOG2E;
+      ro[i] = *(const f32x4*)(obase + row * ldo + c4);
+      rlse[i] = LSE[stat + row];
     }
   };
   auto store_tile = [&](int q0) {
@@ -367,9 +376,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
       const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
       *(f32x4*)(sq + r * TS + c4) = ra[i];
       *(f32x4*)(sd + r * TS + c4) = rb[i];
+      float d = ro[i][0] * rb[i][0] + ro[i][1] * rb[i][1] + ro[i][2] * rb[i][2] + ro[i][3] * rb[i][3];
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
       if ((e & 15) == 0) {
-        sstat[0][r] = rlse[i]; sstat[1][r] = rdelta[i];
-        if (q0 + r < T) DELTA[stat + q0 + r] = rdelta[i];
+        sstat[0][r] = rlse[i] * LOG2E; sstat[1][r] = d;
+        if (q0 + r < T) DELTA[stat + q0 + r] = d;
       }
     }
   };
@@ -377,9 +388,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
   store_tile(0);
   __syncthreads();
   float* myscr = scr[wave];
+#ifdef SSV_STAMP_ATTN
+  unsigned long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   for (int q0 = 0; q0 < T; q0 += 32) {
     const bool more = q0 + 32 < T;
-    if (more) load_tile(q0 + 32);                           // next tile's rows fly under this tile's MFMAs
+    if (PREFETCH && more) load_tile(q0 + 32);               // next tile's rows fly under this tile's MFMAs
+    ASTAMP(0);
     if (active) {
       float fr[32];
       f32x16 s = zero16(), dp = zero16();
@@ -393,13 +410,19 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
       lds_row32(sd, c, half, fr);
 #pragma unroll
       for (int i = 0; i < 32; ++i) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[i], vreg[i], dp, 0, 0, 0);
+      ASTAMP(1);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int r = rowof(j, half);
-        const float p = (q0 + r < T && kvalid) ? ex2(s[j] - sstat[0][r]) : 0.f;
-        s[j] = p;                                              // P
-        dp[j] = p * (dp[j] - sstat[1][r]);                     // dS
+      for (int jj = 0; jj < 4; ++jj) {                         // rows 8 jj + 4 half + {0..3}: their statistics are one ds_read_b128 each
+        const f32x4 l4 = *(const f32x4*)&sstat[0][8 * jj + 4 * half], d4 = *(const f32x4*)&sstat[1][8 * jj + 4 * half];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = 4 * jj + e, r = rowof(j, half);
+          const float p = (q0 + r < T && kvalid) ? ex2(s[j] - l4[e]) : 0.f;
+          s[j] = p;                                            // P
+          dp[j] = p * (dp[j] - d4[e]);                         // dS
+        }
       }
+      ASTAMP(2);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (q0 + rowof(j, 0) >= T) continue;                   // padding queries: P and dS are 0
@@ -410,6 +433,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
         dk_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[c], dp[j], dk_lo, 0, 0, 0);
         dk_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 + c], dp[j], dk_hi, 0, 0, 0);
       }
+      ASTAMP(3);
       // dS (query on the register index, key on the lane) -> dS^T (key on the register index, query on the lane) through this wave's scratch
 #pragma unroll
       for (int j = 0; j < 16; ++j) myscr[rowof(j, half) * 36 + c] = dp[j];
@@ -419,6 +443,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
         const f32x4 t = *(const f32x4*)(myscr + c * 36 + 8 * jj + 4 * half);
         st_[4 * jj] = t[0]; st_[4 * jj + 1] = t[1]; st_[4 * jj + 2] = t[2]; st_[4 * jj + 3] = t[3];
       }
+      ASTAMP(4);
       f32x16 g_lo = zero16(), g_hi = zero16();
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -427,6 +452,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
         g_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[c], st_[j], g_lo, 0, 0, 0);
         g_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[32 + c], st_[j], g_hi, 0, 0, 0);
       }
+      ASTAMP(5);
       // this wave's dQ partial, group-major: group G = registers 4 G' .. 4 G' + 3 of lo (G < 4) / hi, one b128 per lane and group
 #pragma unroll
       for (int G = 0; G < 4; ++G) {
@@ -434,15 +460,26 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
         *(f32x4*)(myscr + ((G + 4) * 64 + lane) * 4) = f32x4{g_hi[4 * G], g_hi[4 * G + 1], g_hi[4 * G + 2], g_hi[4 * G + 3]};
       }
     }
+    ASTAMP(6);
     __syncthreads();                                           // every partial is in LDS; nobody reads sq / sd any more
+    ASTAMP(7);
     for (int G = wave; G < 8; G += NW) {                       // dQ of this query tile: sum over the key tiles in wave order, 4 consecutive d per lane
       f32x4 acc = *(const f32x4*)(scr[0] + (G * 64 + lane) * 4);
       for (int w = 1; w < nact; ++w) acc += *(const f32x4*)(scr[w] + (G * 64 + lane) * 4);
       if (q0 + c < T) *(f32x4*)(dQ + (tok0 + q0 + c) * ldg + h * DH + (G < 4 ? 0 : 32) + 8 * (G & 3) + 4 * half) = acc * scale;
     }
+    if (!PREFETCH && more) load_tile(q0 + 32);
     if (more) store_tile(q0 + 32);
+    ASTAMP(8);
     __syncthreads();
+    ASTAMP(9);
   }
+#ifdef SSV_STAMP_ATTN
+  if (lane == 0 && (wave == 0 || wave == 5)) {               // one wave of each SIMD pair's halves; [10] counts the stamped (wave, tile) pairs
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_attn_stamps[i], tph[i]);
+    atomicAdd(&g_attn_stamps[10], (unsigned long long)((T + 31) / 32));
+  }
+#endif
   store_tile_T(dK + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dk_lo, dk_hi, scale);
   store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dv_lo, dv_hi, 1.f);
 }
@@ -674,17 +711,73 @@ __global__ void vit_embed_fwd_k(int64_t total, int T, int F, int P3, int patch, 
   tok[i] = v;
 }
 
-// dcls[f] = sum_b dtok[b][0][f] (f < P3);  dpos[t][e] = sum_b dtok[b][t][P3+e]
-__global__ void vit_embed_bwd_k(int B, int T, int F, int P3, const float* __restrict__ dtok, float* __restrict__ dcls,
-                                float* __restrict__ dpos, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // over T*F
-  if (i >= T * F) return;
-  const int t = i / F, f = i - t * F;
-  if (f < P3 && t != 0) return;
-  double acc = 0.0;
-  for (int b = 0; b < B; ++b) acc += (double)dtok[(int64_t)b * T * F + i];
-  float* out = f < P3 ? dcls + f : dpos + (int64_t)t * (F - P3) + (f - P3);
-  *out = accumulate ? *out + (float)acc : (float)acc;
+// One workgroup per token row, four features per thread (round 4: the per-element form above spent a 64-bit division chain per float and wrote 4-byte stores -
+// 1.1 TB/s on the 387 MB of a 512-image global-crop pass; it stays for patch sizes that are not multiples of 4).
+// (patch % 4 == 0, patch <= 32, E % 4 == 0.)  The patch's pixels are read as whole float4s of the interleaved image rows (coalesced: a patch row is 3 * patch
+// consecutive floats) into LDS and leave it in the (c, kh, kw) feature order; measured forms without the LDS step gather four scalars 12 bytes apart per thread
+// and reach 1.7-2.1 TB/s.
+constexpr int EMB_MAXP = 32;
+__global__ void __launch_bounds__(256) vit_embed_fwd4_k(int T, int F, int P3, int patch, int H, int W, const float* __restrict__ img,
+                                                        const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ tok) {
+  __shared__ __attribute__((aligned(16))) float sp[3 * EMB_MAXP * EMB_MAXP];
+  const int64_t bt = blockIdx.x;
+  const int t = (int)(bt % T);
+  const int64_t b = bt / T;
+  const int pw = W / patch, pidx = t - 1, py = pidx / pw, px = pidx - py * pw, pp = patch * patch, seg = 3 * patch, seg4 = seg >> 2;
+  if (t != 0) {
+    for (int i = threadIdx.x; i < (P3 >> 2); i += 256) {
+      const int kh = i / seg4, j = i - kh * seg4;
+      *(f32x4*)(sp + kh * seg + 4 * j) = *(const f32x4*)(img + ((b * H + (py * patch + kh)) * (int64_t)W + px * patch) * 3 + 4 * j);
+    }
+    __syncthreads();
+  }
+  for (int f = 4 * threadIdx.x; f < F; f += 1024) {
+    f32x4 v;
+    if (f >= P3) v = *(const f32x4*)(pos + (int64_t)t * (F - P3) + (f - P3));
+    else if (t == 0) v = *(const f32x4*)(cls + f);
+    else {
+      const int ch = f / pp, rem = f - ch * pp, kh = rem / patch, kw = rem - kh * patch;      // four consecutive kw of one (c, kh): patch % 4 == 0
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = sp[kh * seg + (kw + e) * 3 + ch];
+    }
+    *(f32x4*)(tok + bt * F + f) = v;
+  }
+}
+
+// dcls[f] = sum_b dtok[b][0][f] (f < P3);  dpos[t][e] = sum_b dtok[b][t][P3+e].  32 columns x 8 batch groups per workgroup, four independent double sums per
+// thread (b = grp, grp + 8, ... in four interleaved chains), combined in fixed order: deterministic.  (Round 3: one thread per column walked the whole batch in
+// one dependent chain - 0.4-0.6 ms per pass for 64-77 MB of reads.)
+__global__ void __launch_bounds__(256) vit_embed_bwd_k(int B, int T, int F, int P3, const float* __restrict__ dtok, float* __restrict__ dcls,
+                                                       float* __restrict__ dpos, int accumulate) {
+  __shared__ double sh[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int E = F - P3;
+  const int a = blockIdx.x * 32 + col;                         // active columns: the P3 class-token features, then T x E positional ones
+  const bool valid = a < P3 + T * E;
+  int t = 0, f = 0;
+  if (valid) {
+    if (a < P3) f = a;
+    else { const int r = a - P3; t = r / E; f = P3 + (r - t * E); }
+  }
+  const float* p = dtok + (int64_t)t * F + f;
+  const int64_t bs = (int64_t)T * F;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (valid) {
+    int bb = grp;
+    for (; bb + 24 < B; bb += 32) {
+      a0 += (double)p[bb * bs]; a1 += (double)p[(bb + 8) * bs]; a2 += (double)p[(bb + 16) * bs]; a3 += (double)p[(bb + 24) * bs];
+    }
+    for (; bb < B; bb += 8) a0 += (double)p[bb * bs];
+  }
+  sh[grp][col] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && valid) {
+    double acc = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc += sh[g][col];
+    float* out = a < P3 ? dcls + f : dpos + (int64_t)t * E + (f - P3);
+    *out = accumulate ? *out + (float)acc : (float)acc;
+  }
 }
 
 }  // namespace
@@ -809,7 +902,10 @@ extern "C" int ssv_vit_embed_fwd(int32_t B, int32_t H, int32_t W, int32_t patch,
   const int64_t total = (int64_t)B * T * F;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_MISC, s);
-  hipLaunchKernelGGL(vit_embed_fwd_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, total, T, F, P3, patch, H, W, img_nhwc, cls, pos, tokens);
+  if (patch % 4 == 0 && patch <= EMB_MAXP && E % 4 == 0 && (((uintptr_t)img_nhwc | (uintptr_t)cls | (uintptr_t)pos | (uintptr_t)tokens) & 15) == 0 && (int64_t)B * T < (1ll << 31))
+    hipLaunchKernelGGL(vit_embed_fwd4_k, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, s, T, F, P3, patch, H, W, img_nhwc, cls, pos, tokens);
+  else
+    hipLaunchKernelGGL(vit_embed_fwd_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, total, T, F, P3, patch, H, W, img_nhwc, cls, pos, tokens);
   SSV_CHECK_LAUNCH("vit_embed_fwd_k");
   return SSV_OK;
 }
@@ -819,7 +915,15 @@ extern "C" int ssv_vit_embed_bwd(int32_t B, int32_t T, int32_t P3, int32_t E, co
   SSV_REQUIRE(B > 0 && T > 0 && P3 > 0 && E >= 0 && dtokens && dcls && dpos, "ssv_vit_embed_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_MISC, s);
-  hipLaunchKernelGGL(vit_embed_bwd_k, dim3(cdiv(T * (P3 + E), 256)), dim3(256), 0, s, B, T, P3 + E, P3, dtokens, dcls, dpos, accumulate);
+  hipLaunchKernelGGL(vit_embed_bwd_k, dim3(cdiv(P3 + T * E, 32)), dim3(256), 0, s, B, T, P3 + E, P3, dtokens, dcls, dpos, accumulate);
   SSV_CHECK_LAUNCH("vit_embed_bwd_k");
   return SSV_OK;
 }
+
+#ifdef SSV_STAMP_ATTN
+extern "C" int ssv_debug_attn_stamps(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_attn_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif

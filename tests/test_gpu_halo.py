@@ -1,8 +1,9 @@
-"""GPU: the halo loader of the forward kernel (csrc/conv_mfma.hip, conv_fwd_k with C4 == 3) - 3x3 / stride 1 / padding 1 layers with fewer than 128 output channels
-(networks/resnet.py:7-10,56-58: conv2 of the 64-channel units, and its data gradient, which is the same product with the rotated filter) stage every pixel once per
-32-channel chunk instead of once per tap.  Against torch fp64 convolutions: plain forward, the statistics epilogue, the data gradient with addend and with the
-BatchNorm + ReLU gate (recomputed and byte-mask) and its partial sums; tiles that start mid-row, span two images, end past M; maps too wide / too narrow for the
-staged records (generic loader).  Tolerances are those of tests/test_gpu_ops.py."""
+"""GPU: 3x3 / stride 1 / padding 1 layers with fewer than 128 output channels (networks/resnet.py:7-10,56-58: conv2 of the 64-channel units, and its data gradient,
+which is the same product with the rotated filter) on the 256 x 64 tile of the forward kernel (csrc/conv_mfma.hip): the shipped generic loader and, with SSV_HIP_LIB
+pointing at a -DSSV_EXP_HALO diagnostic build (tools/exp/r04_halo.sh), the halo loader (conv_fwd_k with C4 == 3), which stages every pixel once per 16-channel chunk
+instead of once per tap.  Against torch fp64 convolutions: plain forward, the statistics epilogue, the data gradient with addend and with the BatchNorm + ReLU gate
+(recomputed and byte-mask) and its partial sums; tiles that start mid-row, span two images, end past M; maps too wide / too narrow for the halo loader's staged
+records.  Tolerances are those of tests/test_gpu_ops.py."""
 import numpy as np
 import pytest
 import torch

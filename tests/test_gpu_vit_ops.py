@@ -81,7 +81,7 @@ def test_attention_fwd_bwd(dev, b, t, heads):
     assert torch.equal(o, o2)
 
 
-@pytest.mark.parametrize("b,size,patch,e", [(3, 32, 4, 192), (2, 8, 4, 192), (2, 48, 16, 64)])
+@pytest.mark.parametrize("b,size,patch,e", [(3, 32, 4, 192), (2, 8, 4, 192), (2, 48, 16, 64), (41, 16, 4, 192), (37, 8, 4, 20), (2, 9, 3, 8), (5, 8, 2, 6), (70, 96, 16, 192)])
 def test_vit_embed_fwd_bwd(dev, b, size, patch, e):
     from ssv_amd import ops
     img = seeded_randn(40, b, 3, size, size)
@@ -98,8 +98,12 @@ def test_vit_embed_fwd_bwd(dev, b, size, patch, e):
     assert torch.equal(tok.cpu().view(b, n + 1, -1), ref.detach())
     dcls, dpos = torch.zeros(1, p3, device=dev), torch.zeros(n + 3, e, device=dev)
     ops.vit_embed_bwd(dtok.to(dev), b, t, p3, e, dcls, dpos, accumulate=True)
-    _close(dcls, clsr.grad, 1e-5, 1e-6)
-    _close(dpos, posr.grad, 1e-5, 1e-6)
+    # against fp64 sums over the batch (torch's fp32 autograd sums are themselves ~1e-6 off at 70 terms)
+    _close(dcls, dtok[:, 0, :p3].double().sum(0, keepdim=True), 1e-5, 1e-6)
+    want_pos = torch.zeros(n + 3, e, dtype=torch.float64)
+    want_pos[:n + 1] = dtok[:, :, p3:].double().sum(0)
+    _close(dpos, want_pos, 1e-5, 1e-6)
+    assert torch.allclose(clsr.grad.double(), dtok[:, 0, :p3].double().sum(0, keepdim=True), rtol=1e-4, atol=1e-5)
 
 
 def test_weightnorm_fwd_bwd(dev):

@@ -2,7 +2,7 @@
 # Evidence for one kernel state of the training step, written under gpurun_out/<tag>_*: run on the GPU box as
 #   bash tools/profile_step.sh <tag> [bench.py arguments, e.g. --algo dino]
 # 1. rocprofv3 --kernel-trace --stats of a single-stream run and of the two-stream run (per-kernel durations),
-# 2. three separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES+GRBM_GUI_ACTIVE), each with
+# 2. three separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES+GRBM_GUI_ACTIVE+wave stall buckets), each with
 #    --kernel-trace only (counters never share a run with the other trace domains),
 # 3. tools/pmc_traffic.py and tools/pmc_mfma.py aggregate them per kernel class and training step.
 # The program after `--` is python3 itself (no wrapper that re-execs).
@@ -31,9 +31,10 @@ pmc() {     # $1 = name, rest = counters
 }
 F=$(pmc fetch FETCH_SIZE)
 W=$(pmc write WRITE_SIZE)
-M=$(pmc mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE)
+M=$(pmc mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY)
+MT=$(find $OUT/_pmc_mfma -name '*kernel_trace.csv' | head -1)
 # 2 steps in each PMC run (1 warm-up + 1 timed)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic.py "$F" "$W" 2 $OUT/${TAG}_pmc_hbm_traffic.json > /dev/null
-[ -n "$M" ] && (cd tools && python3 pmc_mfma.py "../$M" 2 ../$OUT/${TAG}_pmc_mfma.json ${ALGO_GFLOP:-} > /dev/null)
+[ -n "$M" ] && (cd tools && python3 pmc_mfma.py "../$M" 2 ../$OUT/${TAG}_pmc_mfma.json "${ALGO_GFLOP:--}" "../$MT" > /dev/null)
 ls -la $OUT/${TAG}_* 2>/dev/null
 tail -2 $OUT/_pmc_mfma.log
