@@ -52,6 +52,30 @@ __device__ __forceinline__ void store_tile_T(float* __restrict__ base, int64_t r
   }
 }
 
+// The same tile through a wave-private 32 x 64 float LDS scratch, so that the global stores are whole 256-byte rows (16 lanes x 16 bytes, four rows per
+// instruction) instead of 64 scattered 16-byte pieces: the scattered form is store-ISSUE bound (~7 B / cycle / CU: tools/stamp_attn.py found the 37-token
+// backward spending a quarter of its time issuing dQ stores).  Row c keeps its sixteen 16-byte slots XOR-swizzled with c & 15: the transposing writes and the
+// row-major reads are both free of bank conflicts without padding (the scratch is exactly one tile).  Rows [0, nrows) of the tile are stored.
+__device__ __forceinline__ void store_tile_T_rows(float* __restrict__ scratch, float* __restrict__ base, int64_t row_stride, int row0, int nrows, int lane,
+                                                  const f32x16& lo, const f32x16& hi, float mul) {
+  const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = lo[4 * jj + e] * mul; b[e] = hi[4 * jj + e] * mul; }
+    *(f32x4*)(scratch + c * 64 + (((2 * jj + half) ^ (c & 15)) << 2)) = a;
+    *(f32x4*)(scratch + c * 64 + (((8 + 2 * jj + half) ^ (c & 15)) << 2)) = b;
+  }
+  const int s = lane & 15;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = 4 * k + (lane >> 4);
+    const f32x4 v = *(const f32x4*)(scratch + r * 64 + ((s ^ (r & 15)) << 2));
+    if (r < nrows) *(f32x4*)(base + (int64_t)(row0 + r) * row_stride + 4 * s) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ attention, shared pieces
 // A workgroup = NW wavefronts = NW consecutive 32-row tiles of ONE (image, head).  The tiles it streams over (keys/values in the
 // forward and dQ passes, queries/dO in the dK/dV pass) are staged once per workgroup into LDS with coalesced 16-byte loads
@@ -102,7 +126,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 1)      // 4-wave block
 attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K,
                                                       const float* __restrict__ V, int ld, float scale,
                                                       float* __restrict__ O, int ldo, float* __restrict__ LSE) {
-  __shared__ float sk[2][32 * TS], sv[2][32 * TS];
+  __shared__ __attribute__((aligned(16))) float skv[4][32 * TS];           // K stages 0, 1 | V stages 0, 1; at the end: one output tile per wave
+  float (*sk)[32 * TS] = skv, (*sv)[32 * TS] = skv + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
   const int q0 = (blockIdx.x * NW + wave) * 32, h = blockIdx.y, b = blockIdx.z;
   const bool active = q0 < T;                                 // a trailing wave only helps staging
@@ -157,7 +182,9 @@ attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restric
     __syncthreads();
   }
   const bool valid = q0 + c < T;
-  store_tile_T(O + tok0 * ldo + h * DH, ldo, q0 + c, valid, half, o_lo, o_hi, 1.f / l);
+  // (the loop's last barrier has passed: the four staging buffers are free - 2 x 2 x 32 x 68 floats, of which each wave takes a private 32 x 64 tile)
+  static_assert(NW * 2048 <= 4 * 32 * TS, "one output tile per wave in the staging buffers");
+  if (active) store_tile_T_rows(&skv[0][0] + wave * 2048, O + tok0 * ldo + h * DH, ldo, q0, min(32, T - q0), lane, o_lo, o_hi, 1.f / l);
   if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = (m + log2f(l)) * LN2;
 }
 
@@ -359,9 +386,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
   constexpr bool PREFETCH = NW > 2;
   f32x4 ra[N4], rb[N4], ro[N4];
   float rlse[N4];
-  auto load_tile = [&](int q0) {
+  // (two-wave workgroups whose second - last - tile has at most 8 query rows, the 37-token local crops: those rows are one float4 per thread and tensor; they are
+  //  fetched with the first tile, so the workgroup pays ONE global round trip instead of two - with 1.5 waves per SIMD resident nothing else hides the second)
+  const bool small_next = NW == 2 && T > 32 && T <= 40;       // uniform
+  auto load_tile = [&](int q0, int ni = 512 / (NW * 64)) {    // ni: staged float4s per thread and tensor (rows 8 ni.. keep what the previous tile left: finite)
 #pragma unroll
     for (int i = 0; i < N4; ++i) {
+      if (i >= ni) break;
       const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
       const int64_t row = min(q0 + r, T - 1);
       ra[i] = *(const f32x4*)(qbase + row * ld + c4);
@@ -370,9 +401,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
       rlse[i] = LSE[stat + row];
     }
   };
-  auto store_tile = [&](int q0) {
+  auto store_tile = [&](int q0, int ni = 512 / (NW * 64)) {
 #pragma unroll
     for (int i = 0; i < N4; ++i) {
+      if (i >= ni) break;
       const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
       *(f32x4*)(sq + r * TS + c4) = ra[i];
       *(f32x4*)(sd + r * TS + c4) = rb[i];
@@ -386,10 +418,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
   };
   load_tile(0);
   store_tile(0);
+  if (small_next) load_tile(32, 1);
   __syncthreads();
   float* myscr = scr[wave];
 #ifdef SSV_STAMP_ATTN
-  unsigned long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -455,33 +488,45 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW
       ASTAMP(5);
       // this wave's dQ partial, group-major: group G = registers 4 G' .. 4 G' + 3 of lo (G < 4) / hi, one b128 per lane and group
 #pragma unroll
-      for (int G = 0; G < 4; ++G) {
-        *(f32x4*)(myscr + (G * 64 + lane) * 4) = f32x4{g_lo[4 * G], g_lo[4 * G + 1], g_lo[4 * G + 2], g_lo[4 * G + 3]};
-        *(f32x4*)(myscr + ((G + 4) * 64 + lane) * 4) = f32x4{g_hi[4 * G], g_hi[4 * G + 1], g_hi[4 * G + 2], g_hi[4 * G + 3]};
+      for (int G = 0; G < 4; ++G) {                            // slot of (G, lane): G * 64 + (lane ^ d4), d4 = 2 G + half = the 16-byte piece of the query's row
+        *(f32x4*)(myscr + (G * 64 + (lane ^ (2 * G + half))) * 4) = f32x4{g_lo[4 * G], g_lo[4 * G + 1], g_lo[4 * G + 2], g_lo[4 * G + 3]};
+        *(f32x4*)(myscr + ((G + 4) * 64 + (lane ^ (2 * (G + 4) + half))) * 4) = f32x4{g_hi[4 * G], g_hi[4 * G + 1], g_hi[4 * G + 2], g_hi[4 * G + 3]};
       }
     }
     ASTAMP(6);
     __syncthreads();                                           // every partial is in LDS; nobody reads sq / sd any more
     ASTAMP(7);
-    for (int G = wave; G < 8; G += NW) {                       // dQ of this query tile: sum over the key tiles in wave order, 4 consecutive d per lane
-      f32x4 acc = *(const f32x4*)(scr[0] + (G * 64 + lane) * 4);
-      for (int w = 1; w < nact; ++w) acc += *(const f32x4*)(scr[w] + (G * 64 + lane) * 4);
-      if (q0 + c < T) *(f32x4*)(dQ + (tok0 + q0 + c) * ldg + h * DH + (G < 4 ? 0 : 32) + 8 * (G & 3) + 4 * half) = acc * scale;
+    // the next tile's rows go to LDS BEFORE this tile's dQ stores are issued: waiting for the (older) prefetched loads must not also wait for younger stores
+    // (vmcnt retires in order; the scattered 16-byte stores take far longer than anything else between the two barriers - tools/stamp_attn.py)
+    if (!PREFETCH && more) {
+      if (small_next) store_tile(q0 + 32, 1);
+      else { load_tile(q0 + 32); store_tile(q0 + 32); }
+    } else if (more) store_tile(q0 + 32);
+    ASTAMP(11);
+    // dQ of this query tile: sum over the key tiles in wave order; thread (query q, piece d4) - sixteen lanes store one whole 256-byte row.  The partials'
+    // slots are XOR-swizzled (above) so that these row-major reads hit sixteen distinct bank quads.
+    for (int i = threadIdx.x; i < 512; i += NW * 64) {
+      const int q = i >> 4, d4 = i & 15;
+      const int slot = ((d4 >> 1) * 64 + ((q + 32 * (d4 & 1)) ^ d4)) * 4;
+      f32x4 acc = *(const f32x4*)(scr[0] + slot);
+      for (int w = 1; w < nact; ++w) acc += *(const f32x4*)(scr[w] + slot);
+      if (q0 + q < T) *(f32x4*)(dQ + (tok0 + q0 + q) * ldg + h * DH + 4 * d4) = acc * scale;
     }
-    if (!PREFETCH && more) load_tile(q0 + 32);
-    if (more) store_tile(q0 + 32);
     ASTAMP(8);
     __syncthreads();
     ASTAMP(9);
   }
 #ifdef SSV_STAMP_ATTN
   if (lane == 0 && (wave == 0 || wave == 5)) {               // one wave of each SIMD pair's halves; [10] counts the stamped (wave, tile) pairs
-    for (int i = 0; i < 10; ++i) atomicAdd(&g_attn_stamps[i], tph[i]);
+    for (int i = 0; i < 12; ++i) if (i != 10) atomicAdd(&g_attn_stamps[i], tph[i]);
     atomicAdd(&g_attn_stamps[10], (unsigned long long)((T + 31) / 32));
   }
 #endif
-  store_tile_T(dK + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dk_lo, dk_hi, scale);
-  store_tile_T(dV + tok0 * ldg + h * DH, ldg, k0 + c, kvalid && active, half, dv_lo, dv_hi, 1.f);
+  // (past the loop's last barrier every dQ partial has been read: the wave's scratch takes its dK, then its dV tile - whole rows to global memory)
+  if (active) {
+    store_tile_T_rows(myscr, dK + tok0 * ldg + h * DH, ldg, k0, min(32, T - k0), lane, dk_lo, dk_hi, scale);
+    store_tile_T_rows(myscr, dV + tok0 * ldg + h * DH, ldg, k0, min(32, T - k0), lane, dv_lo, dv_hi, 1.f);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm

@@ -58,7 +58,7 @@ def test_gelu_fwd_bwd(dev):
     _close(ops.gelu_bwd(x.to(dev), dy.to(dev)), xr.grad, 1e-5, 1e-6)
 
 
-@pytest.mark.parametrize("b,t,heads", [(2, 65, 6), (3, 5, 6), (2, 197, 6), (1, 37, 2), (1, 32, 1), (2, 33, 3), (2, 128, 2), (1, 256, 1), (1, 129, 3), (1, 300, 2)])
+@pytest.mark.parametrize("b,t,heads", [(2, 65, 6), (3, 5, 6), (2, 197, 6), (1, 37, 2), (5, 37, 6), (3, 40, 2), (3, 41, 2), (2, 48, 3), (2, 64, 2), (1, 32, 1), (2, 33, 3), (2, 128, 2), (1, 256, 1), (1, 129, 3), (1, 300, 2)])
 def test_attention_fwd_bwd(dev, b, t, heads):
     from ssv_amd import ops
     hid = heads * 64

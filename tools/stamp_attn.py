@@ -29,9 +29,11 @@ torch.cuda.synchronize()
 lib.ssv_debug_attn_stamps(buf, 1)
 n = buf[10]
 names = ["issue next tile's loads", "fragment reads + S, dP (64 MFMAs)", "P, dS (16 exp2)", "dV, dK (64 MFMAs, 64 LDS operand reads)", "dS -> dS^T through LDS",
-         "dQ partial (32 MFMAs)", "write the partial", "barrier 1", "reduce dQ + restage", "barrier 2"]
-tot = sum(buf[i] for i in range(10))
+         "dQ partial (32 MFMAs)", "write the partial", "barrier 1", "reduce dQ: LDS reads, global stores", "barrier 2", None, "restage the next tile's rows"]
+tot = sum(buf[i] for i in range(12) if i != 10)
 print(f"T {T} B {B}: {n} stamped (wave, query tile) pairs (waves 0 and 5 of every workgroup)")
 for i, name in enumerate(names):
+    if name is None:
+        continue
     print(f"   {name:42s} {buf[i] / n:9.0f} cycles / tile  {100.0 * buf[i] / tot:5.1f} %")
 print(f"   total {tot / n:9.0f} cycles / tile; the wave's 160 MFMAs alone: 10240, its SIMD's two waves: 20480")
