@@ -27,6 +27,8 @@ from ._lib import SsvError
 _SLOT = 0
 _STREAMS = {}
 _VIEW_STREAMS = os.environ.get("SSV_SINGLE_STREAM", "0") != "1"
+_VIEW_SKEW_CYCLES = int(float(os.environ.get("SSV_VIEW_SKEW_US", "0")) * 2400)     # diagnostic switch (do the two views' same-kind kernels collide?)
+_VIEW_SKEW_BWD_CYCLES = int(float(os.environ.get("SSV_VIEW_SKEW_BWD_US", "0")) * 2400)
 
 
 def view_streams():
@@ -103,6 +105,8 @@ class _ViewCtx:
             st.wait_event(self.pv.start)
             self.ctx = torch.cuda.stream(st)
             self.ctx.__enter__()
+            if _VIEW_SKEW_CYCLES and self.slot == 1:
+                torch.cuda._sleep(_VIEW_SKEW_CYCLES)          # diagnostic: view 1 starts this many cycles behind view 0
             self.pv.used.add(self.slot)
             _SLOT = self.slot
         return self
@@ -898,6 +902,8 @@ class _Bridge(torch.autograd.Function):
         ctx.tape = None
         if _STREAMS:
             dy.record_stream(torch.cuda.current_stream(dy.device))
+        if _VIEW_SKEW_BWD_CYCLES and tape.slot == 1 and len(tape.ops) > 64:
+            torch.cuda._sleep(_VIEW_SKEW_BWD_CYCLES)          # diagnostic: view 1's encoder backward starts this many cycles behind view 0's
         dx = tape.backward(ctx.y, dy.contiguous())
         if dx is not None:
             dx = ctx.module._finish_input_grad(dx)
