@@ -29,6 +29,8 @@ _STREAMS = {}
 _VIEW_STREAMS = os.environ.get("SSV_SINGLE_STREAM", "0") != "1"
 _VIEW_SKEW_CYCLES = int(float(os.environ.get("SSV_VIEW_SKEW_US", "0")) * 2400)     # diagnostic switch (do the two views' same-kind kernels collide?)
 _VIEW_SKEW_BWD_CYCLES = int(float(os.environ.get("SSV_VIEW_SKEW_BWD_US", "0")) * 2400)
+_VIEW_STREAM_PRIO = int(os.environ.get("SSV_VIEW_STREAM_PRIO", "0"))       # diagnostic switches: HIP stream priorities (-1 = high, 0 = default) of the view streams
+_INPUT_STREAM_PRIO = int(os.environ.get("SSV_INPUT_STREAM_PRIO", "0"))     # ... and of the stream the next batch's augmentation runs on
 
 
 def view_streams():
@@ -140,7 +142,7 @@ def data_ready(device, stream=None):
 def _view_stream_pair(device):
     device = _dev_key(device)
     if device not in _STREAMS:
-        _STREAMS[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        _STREAMS[device] = (torch.cuda.Stream(device, priority=_VIEW_STREAM_PRIO), torch.cuda.Stream(device, priority=_VIEW_STREAM_PRIO))
     return _STREAMS[device]
 
 
@@ -161,7 +163,7 @@ class input_stream:
             self.main = torch.cuda.current_stream(self.device)
             side = _INPUT_STREAMS.get(self.device)
             if side is None:
-                side = _INPUT_STREAMS[self.device] = torch.cuda.Stream(self.device)
+                side = _INPUT_STREAMS[self.device] = torch.cuda.Stream(self.device, priority=_INPUT_STREAM_PRIO)
                 side.wait_stream(self.main)               # whatever built the dataset on the ambient stream
             ready = _DATA_READY.get(self.device)
             if ready is not None:
