@@ -2356,6 +2356,113 @@ extern "C" int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x, const f
 }
 
 namespace {
+// ---- the stem's weight gradient from image ROWS staged in LDS (round 4) -------------------------------------------------------------------------------------------
+// conv_wgrad_k's row-taps gather (GATHER 3) stages a [32 pixels][R x 24] window tile per k-tile with six unaligned, masked 16-byte gathers per thread - index and
+// mask arithmetic that keeps the kernel at 0.59 matrix-pipe busy (69 TFLOP/s inside the step, the slowest launch of the ResNet step).  Here a workgroup walks whole
+// OUTPUT ROWS: the R image rows an output row sees go to LDS once, as they lie in memory (coalesced float4s; zeros left / right of the row and for rows outside the
+// image), with the dY row beside them, and the window element (pixel wo, filter row r, float e) is the LDS float  r * ROWF + off + 3 * stride * wo + e : the B fragment
+// of an MFMA step is one ds_read_b32 at an address that advances by a constant per pixel - no gather, no masks, Wo / 2 steps x 3 MFMAs per wave between two barriers.
+// Output: one partial slab [K = 64][R x 24] per workgroup (columns e >= 3 S of a filter row are written as zeros), reduced by wgrad_reduce_k like the other form's.
+constexpr int SR_R = 7, SR_ROWF = 728, SR_WO = 112, SR_K = 64;      // ROWF = 24 (mod 64): a column block that spans two filter rows reads 32 distinct banks
+constexpr int SR_NX = (SR_R * (SR_ROWF / 4) + 255) / 256, SR_NDY = (SR_WO * SR_K / 4 + 255) / 256;
+
+static inline bool stem_rows_ok(const ssv_conv_desc* d) {
+#ifdef SSV_NO_STEM_ROWS
+  return false;              // diagnostic builds: the gather form everywhere
+#endif
+  const int padl = (d->pad * 3 + 3) / 4 * 4, off = padl - d->pad * 3;
+  return d->C == 3 && d->K == SR_K && d->R <= SR_R && d->S * 3 <= 24 && d->W % 4 == 0 && d->Wo % 2 == 0 && d->Wo <= SR_WO &&
+         padl + d->W * 3 <= SR_ROWF && off + (d->Wo - 1) * d->stride * 3 + 24 <= SR_ROWF && (int64_t)d->N * d->H * d->W * 12 < (1ll << 31);
+}
+
+// (Measured and rejected: the real window floats only, packed as column 3 S r + e - 147 columns = five 32-column blocks on five waves instead of six on four:
+//  1.51 ms against this form's 1.35 although it issues 17 % fewer MFMAs; profiles/r04_probe_stem_rows.txt.)
+__global__ void __launch_bounds__(256, 3)
+stem_wgrad_rows_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int rows_per_wg) {
+  __shared__ __attribute__((aligned(16))) float srows[(SR_R + 1) * SR_ROWF];      // row SR_R stays zero: the columns past R x 24 read it
+  __shared__ __attribute__((aligned(16))) float sdy[SR_WO * SR_K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;                      // this wave: output channels 32 wm .., columns 96 wn ..
+  const int padl = (p.pad * 3 + 3) / 4 * 4, off = padl - p.pad * 3, s3 = p.stride * 3;
+  const int w34 = p.W * 3 / 4, nx = p.R * w34, ndy = p.Wo * SR_K / 4, NCOL = p.R * 24;
+  for (int i = tid; i < (SR_R + 1) * SR_ROWF; i += 256) srows[i] = 0.f;
+  int bbase[3];
+#pragma unroll
+  for (int tn = 0; tn < 3; ++tn) {
+    const int col = 96 * wn + 32 * tn + l31, r = col / 24;
+    bbase[tn] = (col < NCOL ? r * SR_ROWF + off + (col - 24 * r) : SR_R * SR_ROWF) + half * s3;
+  }
+  const int abase = half * SR_K + 32 * wm + l31;
+  int xr[SR_NX], xj[SR_NX];                                    // this thread's float4s of the staged image rows: filter row, float4 within the row
+#pragma unroll
+  for (int i = 0; i < SR_NX; ++i) { const int f = tid + 256 * i; xr[i] = f < nx ? f / w34 : -1; xj[i] = f - (f / w34) * w34; }
+  const int64_t G = (int64_t)p.N * p.Ho;
+  const int64_t g0 = (int64_t)blockIdx.x * rows_per_wg, g1 = g0 + rows_per_wg < G ? g0 + rows_per_wg : G;
+  f32x4 rx[SR_NX], rd[SR_NDY];
+  auto load_row = [&](int64_t g) {
+    const int n = (int)(g / p.Ho), ho = (int)(g - (int64_t)n * p.Ho);
+#pragma unroll
+    for (int i = 0; i < SR_NX; ++i) {
+      const int hi = ho * p.stride - p.pad + xr[i];
+      rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (xr[i] >= 0 && (unsigned)hi < (unsigned)p.H) rx[i] = *reinterpret_cast<const f32x4*>(x + ((int64_t)n * p.H + hi) * p.W * 3 + 4 * xj[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < SR_NDY; ++i) {
+      const int f = tid + 256 * i;
+      if (f < ndy) rd[i] = *reinterpret_cast<const f32x4*>(dy + g * p.Wo * SR_K + 4 * f);
+    }
+  };
+  auto store_row = [&]() {
+#pragma unroll
+    for (int i = 0; i < SR_NX; ++i)
+      if (xr[i] >= 0) *reinterpret_cast<f32x4*>(&srows[xr[i] * SR_ROWF + padl + 4 * xj[i]]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < SR_NDY; ++i) {
+      const int f = tid + 256 * i;
+      if (f < ndy) *reinterpret_cast<f32x4*>(&sdy[4 * f]) = rd[i];
+    }
+  };
+  f32x16 acc[3];
+#pragma unroll
+  for (int tn = 0; tn < 3; ++tn)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[tn][j] = 0.f;
+  __syncthreads();                                              // the zero fill is complete before the first row is stored over it
+  if (g0 < g1) load_row(g0);
+  const int nsteps = p.Wo >> 1;
+  for (int64_t g = g0; g < g1; ++g) {
+    store_row();
+    __syncthreads();
+    if (g + 1 < g1) load_row(g + 1);                            // the next output row's image rows and dY row fly under this row's MFMAs
+#pragma unroll 4
+    for (int st = 0; st < nsteps; ++st) {
+      const float a = sdy[abase + 2 * st * SR_K];
+#pragma unroll
+      for (int tn = 0; tn < 3; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, srows[bbase[tn] + 2 * st * s3], acc[tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * SR_K * NCOL;
+#pragma unroll
+  for (int tn = 0; tn < 3; ++tn) {
+    const int col = 96 * wn + 32 * tn + l31;
+    if (col >= NCOL) continue;
+    const bool real = col - 24 * (col / 24) < 3 * p.S;          // the padding floats of a filter row's 24 stay zero in the row-taps layout
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[(size_t)(32 * wm + (j & 3) + 8 * (j >> 2) + 4 * half) * NCOL + col] = real ? acc[tn][j] : 0.f;
+  }
+}
+
+struct StemRowsPlan { int rows_per_wg, nsplit; };
+static inline StemRowsPlan stem_rows_plan(const ssv_conv_desc* d) {      // one resident round of 3 workgroups per CU, whole output rows per workgroup
+  const int64_t G = (int64_t)d->N * d->Ho;
+  StemRowsPlan r;
+  r.rows_per_wg = (int)cdiv64(G, 768);
+  r.nsplit = (int)cdiv64(G, r.rows_per_wg);
+  return r;
+}
+
 struct StemWgradPlan { int tiles, nsplit, chunk; };
 StemWgradPlan plan_stem_wgrad(const ssv_conv_desc* d) {
   StemWgradPlan w;
@@ -2374,7 +2481,10 @@ StemWgradPlan plan_stem_wgrad(const ssv_conv_desc* d) {
 
 extern "C" size_t ssv_stem_conv_wgrad_workspace_bytes(const ssv_conv_desc* d) {
   if (!d || d->K <= 0 || d->R <= 0) return 0;
-  return (size_t)plan_stem_wgrad(d).nsplit * d->K * d->R * 24 * sizeof(float);
+  const size_t slab = (size_t)d->K * d->R * 24 * sizeof(float);
+  const size_t gather = (size_t)plan_stem_wgrad(d).nsplit * slab;
+  const size_t rows = stem_rows_ok(d) ? (size_t)stem_rows_plan(d).nsplit * slab : 0;
+  return gather > rows ? gather : rows;
 }
 
 // dwrows [K][R][24] = weight gradient in the row-taps layout (columns >= 3 S are zero); overwritten, not accumulated
@@ -2383,12 +2493,21 @@ extern "C" int ssv_stem_conv_wgrad(const ssv_conv_desc* d, const float* x, const
   SSV_REQUIRE(x && dy && dwrows && ws && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dwrows | (uintptr_t)ws) & 15) == 0, "ssv_stem_conv_wgrad: null or unaligned pointer");
   SSV_REQUIRE(d->C == 3 && d->S * 3 <= 24 && d->S <= 8 && d->K % 4 == 0, "ssv_stem_conv_wgrad: a 3-channel input, at most 8 taps per filter row, K %% 4 == 0 (got C=%d S=%d K=%d)", d->C, d->S, d->K);
   const StemWgradPlan wp = plan_stem_wgrad(d);
-  const size_t need = (size_t)wp.nsplit * d->K * d->R * 24 * sizeof(float);
+  const size_t need = ssv_stem_conv_wgrad_workspace_bytes(d);
   if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_stem_conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_WGRAD, s);
   const ConvKP p = make_kp(d);
   float* part = (float*)ws;
+  if (stem_rows_ok(d)) {                                         // whole output rows from image rows staged in LDS
+    const StemRowsPlan rp = stem_rows_plan(d);
+    hipLaunchKernelGGL(stem_wgrad_rows_k, dim3((unsigned)rp.nsplit), dim3(256), 0, s, p, x, dy, part, rp.rows_per_wg);
+    SSV_CHECK_LAUNCH("ssv_stem_conv_wgrad(rows)");
+    const int64_t n = (int64_t)d->K * d->R * 24;
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, (const float*)part, rp.nsplit, n, dwrows, 0);
+    SSV_CHECK_LAUNCH("ssv_stem_conv_wgrad(reduce)");
+    return SSV_OK;
+  }
   hipLaunchKernelGGL((conv_wgrad_k<64, 192, 2, 2, 32, true, 3>), dim3((unsigned)(wp.tiles * wp.nsplit)), dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles);
   SSV_CHECK_LAUNCH("ssv_stem_conv_wgrad(partial)");
   const int64_t n = (int64_t)d->K * d->R * 24;

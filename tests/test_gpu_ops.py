@@ -694,7 +694,8 @@ def test_conv_that_forms_and_writes_the_closing_activation_is_bitwise_bn_apply_t
     np.testing.assert_allclose(y.cpu().double().numpy(), yr.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("n,h,w_,k,r,stride,pad", [(3, 20, 20, 64, 7, 2, 3), (2, 9, 11, 64, 3, 1, 1), (2, 13, 7, 132, 7, 2, 3), (1, 7, 7, 16, 3, 1, 1), (5, 33, 31, 64, 7, 2, 3)])
+@pytest.mark.parametrize("n,h,w_,k,r,stride,pad", [(3, 20, 20, 64, 7, 2, 3), (2, 9, 11, 64, 3, 1, 1), (2, 13, 7, 132, 7, 2, 3), (1, 7, 7, 16, 3, 1, 1), (5, 33, 31, 64, 7, 2, 3),
+                                                    (2, 224, 224, 64, 7, 2, 3), (3, 32, 32, 64, 3, 1, 1), (2, 40, 24, 64, 7, 2, 3), (9, 12, 8, 64, 5, 2, 2), (1, 8, 228, 64, 7, 2, 3)])
 def test_stem_conv_in_the_row_taps_form_on_the_unpadded_image(dev, n, h, w_, k, r, stride, pad):
     """ssv_stem_conv_fwd / ssv_stem_conv_wgrad: the 3-channel stem without channel padding - a k-tile is one filter row, 3 S contiguous floats of
     the image row at a 12-byte-aligned address, left / right image borders masked per element - against torch fp64, with the statistics epilogue;
