@@ -177,6 +177,9 @@ int ssv_conv2d_wgrad_bias(const ssv_conv_desc* d, const float* x, const float* d
  * contraction runs over R rows of 24 floats (3 S <= 24 real ones, zero weights behind them): 168 columns for the 7x7 stem's 147, no channel
  * padding of the images.  wrows / dwrows [K][R][24]: ssv_pad_channels of the OHWI filter viewed as [K*R][3 S] (and back for the gradient). */
 int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x /*[N][H][W][3]*/, const float* wrows, float* y, float* pmean, float* pm2, void* stream);
+/* Output pixels per statistics partial of ssv_stem_conv_fwd for this shape: 64 (groups = ceil(M / 64), as ssv_conv2d_fwd_stats) or a whole number of output rows
+ * (the rows-in-LDS kernel: M is a multiple of it).  pmean / pm2 hold ceil(M / that) rows of K floats. */
+int64_t ssv_stem_conv_fwd_stats_rows_per_group(const ssv_conv_desc* d);
 size_t ssv_stem_conv_wgrad_workspace_bytes(const ssv_conv_desc* d);
 int ssv_stem_conv_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dwrows, void* ws, size_t ws_bytes, void* stream);
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ssv_conv2d_wgrad_bias_workspace_bytes": (_sz, [_cd]),
     "ssv_conv2d_wgrad_bias": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_stem_conv_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_stem_conv_fwd_stats_rows_per_group": (_i64, [_cd]),
     "ssv_stem_conv_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_stem_conv_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_wino_tiles": (_i64, [_i32, _i32, _i32]),

@@ -2336,9 +2336,137 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
 }
 }  // namespace
 
+namespace {
+// ---- the stem's forward from image ROWS staged in LDS (round 4; the weight gradient's twin is stem_wgrad_rows_k below) ---------------------------------------------
+// A workgroup of seven waves walks pairs (RPI-tuples) of OUTPUT ROWS: the (RPI - 1) stride + R image rows they see go to LDS as they lie in memory (coalesced float4s,
+// zeros left / right of a row and for rows outside the image), the whole filter sits in LDS beside them in step order, and the window element (pixel wo of output row
+// rr, filter row r, float e) is the LDS float (rr stride + r) ROWF + off + 3 stride wo + e: wave w owns the 32 pixels 32 w .. of the RPI Wo <= 224 pixels and both
+// 32-channel blocks; an MFMA step (two window floats e = 2 i, 2 i + 1 of one filter row; 3 S floats padded to an even count with zero weights) is one ds_read_b32 of the
+// window at an IMMEDIATE offset of the lane's pixel address and two of the filter.  No gather, no masks, 154 MFMAs per wave between two barriers, 147 -> 154 contraction
+// columns instead of the row-taps form's 168.  Statistics: every wave reduces its 32 pixels per channel to (mean, M2) in registers (two passes over its accumulators),
+// the seven pairs are merged in LDS (Chan's update, equal counts) - one partial per RPI Wo pixels (ssv_stem_conv_fwd_stats_rows_per_group).
+constexpr int SF_ROWS = 9, SF_ROWF = 728, SF_K = 64, SF_NT = 448, SF_MAXSTEPS = 77;
+constexpr int SF_NX = (SF_ROWS * (SF_ROWF / 4) + SF_NT - 1) / SF_NT;
+
+static inline int stem_fwd_rows_rpi(const ssv_conv_desc* d) {       // output rows per iteration, 0 = this launch runs on the row-taps kernel
+#ifdef SSV_NO_STEM_ROWS
+  return 0;
+#endif
+  const int padl = (d->pad * 3 + 3) / 4 * 4, off = padl - d->pad * 3;
+  if (!(d->C == 3 && d->K == SF_K && d->R <= 7 && d->S * 3 <= 24 && d->R * ((d->S * 3 + 1) / 2) <= SF_MAXSTEPS && d->W % 4 == 0 &&
+        padl + d->W * 3 <= SF_ROWF && off + (d->Wo - 1) * d->stride * 3 + 24 <= SF_ROWF && (int64_t)d->N * d->H * d->W * 12 < (1ll << 31)))
+    return 0;
+  int best = 0;
+  for (int r = 1; r * d->Wo <= 224; ++r)
+    if ((r * d->Wo) % 32 == 0 && d->Ho % r == 0 && (r - 1) * d->stride + d->R <= SF_ROWS) best = r;
+  return best * d->Wo >= 192 ? best : 0;                             // at least six of the seven waves have pixels
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(SF_NT, 2)
+stem_fwd_rows_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ wrows, float* __restrict__ y, float* __restrict__ pmean, float* __restrict__ pm2,
+                int rpi, int iters_per_wg) {
+  __shared__ __attribute__((aligned(16))) float srows[SF_ROWS * SF_ROWF];
+  __shared__ __attribute__((aligned(16))) float sw[SF_MAXSTEPS * 2 * SF_K];            // [step][half][channel]
+  __shared__ float sst[STATS ? 2 * 7 * SF_K : 1];                                      // per wave and channel: mean | M2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int padl = (p.pad * 3 + 3) / 4 * 4, off = padl - p.pad * 3, s3 = p.stride * 3, S3 = 3 * p.S, spr = (S3 + 1) >> 1;
+  const int w34 = p.W * 3 / 4, nrows = (rpi - 1) * p.stride + p.R, nx = nrows * w34, miter = rpi * p.Wo, nwav = miter >> 5;
+  for (int i = tid; i < SF_ROWS * SF_ROWF; i += SF_NT) srows[i] = 0.f;
+  for (int i = tid; i < p.R * spr * 2 * SF_K; i += SF_NT) {        // the filter in step order: step = r * spr + i, float e = 2 i + half of filter row r (zero past 3 S)
+    const int n = i & (SF_K - 1), hs = i >> 6, h = hs & 1, st = hs >> 1, r = st / spr, e = 2 * (st - r * spr) + h;
+    sw[i] = e < S3 ? wrows[(n * p.R + r) * 24 + e] : 0.f;
+  }
+  const int mi = 32 * wave + l31, rr = mi / p.Wo, wo = mi - rr * p.Wo;      // this lane's pixel of the iteration (waves past nwav idle)
+  const int abase = rr * p.stride * SF_ROWF + off + s3 * wo + half;
+  const int bbase = half * SF_K + l31;
+  int xr[SF_NX], xj[SF_NX];
+#pragma unroll
+  for (int i = 0; i < SF_NX; ++i) { const int f = tid + SF_NT * i; xr[i] = f < nx ? f / w34 : -1; xj[i] = f - (f / w34) * w34; }
+  const int64_t IT = (int64_t)p.N * p.Ho / rpi;
+  const int64_t it0 = (int64_t)blockIdx.x * iters_per_wg, it1 = it0 + iters_per_wg < IT ? it0 + iters_per_wg : IT;
+  f32x4 rx[SF_NX];
+  auto load_rows = [&](int64_t it) {
+    const int64_t g = it * rpi;
+    const int n = (int)(g / p.Ho), ho = (int)(g - (int64_t)n * p.Ho);
+#pragma unroll
+    for (int i = 0; i < SF_NX; ++i) {
+      const int hi = ho * p.stride - p.pad + xr[i];
+      rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (xr[i] >= 0 && (unsigned)hi < (unsigned)p.H) rx[i] = *reinterpret_cast<const f32x4*>(x + ((int64_t)n * p.H + hi) * p.W * 3 + 4 * xj[i]);
+    }
+  };
+  auto store_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < SF_NX; ++i)
+      if (xr[i] >= 0) *reinterpret_cast<f32x4*>(&srows[xr[i] * SF_ROWF + padl + 4 * xj[i]]) = rx[i];
+  };
+  __syncthreads();                                              // zero fill and filter are in place
+  if (it0 < it1) load_rows(it0);
+  for (int64_t it = it0; it < it1; ++it) {
+    store_rows();
+    __syncthreads();
+    if (it + 1 < it1) load_rows(it + 1);                        // the next iteration's image rows fly under this one's MFMAs
+    f32x16 acc[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[tn][j] = 0.f;
+    if (wave < nwav) {
+      for (int r = 0; r < p.R; ++r) {
+        const float* ar = srows + abase + r * SF_ROWF;
+        const float* br = sw + bbase + r * spr * 2 * SF_K;
+#pragma unroll 11
+        for (int i = 0; i < spr; ++i) {
+          const float a = ar[2 * i];
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[i * 2 * SF_K + 32 * tn], acc[tn], 0, 0, 0);
+        }
+      }
+      const int64_t m0 = it * miter + 32 * wave;                // first pixel of this wave (output rows of an iteration are contiguous in y)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)       // (32 consecutive channels of a pixel per half-wave: 128-byte segments.  Timing what-if 2: no stores - 1.40 -> 1.27 ms at bs 512)
+          if (!(SSV_WHATIF & 2) || acc[tn][j] == 12345.f) y[(m0 + (j & 3) + 8 * (j >> 2) + 4 * half) * SF_K + 32 * tn + l31] = acc[tn][j];
+        if constexpr (STATS) {
+          float sm = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) sm += acc[tn][j];
+          sm += __shfl_xor(sm, 32, 64);
+          const float mean = sm * (1.f / 32.f);
+          float q = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { const float dlt = acc[tn][j] - mean; q += dlt * dlt; }
+          q += __shfl_xor(q, 32, 64);
+          if (half == 0) { sst[wave * SF_K + 32 * tn + l31] = mean; sst[(7 + wave) * SF_K + 32 * tn + l31] = q; }
+        }
+      }
+    }
+    __syncthreads();                                            // every wave has read this iteration's rows; the per-wave statistics are in LDS
+    if constexpr (STATS) {
+      if (tid < SF_K) {
+        float mean = 0.f, m2 = 0.f;
+        for (int w = 0; w < nwav; ++w) mean += sst[w * SF_K + tid];
+        mean /= (float)nwav;
+        for (int w = 0; w < nwav; ++w) { const float dlt = sst[w * SF_K + tid] - mean; m2 += sst[(7 + w) * SF_K + tid] + 32.f * dlt * dlt; }
+        pmean[it * SF_K + tid] = mean;
+        pm2[it * SF_K + tid] = m2;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int64_t ssv_stem_conv_fwd_stats_rows_per_group(const ssv_conv_desc* d) {
+  if (!d) return 0;
+  const int rpi = stem_fwd_rows_rpi(d);
+  return rpi ? (int64_t)rpi * d->Wo : 64;
+}
+
 // ---- the 3-channel image stem on the UNPADDED image (networks/resnet.py:96-99, 147): row-taps form ------------------------------------------
 // x [N][H][W][3]; wrows [K][R][24] = the filter's rows, 3 S floats each ((s, c) order = OHWI memory) zero-padded to 24; y [N][Ho][Wo][K];
-// optional statistics partials as ssv_conv2d_fwd_stats.  3 S <= 24, K % 4 == 0.
+// optional statistics partials: one (mean, M2) per ssv_stem_conv_fwd_stats_rows_per_group(d) output pixels (64, as ssv_conv2d_fwd_stats, on the row-taps kernel).  3 S <= 24, K % 4 == 0.
 extern "C" int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x, const float* wrows, float* y, float* pmean, float* pm2, void* stream) {
   if (int rc = check_desc(d, "ssv_stem_conv_fwd")) return rc;
   SSV_REQUIRE(x && wrows && y && (pmean == nullptr) == (pm2 == nullptr), "ssv_stem_conv_fwd: bad pointers");
@@ -2348,6 +2476,15 @@ extern "C" int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x, const f
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   ConvKP p = make_kp(d);
   p.aux_out = pmean; p.aux_out2 = pm2;
+  if (const int rpi = stem_fwd_rows_rpi(d)) {                    // whole output rows from image rows staged in LDS
+    const int64_t iters = (int64_t)d->N * d->Ho / rpi;
+    const int ipw = (int)cdiv64(iters, 512);                     // one resident round of two workgroups per CU
+    const unsigned g = (unsigned)cdiv64(iters, ipw);
+    if (pmean) hipLaunchKernelGGL((stem_fwd_rows_k<true>), dim3(g), dim3(SF_NT), 0, s, p, x, wrows, y, pmean, pm2, rpi, ipw);
+    else       hipLaunchKernelGGL((stem_fwd_rows_k<false>), dim3(g), dim3(SF_NT), 0, s, p, x, wrows, y, pmean, pm2, rpi, ipw);
+    SSV_CHECK_LAUNCH("ssv_stem_conv_fwd(rows)");
+    return SSV_OK;
+  }
   const unsigned grid = (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
   if (pmean) hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 24, true, false, true, 2>), dim3(grid), dim3(256), 0, s, p, x, wrows, (const float*)nullptr, (const float*)nullptr, y);
   else       hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 24, true, false, false, 2>), dim3(grid), dim3(256), 0, s, p, x, wrows, (const float*)nullptr, (const float*)nullptr, y);

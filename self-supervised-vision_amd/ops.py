@@ -1220,15 +1220,22 @@ def stem_conv_fwd(x, wrows, w_shape, stride, pad, want_stats=False):
     d = conv_desc(x.shape, w_shape, stride, pad)
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
     lib = _lib.load()
-    part = _empty((2, int(lib.ssv_conv2d_fwd_stats_groups(C.byref(d))), d.K), x) if want_stats else None
+    # statistics partials: one per 64 output pixels, or per whole output rows on the rows-in-LDS kernel (the same for every chunk: it depends on the map, not the batch)
+    rpg = int(lib.ssv_stem_conv_fwd_stats_rows_per_group(C.byref(d)))
+    m = d.N * d.Ho * d.Wo
+    part = _empty((2, -(-m // rpg), d.K), x) if want_stats else None
     g0 = 0
     for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo if want_stats else None):
         dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), w_shape, stride, pad)
-        gc = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(dc)))
+        if int(lib.ssv_stem_conv_fwd_stats_rows_per_group(C.byref(dc))) != rpg:
+            raise _lib.SsvError("ssv_stem_conv_fwd: statistics group size changed between batch chunks")
+        gc = -(-(n1 - n0) * d.Ho * d.Wo // rpg)
         call("ssv_stem_conv_fwd", C.byref(dc), ptr(x[n0:n1]), ptr(wrows), ptr(y[n0:n1]),
              ptr(part[0][g0:g0 + gc]) if want_stats else None, ptr(part[1][g0:g0 + gc]) if want_stats else None, stream())
         g0 += gc
-    return y, (None if part is None else (part[0], part[1]))
+    if part is None:
+        return y, None
+    return y, ((part[0], part[1]) if rpg == 64 else (part[0], part[1], rpg))
 
 
 def stem_conv_wgrad(x, dy, w_shape, stride, pad):

@@ -717,11 +717,18 @@ def test_stem_conv_in_the_row_taps_form_on_the_unpadded_image(dev, n, h, w_, k, 
     assert none is None and torch.equal(y0, y)
     m = y.numel() // k
     y2 = y.view(m, k).cpu().double()
-    assert part[0].shape == ((m + 63) // 64, k)
-    for g in range(part[0].shape[0]):
-        blk = y2[64 * g:64 * g + 64]
+    rpg = ops._rows_per_group(part)              # 64 output pixels per partial, or whole output rows on the rows-in-LDS kernel
+    assert part[0].shape == ((m + rpg - 1) // rpg, k) and (rpg == 64 or m % rpg == 0)
+    for g in range(0, part[0].shape[0], max(1, part[0].shape[0] // 40)):
+        blk = y2[rpg * g:rpg * g + rpg]
         np.testing.assert_allclose(part[0][g].cpu().numpy(), blk.mean(0).numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(part[1][g].cpu().numpy(), ((blk - blk.mean(0)) ** 2).sum(0).numpy(), rtol=1e-3, atol=1e-4)
+    # ... and BatchNorm from the partials == BatchNorm from its own statistics pass
+    gamma, beta = (seeded_randn(7, k).abs() + 0.5).to(dev), seeded_randn(8, k).to(dev)
+    rm, rv, nbt = torch.zeros(k, device=dev), torch.ones(k, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    mean, invstd, _, _ = ops.bn_stats_finalize(m, k, part, gamma, beta, rm, rv, nbt)
+    np.testing.assert_allclose(mean.cpu().double().numpy(), y2.mean(0).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(invstd.cpu().double().numpy(), (1.0 / torch.sqrt(y2.var(0, unbiased=False) + 1e-5)).numpy(), rtol=1e-4)
     dwr = ops.stem_conv_wgrad(x3.to(dev), dy.to(dev), tuple(wd.shape), stride, pad)
     assert dwr.shape == (k * r, 24) and float(dwr[:, 3 * r:].abs().max()) == 0.0            # the padding columns see zero operands
     got = dwr[:, :3 * r].reshape(k, r, r, 3).permute(0, 3, 1, 2)
