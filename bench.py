@@ -185,7 +185,7 @@ def _cpu_model():
 GATE_LR_SCALES = {"simclr": 0.01, "byol": 0.01, "barlow": 1e-4}
 
 
-def cpu_baseline(views, steps, algo="simclr", lr_scale=None):
+def cpu_baseline(views, steps, algo="simclr", lr_scale=None, fp64=True):
     """The oracle (CPU restatement of the reference step, pinned to reference fixtures) on this box's host cores, on the SAME augmented
     views the GPU path is given: (v1, v2) fp32 [B,3,S,S] CPU tensors.  1 warm-up + `steps` timed fp32 steps (the state every
     step starts from is kept, outside the timed intervals, for the teacher-forced gate); then, untimed, an fp64 twin of the oracle (same
@@ -219,11 +219,13 @@ def cpu_baseline(views, steps, algo="simclr", lr_scale=None):
         dt += time.perf_counter() - t0
     dt /= steps
     del m
-    m64 = oracle.twin64(make)
-    run64 = step_of(m64, v1.double(), v2.double())
-    first64 = run64(0)
-    losses64 = [first64["loss"]] + [run64(s)["loss"] for s in range(1, steps + 1)]
-    del m64
+    first64, losses64 = {}, None
+    if fp64:
+        m64 = oracle.twin64(make)
+        run64 = step_of(m64, v1.double(), v2.double())
+        first64 = run64(0)
+        losses64 = [first64["loss"]] + [run64(s)["loss"] for s in range(1, steps + 1)]
+        del m64
     out = {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cpus": host, "cpu_model": _cpu_model(), "kind": "port",
            "sample": f"{steps} timed steps (1 warm-up) of the same {algo} ResNet-50 {size}x{size} step at batch {batch} on the GPU path's own augmented views, "
                      f"torch fp32 CPU, lr = config / {round(1 / lr_scale)}"}
@@ -293,49 +295,67 @@ def parity_gate_dino(device, cpu_losses, batch=2, steps=3):
             "pass": bool(max(rel) <= 1e-4)}
 
 
-def parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, batch=32, steps=3):
+def parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, batch=32, steps=3, fp64=True):
     """SURVEY 8d "parity gates (same run)": the CPU oracle and a fresh HIP trainer run the same `steps`+1 training steps on the same
     `batch` augmented views (the first rows of the bench's own source images).  Two statements:
       * teacher-forced (the north-star's bar, per step): before every step the HIP trainer is given the CPU trajectory's state
         (weights, momentum), so each step is the same pure function on both sides - per-step loss within 1e-4 relative on EVERY step;
       * free-running: the HIP trainer carries its own state - step 0 within 1e-4, later steps inside the fp64 envelope of the CPU path;
-    plus the step-0 projected features.  The CPU side of it IS the cpu_baseline timing."""
+    plus the step-0 projected features.  The CPU side of it IS the cpu_baseline timing.
+    The HIP trainer of the gate runs under ops.large_batch_dispatch: the Winograd forms' tile-count floors are lifted, so the batch-32 gate
+    takes the kernel selection of the timed batch-512 step (F(4x4) on the 14x14 data gradients and the 7x7 layers too); `dispatch` in the
+    result counts the launches per form.  ``fp64`` False (the short gates of `other_configs`): no fp64 twin, no free-running envelope -
+    step 0 and the teacher-forced steps only."""
+    from ssv_amd import ops
     b = min(batch, source.shape[0])
     views = tf.apply(source, rows[:b], tf.draw(source, sample_ids[:b], 0))
     v1, v2 = views[0], views[1]                              # channels_last memory, as the timed steps get them
-    base, cpu_losses, f64_losses, z_cpu, z64, states = cpu_baseline((v1.cpu().contiguous(), v2.cpu().contiguous()), steps, algo)
-    hip_step, _ = build(device, algo, lr_scale=GATE_LR_SCALES[algo])
-    captured = {}
-    t = hip_step.trainer
-    if algo in ("simclr", "barlow"):
-        inner = t.loss_fn
+    base, cpu_losses, f64_losses, z_cpu, z64, states = cpu_baseline((v1.cpu().contiguous(), v2.cpu().contiguous()), steps, algo, fp64=fp64)
+    with ops.large_batch_dispatch() as disp:
+        hip_step, _ = build(device, algo, lr_scale=GATE_LR_SCALES[algo])
+        captured = {}
+        t = hip_step.trainer
+        if algo in ("simclr", "barlow"):
+            inner = t.loss_fn
 
-        def spy(z1, z2):
-            captured.setdefault("z_1", z1.detach().float().cpu())
-            return inner(z1, z2)
-        t.loss_fn = spy
-    hip_losses = [hip_step({"aug_1": v1, "aug_2": v2}) for _ in range(steps + 1)]
-    torch.cuda.synchronize()
-    # teacher-forced: step 0 starts from the common initialisation on both sides (the run above); steps >= 1 from the CPU trajectory's state
-    forced = [hip_losses[0]]
-    for s_ in range(1, steps + 1):
-        _load_cpu_state(t, states[s_], s_, algo)
-        forced.append(t.train_step({"aug_1": v1, "aug_2": v2})["loss"])
-        t._after_step(s_)
-    torch.cuda.synchronize()
+            def spy(z1, z2):
+                captured.setdefault("z_1", z1.detach().float().cpu())
+                return inner(z1, z2)
+            t.loss_fn = spy
+        hip_losses = [hip_step({"aug_1": v1, "aug_2": v2}) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        # teacher-forced: step 0 starts from the common initialisation on both sides (the run above); steps >= 1 from the CPU trajectory's state
+        forced = [hip_losses[0]]
+        for s_ in range(1, steps + 1):
+            _load_cpu_state(t, states[s_], s_, algo)
+            forced.append(t.train_step({"aug_1": v1, "aug_2": v2})["loss"])
+            t._after_step(s_)
+        torch.cuda.synchronize()
+        dispatch = {k: round(v / (2 * steps + 1), 1) for k, v in sorted(disp.log.items())}   # launches per step (2 * steps + 1 steps ran)
     del hip_step, t, states
     torch.cuda.empty_cache()
     rel = [abs(h - c) / abs(c) for h, c in zip(hip_losses, cpu_losses)]
     rel_forced = [abs(h - c) / abs(c) for h, c in zip(forced, cpu_losses)]
+    sci = lambda xs: [float(f"{x:.2e}") for x in xs]
+    if not fp64:
+        gate = {"workload": f"{algo} ResNet-50 {v1.shape[-1]}x{v1.shape[-1]}, batch {b}, the bench's own augmented views, lr = config / {round(1 / GATE_LR_SCALES[algo])}, "
+                            f"step 0 + {steps} teacher-forced step(s) on that batch",
+                "loss_hip_teacher_forced": [round(x, 7) for x in forced], "loss_cpu": [round(x, 7) for x in cpu_losses],
+                "loss_rel_err_teacher_forced": sci(rel_forced), "teacher_forced_pass": bool(max(rel_forced) <= 1e-4),
+                "dispatch": {"rule": "kernel selection of the batch-512 step (ops.large_batch_dispatch)", "winograd_launches_per_step": dispatch},
+                "bar": {"loss_teacher_forced": "1e-4 relative to the fp32 CPU oracle on every step, each step evaluated from the CPU trajectory's own state"}}
+        gate["pass"] = bool(rel[0] <= 1e-4 and gate["teacher_forced_pass"])
+        return gate, base
     d_hip = [abs(h - f) / abs(f) for h, f in zip(hip_losses, f64_losses)]
     d_cpu = [abs(c - f) / abs(f) for c, f in zip(cpu_losses, f64_losses)]
-    sci = lambda xs: [float(f"{x:.2e}") for x in xs]
     gate = {"workload": f"{algo} ResNet-50 {v1.shape[-1]}x{v1.shape[-1]}, batch {b}, the bench's own augmented views, lr = config / {round(1 / GATE_LR_SCALES[algo])}, {steps + 1} steps on that batch",
             "loss_hip_teacher_forced": [round(x, 7) for x in forced], "loss_cpu": [round(x, 7) for x in cpu_losses],
             "loss_rel_err_teacher_forced": sci(rel_forced),
             "teacher_forced_pass": bool(max(rel_forced) <= 1e-4),
             "loss_hip": [round(x, 7) for x in hip_losses], "loss_cpu_fp64": [round(x, 7) for x in f64_losses],
             "loss_rel_err": sci(rel), "loss_rel_err_hip_vs_fp64": sci(d_hip), "loss_rel_err_cpu32_vs_fp64": sci(d_cpu),
+            "dispatch": {"rule": "kernel selection of the batch-512 step (ops.large_batch_dispatch: the Winograd forms' tile-count floors lifted for the gate trainer)",
+                         "winograd_launches_per_step": dispatch},
             "bar": {"loss_teacher_forced": "1e-4 relative to the fp32 CPU oracle on EVERY step (north-star), each step evaluated from the CPU trajectory's "
                                            "own weights and momentum - the per-step statement",
                     "loss_step0": "1e-4 relative to the fp32 CPU oracle (north-star)",
@@ -431,6 +451,129 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
             "loss_step0": {"hip": round(hip0, 7), "cpu": round(cpu0, 7), "rel_err": float(f"{abs(hip0 - cpu0) / abs(cpu0):.2e}")}}
 
 
+def make_step(device, algo, train_step, source, sample_ids, rows, tf, multi_crop):
+    """One bench step: fresh augmentation parameters (Philox keyed by GLOBAL sample id and step) -> the views on the input stream ->
+    the trainer's own train_step(batch)."""
+    from ssv_amd import nn as hnn
+    counter = [0]
+
+    def step():
+        with hnn.input_stream(device) as ins:                         # as utils/data_utils.GpuTwoViewLoader does: the views are built on their own stream
+            if multi_crop is not None:                                # two augmented copies -> 2 x (2 global + 8 local) bicubic crops
+                batch = multi_crop(source, rows, counter[0], sample_ids=sample_ids)
+            else:
+                params = tf.draw(source, sample_ids, counter[0])      # RNG keyed by the GLOBAL sample id
+                views = tf.apply(source, rows, params)
+                batch = {"aug_1": views[0], "aug_2": views[1]}
+            ins.publish(*batch.values())
+        counter[0] += 1
+        return train_step(batch)
+    return step
+
+
+def time_ntxent(device, nglob, b, d=128, reps=20):
+    """The two NT-Xent row kernels alone at ONE RANK's shape - 2b local rows against 2 nglob gathered columns (utils/losses.py:15-46 in the
+    row-block form, SURVEY 8e iii) - HIP events on the launch stream, `reps` launches each, with the library's column split and unsplit."""
+    from ssv_amd import ops
+    g = torch.Generator(device=device).manual_seed(5)
+    z = torch.randn(2 * nglob, d, generator=g, device=device)
+    z, _ = ops.l2norm_fwd(z, True)
+    lse_all = torch.empty(2 * nglob, device=device)
+    for r in range(nglob // b):                                   # every row's log-sum-exp (what the second all-gather delivers)
+        lse, _ = ops.ntxent_fwd(z, nglob, b, r * b, 2.0)
+        lse_all[r * b:(r + 1) * b].copy_(lse[:b])
+        lse_all[nglob + r * b:nglob + (r + 1) * b].copy_(lse[b:])
+    out = {"rows": 2 * b, "cols": 2 * nglob, "dim": d, "splits": ops.ntxent_splits(nglob, b)}
+    for tag, splits in (("", out["splits"]), ("_unsplit", 1)):
+        for name, fn in (("fwd", lambda: ops.ntxent_fwd(z, nglob, b, 0, 2.0, splits=splits)),
+                         ("bwd", lambda: ops.ntxent_bwd(z, lse_all, nglob, b, 0, 2.0, 2.0 / (2 * nglob), splits=splits))):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            out[f"{name}_us{tag}"] = round(e0.elapsed_time(e1) / reps * 1e3, 1)
+    flop = 2.0 * (2 * b) * (2 * nglob) * d
+    out["fwd_tflops"] = round(flop / out["fwd_us"] / 1e6, 1)
+    out["bwd_tflops"] = round(2 * flop / out["bwd_us"] / 1e6, 1)      # the Gram tile again + W . Z
+    return out
+
+
+def config3_rank_emulation(device, train_step, step, b, n1_ms, world=8, warmup=2, steps=5):
+    """BASELINE config 3 (SimCLR resnet50, global batch 4096 on 8 GPUs) as the step ONE RANK of it executes, measured on the one GPU this run
+    has: ssv_amd.distributed.emulate_world(8) - the trainer takes every data-parallel code path (NT-Xent of its 1,024 rows against 8,192
+    gathered columns, two all-gathers, per-bucket slab folds and SUM all-reduces launched from the backward pass on the exchange stream)
+    with the transport replaced by device copies: the seven peers hold this rank's own shard, for which the emulation is exact
+    (tests/test_gpu_config3.py).  What it cannot show is the xGMI time of the collectives (4.2 MB + 36 KB gathered, 112 MB all-reduced
+    per step against >= 200 ms of compute)."""
+    from ssv_amd import distributed as hdist
+    t = train_step.trainer
+    mods = t._sync_modules()
+    prev = hdist.emulate_world(world, 0)
+    try:
+        hdist.attach_grad_sync(t.optim, mods)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        buckets = [[n, (hi - lo) * 4] for n, lo, hi in t.optim.grad_sync.buckets]
+    finally:
+        hdist.detach_grad_sync(t.optim, mods)
+        hdist.restore_world(prev)
+    return {"emulated_world": world, "rank": 0, "per_rank_batch": b, "global_batch": b * world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms, 3), "images_per_sec_per_rank": round(b / ms * 1e3, 1), "last_loss": loss,
+            "n1_ms_per_step": round(n1_ms, 3), "compute_side_scaling_ceiling": round(n1_ms / ms, 4),
+            "ceiling_note": "ms_per_step of the single-GPU step / ms_per_step of one rank's step of the 8-GPU job with free transport: the scaling efficiency "
+                            "the compute side alone allows (the collectives' xGMI time is NOT in it - no multi-GPU node was available to this build)",
+            "ntxent": time_ntxent(device, b * world, b),
+            "gradient_buckets": buckets,
+            "transport": "emulated (ssv_amd.distributed.emulate_world): all-gather = one device copy of the gathered size with this rank's block in every "
+                         "slot, all-reduce(SUM) = x world on the exchange stream; every kernel of the rank's step is the real one"}
+
+
+def other_config_leg(device, algo, tf, source, sample_ids, rows, cfg, warmup=2, steps=5):
+    """BASELINE configs 4 (BYOL resnet50 bs 512 / GPU) and 5 (DINO ViT-S/16 multi-crop bs 128 / GPU) in the driver's default line: a fresh trainer,
+    `warmup` + `steps` timed steps of its per-GPU workload, and a short parity gate against the CPU oracle at a small batch."""
+    from ssv_amd.utils import augmentations
+    b = min(128, source.shape[0]) if algo == "dino" else source.shape[0]
+    train_step, nparams = build(device, algo)
+    multi_crop = augmentations.MultiCrop({**DINO_CROPS, "train_transforms": cfg}) if algo == "dino" else None
+    step = make_step(device, algo, train_step, source[:b], sample_ids[:b], rows[:b], tf, multi_crop)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del step, train_step
+    torch.cuda.empty_cache()
+    s = source.shape[1]
+    if algo == "dino":
+        gemm, attn, _ = dino_work(b)
+        flop = gemm + attn
+    else:
+        flop, _ = step_work(algo, s, s, b)
+    out = {"metric": f"images/sec {algo} per-GPU workload of BASELINE config {'5' if algo == 'dino' else '4'}", "value": round(b / dt, 2), "unit": "images/sec",
+           "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "per_gpu_batch": b, "params": nparams, "last_loss": loss, "dtype": "f32",
+           "whole_step_mfma_frac": round(flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if algo == "dino":
+        base, cpu_losses = cpu_baseline_dino(batch=2, steps=2)
+        gate = parity_gate_dino(device, cpu_losses, batch=2, steps=3)
+    else:
+        gate, base = parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, batch=16, steps=1, fp64=False)
+    out.update(parity_gate=gate, cpu_baseline=base)
+    out["pass"] = bool(gate["pass"])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,6 +584,9 @@ def main():
     ap.add_argument("--algo", choices=tuple(ALGOS), default="simclr", help="simclr = BASELINE.json's metric; byol = its config 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=2, help="extra instrumented steps for the per-kernel-class roofline")
+    ap.add_argument("--emulate-world", type=int, default=0, help="W > 1: this ONE process runs the step of rank 0 of a W-rank job "
+                    "(ssv_amd.distributed.emulate_world: every data-parallel code path, transport replaced by device copies)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config3_rank_emulation / other_configs (BYOL, DINO) legs of the default line")
     args = ap.parse_args()
 
     from ssv_amd import _lib, distributed as hdist
@@ -453,6 +599,10 @@ def main():
         raise SystemExit(f"bench.py needs an MI355X: no HIP device visible (rank {rank} of {world})")
     device = torch.device("cuda", torch.cuda.current_device())
     _lib.load()
+    if args.emulate_world > 1:
+        if world != 1:
+            raise SystemExit("--emulate-world runs in ONE process (it replaces the process group): use it with --gpus 1")
+        hdist.emulate_world(args.emulate_world, 0)                    # before build(): the trainer attaches its gradient buckets
 
     if args.batch is None:
         args.batch = int(os.environ.get("SSV_BENCH_BATCH", "128" if args.algo == "dino" else "512"))
@@ -471,19 +621,7 @@ def main():
     cfg["random_resized_crop"] = {"size": [s, s], "scale": [0.2, 1.0]}
     tf = augmentations.get_transform(cfg)
     multi_crop = augmentations.MultiCrop({**DINO_CROPS, "train_transforms": cfg}) if args.algo == "dino" else None
-    counter = [0]
-
-    def step():
-        with hnn.input_stream(device) as ins:                         # as utils/data_utils.GpuTwoViewLoader does: the views are built on their own stream
-            if multi_crop is not None:                                # two augmented copies -> 2 x (2 global + 8 local) bicubic crops
-                batch = multi_crop(source, rows, counter[0], sample_ids=sample_ids)
-            else:
-                params = tf.draw(source, sample_ids, counter[0])      # RNG keyed by the GLOBAL sample id
-                views = tf.apply(source, rows, params)
-                batch = {"aug_1": views[0], "aug_2": views[1]}
-            ins.publish(*batch.values())
-        counter[0] += 1
-        return train_step(batch)
+    step = make_step(device, args.algo, train_step, source, sample_ids, rows, tf, multi_crop)
 
     def barrier():
         if world > 1:
@@ -638,6 +776,24 @@ def main():
                                                               "achieved_tflops": round(attn_flop_step / max(attn_ms, 1e-9) / 1e9, 2)},
                 "classes": classes}
 
+    # ---- BASELINE config 3's per-rank step on this one GPU (default SimCLR line only; after the timed region and the instrumented steps) ----
+    emu_block = None
+    legs = rank == 0 and world == 1 and args.algo == "simclr" and not args.emulate_world and not args.no_other_configs
+    if legs:
+        try:
+            emu_block = config3_rank_emulation(device, train_step, step, b, ms_per_step)
+        except Exception as exc:                                       # a failing extra leg must not take the headline line with it
+            emu_block = {"error": f"{type(exc).__name__}: {exc}"}
+    emu_self = None
+    if args.emulate_world > 1:                                         # --emulate-world W: the whole line IS one rank's step of the W-rank job
+        emu_self = {"emulated_world": args.emulate_world, "rank": 0, "global_batch": b * args.emulate_world,
+                    "value_is": "images/sec of ONE rank's step (per-rank batch / step time); the W-rank job with free transport would run W x that",
+                    "ntxent": time_ntxent(device, b * args.emulate_world, b) if args.algo == "simclr" else None,
+                    "gradient_buckets": [[n, (hi - lo) * 4] for n, lo, hi in train_step.trainer.optim.grad_sync.buckets],
+                    "transport": "emulated (ssv_amd.distributed.emulate_world): all-gather = one device copy of the gathered size with this rank's block in "
+                                 "every slot, all-reduce(SUM) = x world on the exchange stream; every kernel of the rank's step is the real one"}
+        hdist.emulate_world(None)
+
     label = {"simclr": "SimCLR", "byol": "BYOL", "barlow": "Barlow Twins", "dino": "DINO"}[args.algo]
     loss_desc = {"simclr": "NT-Xent(normalize, T=0.5) over the global batch", "byol": "EMA target encoder (4 encoder passes), pair MSE of unit vectors",
                  "barlow": "cross-correlation loss D=4096 over the global batch",
@@ -659,6 +815,12 @@ def main():
         "roofline": roof,
         "distributed": dist_info,
     }
+    if emu_self is not None:
+        out["emulated_world"] = emu_self
+    if emu_block is not None:
+        out["config3_rank_emulation"] = emu_block
+    del step, train_step                                               # the extra legs below build their own trainers
+    torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.algo == "dino":
             out["cpu_baseline"], dino_cpu_losses = cpu_baseline_dino()
@@ -667,6 +829,16 @@ def main():
             out["parity_gate"], out["cpu_baseline"] = parity_gate_and_cpu_baseline(device, args.algo, tf, source, sample_ids, rows)
             if args.algo == "simclr":
                 out["config1"] = config1_line(device)
+        if legs:                                                       # BASELINE configs 4 and 5, driver-visible: each leg on its own, errors recorded
+            out["other_configs"] = {}
+            for other in ("byol", "dino"):
+                t_leg = time.perf_counter()
+                try:
+                    out["other_configs"][other] = other_config_leg(device, other, tf, source, sample_ids, rows, cfg)
+                except Exception as exc:
+                    out["other_configs"][other] = {"error": f"{type(exc).__name__}: {exc}", "pass": False}
+                    torch.cuda.empty_cache()
+                out["other_configs"][other]["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
     elif rank == 0:
         out["cpu_baseline"], out["parity_gate"] = None, None
     if rank == 0:

@@ -327,6 +327,18 @@ int ssv_ntxent_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const
 int ssv_ntxent_loss(int32_t rows, const float* lse, const float* pos, float scale, float* loss, void* stream);
 int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
                    const float* lse_all, float inv_temp, float gscale, float* dZ, void* stream);
+/* The same two passes with the COLUMN sweep cut into `splits` runs of column tiles, one workgroup per (32 rows, run): a rank of the
+ * 8-GPU job owns 2*512 rows against 2*4096 gathered columns (BASELINE config 3) - 32 row blocks alone would leave 7/8 of the CUs idle.
+ * Partials go through the caller's workspace (ssv_ntxent_split_workspace_bytes; [splits][2*Bloc][max(ldz,3)] floats) and are folded in
+ * split order (deterministic).  splits = 1 is ssv_ntxent_fwd / _bwd (no workspace).  ssv_ntxent_default_splits is the library's own
+ * choice for a shape (a count, not a status: two workgroups per CU where the columns allow, >= 8 column tiles per run). */
+int64_t ssv_ntxent_default_splits(int32_t Nglob, int32_t Bloc);
+size_t ssv_ntxent_split_workspace_bytes(int32_t Bloc, int32_t ldz, int32_t splits);
+int ssv_ntxent_fwd_split(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                         float inv_temp, float* lse, float* pos, int32_t splits, void* ws, size_t ws_bytes, void* stream);
+int ssv_ntxent_bwd_split(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                         const float* lse_all, float inv_temp, float gscale, float* dZ,
+                         int32_t splits, void* ws, size_t ws_bytes, void* stream);
 /* The same loss for projection widths beyond the register-resident kernels (ldz > 128; the reference accepts any D): the host forms the
  * Gram block S[2*Bloc][lds] = Z_loc . Z_all^T with ssv_conv2d_fwd (lds = 2*Nglob rounded up to 16, pad columns are products with zero
  * rows), ssv_ntxent_gram_fwd reads lse / pos off it, ssv_ntxent_gram_weights turns it IN PLACE into

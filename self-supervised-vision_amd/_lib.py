@@ -117,6 +117,10 @@ SIGNATURES = {
     "ssv_ntxent_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
     "ssv_ntxent_loss": (C.c_int, [_i32, _vp, _vp, _f32, _vp, _vp]),
     "ssv_ntxent_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "ssv_ntxent_default_splits": (_i64, [_i32, _i32]),
+    "ssv_ntxent_split_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "ssv_ntxent_fwd_split": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "ssv_ntxent_bwd_split": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _i32, _vp, _sz, _vp]),
     "ssv_ntxent_gram_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
     "ssv_ntxent_gram_weights": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp]),
     "ssv_reduce_workspace_bytes": (_sz, [_i64]),

@@ -9,6 +9,7 @@
 //   * in the backward the weight tile W (same layout) is directly the A operand of the second
 //     product dZ += W . Zc (A[i = l&31][k = l>>5] = W[r][crow(j,h)] for MFMA step j), so the P
 //     matrix never touches LDS or HBM.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -70,7 +71,10 @@ __device__ __forceinline__ f32x16 gram_tile(const float* __restrict__ Z, int ldz
 
 template <int DQ>
 __global__ void __launch_bounds__(256)
-ntxent_fwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z, float inv_temp, float* __restrict__ lse, float* __restrict__ pos) {
+ntxent_fwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z, float inv_temp, float* __restrict__ lse, float* __restrict__ pos,
+             int tiles_per_split, float* __restrict__ part) {
+  // grid (row blocks of 32, column splits): with gridDim.y > 1 a workgroup sweeps only its own run of column tiles and leaves the
+  // running (max, sum, positive) of its rows in part[split][row][3]; ntxent_merge_k folds the splits in split order.
   __shared__ float sm_m[4][32], sm_s[4][32], sm_p[4][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int R2 = 2 * Nglob, rows_loc = 2 * Bloc;
@@ -84,7 +88,8 @@ ntxent_fwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z
 
   float m = -INFINITY, s = 0.f, pv = 0.f;
   const int ntile = (R2 + 31) / 32;
-  for (int ct = wave; ct < ntile; ct += 4) {
+  const int t0 = blockIdx.y * tiles_per_split, t1 = min(ntile, t0 + tiles_per_split);
+  for (int ct = t0 + wave; ct < t1; ct += 4) {
     const int cl = ct * 32 + l31;
     const f32x16 T = gram_tile<DQ>(Z, ldz, cl < R2 ? cl : R2 - 1, h, zr);
     float sv[16];
@@ -125,15 +130,40 @@ ntxent_fwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z
       mm = mn;
       pp += sm_p[w][l31];
     }
-    lse[lr] = mm + logf(ss);
-    pos[lr] = pp;
+    if (gridDim.y == 1) {
+      lse[lr] = mm + logf(ss);
+      pos[lr] = pp;
+    } else {
+      float* p = part + ((size_t)blockIdx.y * rows_loc + lr) * 3;
+      p[0] = mm; p[1] = ss; p[2] = pp;
+    }
   }
+}
+
+// fold the column splits' (max, sum, positive) of every local row, in split order
+__global__ void __launch_bounds__(256)
+ntxent_merge_k(int rows_loc, int splits, const float* __restrict__ part, float* __restrict__ lse, float* __restrict__ pos) {
+  const int lr = blockIdx.x * 256 + threadIdx.x;
+  if (lr >= rows_loc) return;
+  float mm = -INFINITY, ss = 0.f, pp = 0.f;
+  for (int sp = 0; sp < splits; ++sp) {
+    const float* p = part + ((size_t)sp * rows_loc + lr) * 3;
+    const float m2 = p[0], s2 = p[1];
+    const float mn = fmaxf(mm, m2);
+    ss = (mm > -INFINITY ? ss * expf(mm - mn) : 0.f) + (m2 > -INFINITY ? s2 * expf(m2 - mn) : 0.f);
+    mm = mn;
+    pp += p[2];
+  }
+  lse[lr] = mm + logf(ss);
+  pos[lr] = pp;
 }
 
 template <int DQ>
 __global__ void __launch_bounds__(256)
 ntxent_bwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z, const float* __restrict__ lse_all,
-             float inv_temp, float gscale, float* __restrict__ dZ) {
+             float inv_temp, float gscale, float* __restrict__ dZ, int tiles_per_split, float* __restrict__ part) {
+  // grid (row blocks of 32, column splits): with gridDim.y > 1 the workgroup's sum over ITS column tiles goes to part[split][row][ldz]
+  // and ntxent_bwd_reduce_k adds the splits in split order, subtracts the positive and scales.
   constexpr int DC = DQ / 4;                 // 32-wide chunks of the embedding dimension
   __shared__ float red[32][DQ * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -153,7 +183,8 @@ ntxent_bwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z
     for (int j = 0; j < 16; ++j) out[dc][j] = 0.f;
 
   const int ntile = (R2 + 31) / 32;
-  for (int ct = wave; ct < ntile; ct += 4) {
+  const int t0 = blockIdx.y * tiles_per_split, t1 = min(ntile, t0 + tiles_per_split);
+  for (int ct = t0 + wave; ct < t1; ct += 4) {
     const int cl = ct * 32 + l31;
     const f32x16 T = gram_tile<DQ>(Z, ldz, cl < R2 ? cl : R2 - 1, h, zr);
 #pragma unroll
@@ -185,11 +216,29 @@ ntxent_bwd_k(int Nglob, int Bloc, int seg0, int ldz, const float* __restrict__ Z
     const int r = e / ldz, d = e - r * ldz;
     const int lrow = blockIdx.x * 32 + r;
     if (lrow < rows_loc) {
-      const int g = global_row(lrow, Bloc, Nglob, seg0);
-      const int pg = g < Nglob ? g + Nglob : g - Nglob;
-      dZ[(size_t)lrow * ldz + d] = gscale * (red[r][d] - 2.f * Z[(size_t)pg * ldz + d]);
+      if (gridDim.y == 1) {
+        const int g = global_row(lrow, Bloc, Nglob, seg0);
+        const int pg = g < Nglob ? g + Nglob : g - Nglob;
+        dZ[(size_t)lrow * ldz + d] = gscale * (red[r][d] - 2.f * Z[(size_t)pg * ldz + d]);
+      } else {
+        part[((size_t)blockIdx.y * rows_loc + lrow) * ldz + d] = red[r][d];
+      }
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+ntxent_bwd_reduce_k(int Nglob, int Bloc, int seg0, int ldz, int splits, const float* __restrict__ Z, const float* __restrict__ part,
+                    float gscale, float* __restrict__ dZ) {
+  const int rows_loc = 2 * Bloc;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows_loc * ldz) return;
+  const int lrow = e / ldz, d = e - lrow * ldz;
+  float acc = 0.f;
+  for (int sp = 0; sp < splits; ++sp) acc += part[((size_t)sp * rows_loc + lrow) * ldz + d];
+  const int g = global_row(lrow, Bloc, Nglob, seg0);
+  const int pg = g < Nglob ? g + Nglob : g - Nglob;
+  dZ[e] = gscale * (acc - 2.f * Z[(size_t)pg * ldz + d]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -293,21 +342,55 @@ static int check_ntxent(int Nglob, int Bloc, int seg0, int ldz, const char* who)
   return SSV_OK;
 }
 
-extern "C" int ssv_ntxent_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
-                              float inv_temp, float* lse, float* pos, void* stream) {
+// how many column splits the loss kernels take at this shape: enough workgroups for two per CU (row blocks x splits >= 512 where the
+// columns allow), every split at least 8 column tiles (two per wavefront) so the sweep still amortises the row fragments it keeps in registers
+extern "C" int64_t ssv_ntxent_default_splits(int32_t Nglob, int32_t Bloc) {
+  if (Nglob <= 0 || Bloc <= 0) return 1;
+  const int row_blocks = cdiv(2 * Bloc, 32), ntile = cdiv(2 * Nglob, 32);
+  int splits = std::min(512 / std::max(row_blocks, 1), ntile / 8);
+  return std::max(1, std::min(splits, 64));
+}
+
+extern "C" size_t ssv_ntxent_split_workspace_bytes(int32_t Bloc, int32_t ldz, int32_t splits) {
+  if (Bloc <= 0 || ldz <= 0 || splits <= 1) return 0;
+  return (size_t)splits * 2 * Bloc * (size_t)std::max(ldz, 3) * sizeof(float);
+}
+
+static int check_split(int Nglob, int Bloc, int ldz, int splits, const void* ws, size_t ws_bytes, const char* who) {
+  SSV_REQUIRE(splits >= 1 && splits <= 64, "%s: splits must be 1..64 (got %d)", who, splits);
+  SSV_REQUIRE(splits <= cdiv(2 * Nglob, 32), "%s: more splits (%d) than column tiles", who, splits);
+  if (splits > 1) {
+    SSV_REQUIRE(ws, "%s: workspace required with splits > 1", who);
+    if (ws_bytes < ssv_ntxent_split_workspace_bytes(Bloc, ldz, splits)) SSV_FAIL(SSV_ERR_WORKSPACE, "%s: workspace too small", who);
+  }
+  return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_fwd_split(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                                    float inv_temp, float* lse, float* pos, int32_t splits, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_ntxent(Nglob, Bloc, seg0, ldz, "ssv_ntxent_fwd")) return rc;
+  if (int rc = check_split(Nglob, Bloc, ldz, splits, ws, ws_bytes, "ssv_ntxent_fwd_split")) return rc;
   SSV_REQUIRE(Z && lse && pos && ((uintptr_t)Z & 15) == 0, "ssv_ntxent_fwd: null or unaligned pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_LOSS, s);
-  const dim3 grid(cdiv(2 * Bloc, 32));
+  const int tps = cdiv(cdiv(2 * Nglob, 32), splits);
+  splits = cdiv(cdiv(2 * Nglob, 32), tps);                       // no empty trailing split
+  const dim3 grid(cdiv(2 * Bloc, 32), splits);
+  float* part = (float*)ws;
   switch (ldz / 8) {
-    case 4:  hipLaunchKernelGGL((ntxent_fwd_k<4>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
-    case 8:  hipLaunchKernelGGL((ntxent_fwd_k<8>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
-    case 12: hipLaunchKernelGGL((ntxent_fwd_k<12>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
-    default: hipLaunchKernelGGL((ntxent_fwd_k<16>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos); break;
+    case 4:  hipLaunchKernelGGL((ntxent_fwd_k<4>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos, tps, part); break;
+    case 8:  hipLaunchKernelGGL((ntxent_fwd_k<8>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos, tps, part); break;
+    case 12: hipLaunchKernelGGL((ntxent_fwd_k<12>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos, tps, part); break;
+    default: hipLaunchKernelGGL((ntxent_fwd_k<16>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos, tps, part); break;
   }
+  if (splits > 1) hipLaunchKernelGGL(ntxent_merge_k, dim3(cdiv(2 * Bloc, 256)), dim3(256), 0, s, 2 * Bloc, splits, part, lse, pos);
   SSV_CHECK_LAUNCH("ssv_ntxent_fwd");
   return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_fwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                              float inv_temp, float* lse, float* pos, void* stream) {
+  return ssv_ntxent_fwd_split(Nglob, Bloc, seg0, ldz, Z, inv_temp, lse, pos, 1, nullptr, 0, stream);
 }
 
 extern "C" int ssv_ntxent_loss(int32_t rows, const float* lse, const float* pos, float scale, float* loss, void* stream) {
@@ -319,21 +402,33 @@ extern "C" int ssv_ntxent_loss(int32_t rows, const float* lse, const float* pos,
   return SSV_OK;
 }
 
-extern "C" int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
-                              const float* lse_all, float inv_temp, float gscale, float* dZ, void* stream) {
+extern "C" int ssv_ntxent_bwd_split(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                                    const float* lse_all, float inv_temp, float gscale, float* dZ,
+                                    int32_t splits, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_ntxent(Nglob, Bloc, seg0, ldz, "ssv_ntxent_bwd")) return rc;
+  if (int rc = check_split(Nglob, Bloc, ldz, splits, ws, ws_bytes, "ssv_ntxent_bwd_split")) return rc;
   SSV_REQUIRE(Z && lse_all && dZ && ((uintptr_t)Z & 15) == 0, "ssv_ntxent_bwd: null or unaligned pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_LOSS, s);
-  const dim3 grid(cdiv(2 * Bloc, 32));
+  const int tps = cdiv(cdiv(2 * Nglob, 32), splits);
+  splits = cdiv(cdiv(2 * Nglob, 32), tps);
+  const dim3 grid(cdiv(2 * Bloc, 32), splits);
+  float* part = (float*)ws;
   switch (ldz / 8) {
-    case 4:  hipLaunchKernelGGL((ntxent_bwd_k<4>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
-    case 8:  hipLaunchKernelGGL((ntxent_bwd_k<8>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
-    case 12: hipLaunchKernelGGL((ntxent_bwd_k<12>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
-    default: hipLaunchKernelGGL((ntxent_bwd_k<16>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ); break;
+    case 4:  hipLaunchKernelGGL((ntxent_bwd_k<4>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ, tps, part); break;
+    case 8:  hipLaunchKernelGGL((ntxent_bwd_k<8>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ, tps, part); break;
+    case 12: hipLaunchKernelGGL((ntxent_bwd_k<12>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ, tps, part); break;
+    default: hipLaunchKernelGGL((ntxent_bwd_k<16>), grid, dim3(256), 0, s, Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ, tps, part); break;
   }
+  if (splits > 1)
+    hipLaunchKernelGGL(ntxent_bwd_reduce_k, dim3(cdiv(2 * Bloc * ldz, 256)), dim3(256), 0, s, Nglob, Bloc, seg0, ldz, splits, Z, part, gscale, dZ);
   SSV_CHECK_LAUNCH("ssv_ntxent_bwd");
   return SSV_OK;
+}
+
+extern "C" int ssv_ntxent_bwd(int32_t Nglob, int32_t Bloc, int32_t seg0, int32_t ldz, const float* Z,
+                              const float* lse_all, float inv_temp, float gscale, float* dZ, void* stream) {
+  return ssv_ntxent_bwd_split(Nglob, Bloc, seg0, ldz, Z, lse_all, inv_temp, gscale, dZ, 1, nullptr, 0, stream);
 }
 
 // ---- NT-Xent for projection widths beyond the register-resident kernels (ldz > 128): the Gram block S = Z_loc Z_all^T comes from the

@@ -15,18 +15,73 @@ from . import ops
 
 
 _FORCE = False      # a world of ONE rank still takes the collective code paths (the single-GPU functional test of the RCCL calls)
+_EMU = None         # an emulated world (emulate_world): this ONE process runs the kernel sequence of rank r of W, no process group
 
 
-def is_on():
+class _EmulatedWorld:
+    """Rank ``rank`` of ``world`` ranks emulated by one process on one GPU (BASELINE config 3's per-rank step measured where only one device
+    exists): every code path of the data-parallel step is the real one - the rank's 2B rows of NT-Xent against all 2*B*world gathered
+    columns, the per-bucket slab folds launched from the backward pass on the exchange stream - and only the transport is replaced:
+      * ``gather(out, mine)`` stands in for the all-gather: it must fill ``out`` [world*n, ...] (this rank's block ``mine`` at slot
+        ``rank``).  Default: every slot receives ``mine`` - the job whose ``world`` ranks hold the SAME shard, for which the emulation is
+        exact (every peer's embeddings, row log-sum-exps and loss partial equal this rank's), written as ONE device copy of the
+        all-gather's own size;
+      * ``reduce(t)`` stands in for the SUM all-reduce.  Default: ``t *= world`` (the sum over ``world`` identical ranks), one pass over
+        the bucket on the exchange stream like the collective's own local reduce.
+    Tests hand in ``gather`` / ``reduce`` closures that supply REAL peers (other shards run one after the other)."""
+
+    def __init__(self, world, rank, gather=None, reduce=None):
+        if not (world >= 1 and 0 <= rank < world):
+            raise ValueError(f"emulate_world: rank {rank} of {world}")
+        self.world, self.rank = int(world), int(rank)
+        self.gather = gather or self._replicate
+        self.reduce = reduce or self._times_world
+
+    def _replicate(self, out, mine):
+        out.view(self.world, *mine.shape).copy_(mine)
+
+    def _times_world(self, t):
+        t.mul_(float(self.world))
+
+
+def emulate_world(world, rank=0, gather=None, reduce=None):
+    """Switch the emulated world on (``world`` ranks, this process is ``rank``) or off (``world`` None); returns the previous setting's
+    object (hand it back to ``restore_world``).  Refused while a real process group is initialised."""
+    global _EMU
+    if world is not None and dist.is_available() and dist.is_initialized():
+        raise RuntimeError("emulate_world: a process group is initialised - the emulation replaces it, it cannot sit on top of it")
+    prev = _EMU
+    _EMU = None if world is None else _EmulatedWorld(world, rank, gather, reduce)
+    return prev
+
+
+def restore_world(prev):
+    global _EMU
+    _EMU = prev
+
+
+def emulated():
+    return _EMU is not None
+
+
+def _group_on():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
+def is_on():
+    return _EMU is not None or _group_on()
+
+
 def world_size():
-    return dist.get_world_size() if is_on() else 1
+    if _EMU is not None:
+        return _EMU.world
+    return dist.get_world_size() if _group_on() else 1
 
 
 def rank():
-    return dist.get_rank() if is_on() else 0
+    if _EMU is not None:
+        return _EMU.rank
+    return dist.get_rank() if _group_on() else 0
 
 
 def init_from_env(backend=None):
@@ -34,7 +89,7 @@ def init_from_env(backend=None):
     global _FORCE
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     force = os.environ.get("SSV_DIST_FORCE", "0") == "1"          # WORLD_SIZE=1 + SSV_DIST_FORCE=1: every collective runs over one rank
-    if (ws <= 1 and not force) or (dist.is_available() and dist.is_initialized()):
+    if (ws <= 1 and not force) or (dist.is_available() and dist.is_initialized()) or _EMU is not None:
         return rank(), world_size()
     _FORCE = force and ws <= 1
     if _FORCE:
@@ -58,7 +113,9 @@ def all_gather_rows(buf, rows_per_rank):
         return buf
     mine = buf[rank() * rows_per_rank:(rank() + 1) * rows_per_rank].clone()      # input must not alias the output
     with _timed(buf):
-        if dist.get_backend() == "nccl":
+        if _EMU is not None:
+            _EMU.gather(buf, mine)
+        elif dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(buf, mine)                               # one RCCL all-gather straight into place
         else:
             dist.all_gather([buf[r * rows_per_rank:(r + 1) * rows_per_rank] for r in range(world_size())], mine)
@@ -106,7 +163,9 @@ def all_gather_blocks(out, mine):
         out.copy_(mine)
         return out
     with _timed(out):
-        if dist.get_backend() == "nccl":
+        if _EMU is not None:
+            _EMU.gather(out, mine)
+        elif dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(out, mine)
         else:
             n = mine.shape[0]
@@ -117,7 +176,10 @@ def all_gather_blocks(out, mine):
 def all_reduce_sum(t):
     if is_on():
         with _timed(t):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if _EMU is not None:
+                _EMU.reduce(t)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -251,15 +313,24 @@ def attach_grad_sync(optimizer, modules=(), bucketed=None):
     return optimizer
 
 
+def detach_grad_sync(optimizer, modules=()):
+    """Undo ``attach_grad_sync`` (the emulated-world leg of bench.py hands the trainer back to its single-GPU form)."""
+    optimizer.grad_sync = None
+    for m in modules:
+        if "_grad_sync" in m.__dict__:
+            object.__delattr__(m, "_grad_sync")
+    return optimizer
+
+
 def broadcast_parameters(flat):
-    if is_on():
+    if _group_on():
         dist.broadcast(flat, src=0)
     return flat
 
 
 def broadcast_object(obj, src=0):
     """Rank ``src``'s python object on every rank (run names, small configuration)."""
-    if not is_on():
+    if not _group_on():
         return obj
     box = [obj]
     dist.broadcast_object_list(box, src=src)
@@ -267,5 +338,5 @@ def broadcast_object(obj, src=0):
 
 
 def barrier():
-    if is_on():
+    if _group_on():
         dist.barrier()

@@ -645,12 +645,30 @@ def add_(dst, src):
     return dst
 
 
-def ntxent_fwd(zall, nglob, b, seg0, inv_temp):
+def ntxent_splits(nglob, b):
+    """Column splits of the NT-Xent row kernels at this shape: the library's choice (ssv_ntxent_default_splits), or SSV_NTXENT_SPLITS
+    (diagnostic switch: 1 = the unsplit kernels)."""
+    forced = os.environ.get("SSV_NTXENT_SPLITS")
+    if forced:
+        return max(1, min(int(forced), (2 * nglob + 31) // 32, 64))
+    return int(_lib.load().ssv_ntxent_default_splits(nglob, b))
+
+
+def _ntxent_ws(zall, b, splits):
+    if splits <= 1:
+        return None, 0
+    nbytes = int(_lib.load().ssv_ntxent_split_workspace_bytes(b, zall.shape[1], splits))
+    return workspace.get(nbytes, zall.device), nbytes
+
+
+def ntxent_fwd(zall, nglob, b, seg0, inv_temp, splits=None):
     """Row log-sum-exp and positive logit of this rank's 2*b rows against the gathered [2*nglob, ld] matrix."""
     _lib._dev(zall)
     lse = _empty((2 * b,), zall)
     pos = _empty((2 * b,), zall)
-    call("ssv_ntxent_fwd", nglob, b, seg0, zall.shape[1], ptr(zall), float(inv_temp), ptr(lse), ptr(pos), stream())
+    splits = ntxent_splits(nglob, b) if splits is None else splits
+    ws, nbytes = _ntxent_ws(zall, b, splits)
+    call("ssv_ntxent_fwd_split", nglob, b, seg0, zall.shape[1], ptr(zall), float(inv_temp), ptr(lse), ptr(pos), splits, ptr(ws), nbytes, stream())
     return lse, pos
 
 
@@ -675,10 +693,13 @@ def ntxent_loss(lse, pos, scale):
     return loss
 
 
-def ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_temp, gscale):
+def ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_temp, gscale, splits=None):
     _lib._dev(zall, lse_all)
     dz = _empty((2 * b, zall.shape[1]), zall)
-    call("ssv_ntxent_bwd", nglob, b, seg0, zall.shape[1], ptr(zall), ptr(lse_all), float(inv_temp), float(gscale), ptr(dz), stream())
+    splits = ntxent_splits(nglob, b) if splits is None else splits
+    ws, nbytes = _ntxent_ws(zall, b, splits)
+    call("ssv_ntxent_bwd_split", nglob, b, seg0, zall.shape[1], ptr(zall), ptr(lse_all), float(inv_temp), float(gscale), ptr(dz),
+         splits, ptr(ws), nbytes, stream())
     return dz
 
 
@@ -1058,6 +1079,33 @@ WINOGRAD44_MAX_CHANNELS = 512
 WINOGRAD44_MIN_TILES = 1024
 
 
+# Which Winograd form each product took (launch counts by name), recorded while DISPATCH is a dict: bench.py's parity gate prints it so that the line
+# shows the gate ran the kernel selection of the timed batch-512 step (`large_batch_dispatch`)
+DISPATCH = None
+
+
+def _note(kind):
+    if DISPATCH is not None:
+        DISPATCH[kind] = DISPATCH.get(kind, 0) + 1
+
+
+class large_batch_dispatch:
+    """Run a SMALL batch through the kernel selection of a large one: the tile-count floors of the two Winograd forms are lifted, so every 3x3 product
+    that takes F(4x4) / F(2x2) at batch 512 takes it here too (the ratio / channel rules are batch-independent).  Test and gate plumbing only."""
+
+    def __enter__(self):
+        global WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH
+        self.prev = (WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH)
+        WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH = 0, 0, {}
+        self.log = DISPATCH
+        return self
+
+    def __exit__(self, *exc):
+        global WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH
+        WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH = self.prev
+        return False
+
+
 def _wino44_ratio(h, w_):
     return (36.0 * ((h + 3) // 4) * ((w_ + 3) // 4)) / (16.0 * ((h + 1) // 2) * ((w_ + 1) // 2))
 
@@ -1085,6 +1133,7 @@ def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     """wino_conv2d_fwd through F(4x4, 3x3): 36 transformed-domain GEMMs over a quarter of the tiles.  ``keep_v``: the input transform also leaves the
     F(2x2) transformed input (the weight gradient's operand - wino_conv2d_wgrad takes it unchanged).  Statistics partials: one per row of tiles
     (H % 4 == 0) or per image."""
+    _note("wino44_fwd")
     _lib._dev(x, w)
     w, wshape = _ohwi(w)
     n, h, w_, c = x.shape
@@ -1109,6 +1158,7 @@ def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
 
 def wino44_conv2d_dgrad(dy, w, gate=None):
     """wino_conv2d_dgrad through F(4x4, 3x3); the gate's partial sums come one per row of tiles."""
+    _note("wino44_dgrad")
     _lib._dev(dy, w)
     w, wshape = _ohwi(w)
     n, h, w_, k = dy.shape
@@ -1136,6 +1186,7 @@ def wino_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     partials are one per 16 tiles = 64 output rows (needs even H, W); V is the transformed input, kept for the weight gradient."""
     if _use_wino44(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], WINOGRAD44_MAX_RATIO_FWD):
         return wino44_conv2d_fwd(x, w, in_affine, want_stats, keep_v)
+    _note("wino22_fwd")
     _lib._dev(x, w)
     w, wshape = _ohwi(w)
     n, h, w_, c = x.shape
@@ -1163,6 +1214,7 @@ def wino_conv2d_dgrad(dy, w, gate=None):
     a second target): dx is gated and its partial sums come back as ``dx._gate_partials`` like conv2d_dgrad's."""
     if _use_wino44(dy.shape[0], dy.shape[1], dy.shape[2], w.shape[1], dy.shape[3], WINOGRAD44_MAX_RATIO_DGRAD):
         return wino44_conv2d_dgrad(dy, w, gate)
+    _note("wino22_dgrad")
     _lib._dev(dy, w)
     w, wshape = _ohwi(w)
     n, h, w_, k = dy.shape
@@ -1187,6 +1239,7 @@ def wino_conv2d_dgrad(dy, w, gate=None):
 
 def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     """dw (+)= weight gradient of the 3x3 convolution whose transformed input V was kept by wino_conv2d_fwd."""
+    _note("wino22_wgrad")
     _lib._dev(v, dy, dw)
     _, wshape = _ohwi(w_like)
     n, h, w_, k = dy.shape

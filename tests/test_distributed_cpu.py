@@ -431,3 +431,94 @@ def test_loader_sharding_is_a_partition_of_the_single_process_epoch():
             seen += glob
         assert len(set(seen)) == len(seen) and n - len(seen) < world
     assert _StubLoader(n, b, rank=0, world=1).num_classes == 5
+
+
+def _patch_loss_ops(monkeypatch):
+    from ssv_amd import ops
+    for name, fn in (("l2norm_fwd", _emu_l2norm_fwd), ("l2norm_bwd", _emu_l2norm_bwd), ("ntxent_fwd", _emu_ntxent_fwd), ("ntxent_loss", _emu_ntxent_loss),
+                     ("ntxent_bwd", _emu_ntxent_bwd), ("scale_", lambda x, f: x.mul_(f)), ("fill_", lambda x, v: x.fill_(v)), ("add_", lambda d, s_: d.add_(s_)),
+                     ("mse_pair", _emu_mse_pair)):
+        monkeypatch.setattr(ops, name, fn)
+
+
+def test_emulated_world_replicated_peers_equal_the_oracle_on_the_repeated_batch(monkeypatch):
+    """ssv_amd.distributed.emulate_world(W) - bench.py's config3_rank_emulation: ONE process takes the data-parallel code paths of rank r of W with the
+    transport replaced; with the default peers (every rank holds this rank's shard) the loss and the local gradient rows are exactly those of the
+    W x repeated batch, and the emulated SUM all-reduce multiplies by W."""
+    from ssv_amd import distributed as hdist
+    from ssv_amd.utils import losses
+    _patch_loss_ops(monkeypatch)
+    world, rank, b, d = 4, 2, 6, 20
+    zi, zj = seeded_randn(1, b, d), seeded_randn(2, b, d)
+    a, c = zi.repeat(world, 1).requires_grad_(), zj.repeat(world, 1).requires_grad_()
+    ref = oracle.ntxent_loss(a, c, True, 0.5)
+    ref.backward()
+    assert not hdist.is_on()
+    prev = hdist.emulate_world(world, rank)
+    try:
+        assert hdist.is_on() and hdist.emulated() and hdist.world_size() == world and hdist.rank() == rank
+        assert hdist.init_from_env() == (rank, world)                      # no process group is started under an emulation
+        li, lj = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+        loss = losses.SimclrLoss(True, 0.5)(li, lj)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        sl = slice(rank * b, (rank + 1) * b)
+        np.testing.assert_allclose(li.grad.numpy(), a.grad[sl].numpy(), rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(lj.grad.numpy(), c.grad[sl].numpy(), rtol=2e-4, atol=1e-7)
+        t = torch.arange(5.0)
+        assert torch.equal(hdist.all_reduce_sum(t), torch.arange(5.0) * world)
+        buf = torch.zeros(world * 3, 2)
+        buf[rank * 3:(rank + 1) * 3] = 7.0
+        assert torch.equal(hdist.all_gather_rows(buf, 3), torch.full((world * 3, 2), 7.0))
+        hdist.barrier()                                                    # group-only helpers are no-ops under an emulation
+        assert hdist.broadcast_object("x") == "x"
+        # the BYOL pair loss: global mean with the scalar summed over the (identical) ranks
+        o = [seeded_randn(10 + k, b, d) for k in range(2)]
+        tg = [seeded_randn(12 + k, b, d) for k in range(2)]
+        want = oracle.byol_mse_loss(o[0], o[1], tg[0], tg[1])
+        got = losses.byol_pair_loss(o[0].clone().requires_grad_(), o[1].clone().requires_grad_(), tg[0], tg[1])
+        np.testing.assert_allclose(got.item(), want.item(), rtol=2e-6)
+    finally:
+        hdist.restore_world(prev)
+    assert not hdist.is_on() and hdist.world_size() == 1
+
+
+def test_emulated_world_with_real_peers_is_the_sharded_loss(monkeypatch):
+    """The ``gather`` closure supplies REAL peers (what tests/test_gpu_config3.py does with shards run one after the other): rank r's loss and gradient
+    rows equal the oracle's on the concatenated batch."""
+    from ssv_amd import distributed as hdist
+    from ssv_amd.utils import losses
+    _patch_loss_ops(monkeypatch)
+    world, rank, b, d, ld = 4, 1, 5, 20, 32
+    n = world * b
+    zi, zj = seeded_randn(3, n, d), seeded_randn(4, n, d)
+    a, c = zi.clone().requires_grad_(), zj.clone().requires_grad_()
+    ref = oracle.ntxent_loss(a, c, True, 0.5)
+    ref.backward()
+    blocks = torch.zeros(world, 2 * b, ld)
+    for r in range(world):
+        _emu_l2norm_fwd(zi[r * b:(r + 1) * b], True, ld, out=blocks[r, :b])
+        _emu_l2norm_fwd(zj[r * b:(r + 1) * b], True, ld, out=blocks[r, b:])
+    zall = blocks.view(world, 2, b, ld).permute(1, 0, 2, 3).reshape(2 * n, ld)
+    packs = torch.zeros(world, 2 * b + 4)
+    for r in range(world):
+        lse, pos = _emu_ntxent_fwd(zall, n, b, r * b, 2.0)
+        packs[r, :2 * b], packs[r, 2 * b:] = lse, _emu_ntxent_loss(lse, pos, 1.0 / (2 * n))
+
+    def gather(out, mine):
+        src = blocks.view(world * 2 * b, ld) if out.shape[-1] == ld else packs
+        out.copy_(src)
+        out.view(world, *mine.shape)[rank].copy_(mine)
+    prev = hdist.emulate_world(world, rank, gather=gather)
+    try:
+        sl = slice(rank * b, (rank + 1) * b)
+        li, lj = zi[sl].clone().requires_grad_(), zj[sl].clone().requires_grad_()
+        loss = losses.SimclrLoss(True, 0.5)(li, lj)
+        loss.backward()
+    finally:
+        hdist.restore_world(prev)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(li.grad.numpy(), a.grad[sl].numpy(), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(lj.grad.numpy(), c.grad[sl].numpy(), rtol=2e-4, atol=1e-7)
+    with pytest.raises(ValueError):
+        hdist.emulate_world(4, 4)
