@@ -219,12 +219,23 @@ int ssv_wino44_input_transform(int32_t N, int32_t H, int32_t W, int32_t C, const
                                float* V /*[36][T][C]*/, float* V2 /*[16][ssv_wino_tiles][C] or NULL*/, void* stream);
 int ssv_wino44_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* M /*[36][T][K]*/, float* y, float* pmean, float* pm2,
                                 const ssv_bn_gate* gate, void* stream);   /* pmean / pm2 [groups][K] or NULL; gate (mask or scale + shift, no x2) or NULL */
+/* The WEIGHT gradient through F(4x4) (round 5): dM = A dY A^T per 4x4 output tile [36][T][K], dU_p = dM_p^T . V_p (ssv_gemm_batched_wgrad(36, T, C, K, V, dM, dU) on
+ * the V the forward's input transform left - no V2 needed then), dw (+)= G^T dU G.  0.5625x the F(2x2) weight gradient's products, a 2.25x instead of a 4x dY
+ * transform.  Its error against fp64 is 1.1 - 1.6e-6 relative (F(2x2): 3 - 4e-7) - a weight gradient's error never crosses a ReLU; the bar it is held to is
+ * 2e-6 relative l2 on the ResNet-50 shapes (tests/test_gpu_winograd44.py). */
+int ssv_wino44_dy_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, float* dM /*[36][T][K]*/, void* stream);
+int ssv_wino44_filter_grad(int32_t K, int32_t C, const float* dU /*[36][K][C]*/, float* dw /*[K][3][3][C]*/, int accumulate, void* stream);
 /* batched GEMMs on the implicit-GEMM kernels, ONE launch: y[b] = a[b] . w[b]^T   /   dw[b] = dy[b]^T . x[b]   (b < batch) */
 int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
                      float* y /*[batch][rows][K]*/, void* stream);
 size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K);
 int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x /*[batch][rows][C]*/, const float* dy /*[batch][rows][K]*/,
                            float* dw /*[batch][K][C]*/, void* ws, size_t ws_bytes, void* stream);
+/* The same products with BLOCKED accumulation: no fp32 accumulator chain runs over more than max_chunk_rows (>= 32) rows, the row chunks' slabs are folded in fp64
+ * in fixed order.  For sums whose rounding error must not grow with their length: the Winograd F(4x4) weight gradient (ops.wino44_conv2d_wgrad). */
+size_t ssv_gemm_batched_wgrad_blocked_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K, int32_t max_chunk_rows);
+int ssv_gemm_batched_wgrad_blocked(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
+                                   int32_t max_chunk_rows, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm (training mode, batch statistics) over rows of an [M][C] matrix ------------
  * replaces nn.BatchNorm2d / nn.BatchNorm1d (+ReLU, + residual add) at networks/resnet.py:39-44,

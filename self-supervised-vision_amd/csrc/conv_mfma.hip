@@ -2678,8 +2678,24 @@ extern "C" int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t 
 }
 
 namespace {
+// the same fixed-order fold with the slabs accumulated in fp64: the cross-chunk half of the BLOCKED weight gradient (ssv_gemm_batched_wgrad_blocked)
+__global__ void __launch_bounds__(256)
+wgrad_reduce64_k(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ dw, int accumulate) {
+  __shared__ double sm[4][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  partial += (size_t)blockIdx.y * nsplit * n; dw += (size_t)blockIdx.y * n;
+  const int per = (nsplit + 3) / 4;
+  const int k0 = grp * per, k1 = min(k0 + per, nsplit);
+  double s = 0.0;
+  if (i < n) for (int k = k0; k < k1; ++k) s += (double)partial[(size_t)k * n + i];
+  sm[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) dw[i] = (float)((accumulate ? (double)dw[i] : 0.0) + ((sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e])));
+}
+
 struct BatchedWgradPlan { int bm, bn, tiles, nsplit, chunk; };
-BatchedWgradPlan plan_batched_wgrad(int batch, int64_t rows, int C, int K) {
+BatchedWgradPlan plan_batched_wgrad(int batch, int64_t rows, int C, int K, int max_chunk = 0) {
   BatchedWgradPlan w;
   w.bm = K >= 128 ? 128 : 64;
   w.bn = C <= 64 ? 64 : 128;
@@ -2689,7 +2705,11 @@ BatchedWgradPlan plan_batched_wgrad(int batch, int64_t rows, int C, int K) {
   const int64_t max_by_rows = cdiv64(rows, 256);
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
-  const int64_t chunk = cdiv64(cdiv64(rows, ns), 32) * 32;
+  int64_t chunk = cdiv64(cdiv64(rows, ns), 32) * 32;
+  if (max_chunk > 0 && chunk > max_chunk) {                   // blocked accumulation: no fp32 chain longer than max_chunk rows; equal chunks
+    const int64_t nb = cdiv64(rows, (int64_t)max_chunk);
+    chunk = cdiv64(cdiv64(rows, nb), 32) * 32;
+  }
   w.chunk = (int)chunk;
   w.nsplit = (int)cdiv64(rows, chunk);
   return w;
@@ -2701,23 +2721,31 @@ extern "C" size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t 
   const BatchedWgradPlan w = plan_batched_wgrad(batch, rows, C, K);
   return (size_t)batch * w.nsplit * K * C * sizeof(float);
 }
+extern "C" size_t ssv_gemm_batched_wgrad_blocked_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K, int32_t max_chunk_rows) {
+  if (batch <= 0 || rows <= 0 || C <= 0 || K <= 0 || max_chunk_rows < 32) return 0;
+  const BatchedWgradPlan w = plan_batched_wgrad(batch, rows, C, K, max_chunk_rows);
+  return (size_t)batch * w.nsplit * K * C * sizeof(float);
+}
 
-// dw[b] [K][C] = dy[b]^T [K][rows] . x[b] [rows][C] for b < batch: one launch of the weight-gradient kernel (split over the rows, fixed-order reduce)
-extern "C" int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
-                                      void* ws, size_t ws_bytes, void* stream) {
-  SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "ssv_gemm_batched_wgrad: bad shape");
-  SSV_REQUIRE(C % 4 == 0 && K % 4 == 0, "ssv_gemm_batched_wgrad: needs C %% 4 == 0 and K %% 4 == 0 (got C=%d K=%d)", C, K);
-  SSV_REQUIRE(x && dy && dw && ws && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws) & 15) == 0, "ssv_gemm_batched_wgrad: null or unaligned pointer");
+// dw[b] [K][C] = dy[b]^T [K][rows] . x[b] [rows][C] for b < batch: one launch of the weight-gradient kernel (split over the rows, fixed-order reduce).
+// max_chunk > 0 (ssv_gemm_batched_wgrad_blocked): BLOCKED accumulation - no fp32 accumulator chain runs over more than max_chunk rows, and the slabs are
+// folded in fp64 (still fixed order): the error of a long transformed-domain sum (Winograd F(4x4): 25,088 tiles at 28x28 / batch 512) stops growing with its length.
+static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw, int max_chunk,
+                              void* ws, size_t ws_bytes, void* stream, const char* who) {
+  SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "%s: bad shape", who);
+  SSV_REQUIRE(C % 4 == 0 && K % 4 == 0, "%s: needs C %% 4 == 0 and K %% 4 == 0 (got C=%d K=%d)", who, C, K);
+  SSV_REQUIRE(x && dy && dw && ws && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws) & 15) == 0, "%s: null or unaligned pointer", who);
   ssv_conv_desc d = {(int32_t)rows, 1, 1, C, K, 1, 1, 1, 0, 1, 1};
-  if (int rc = check_desc(&d, "ssv_gemm_batched_wgrad")) return rc;
-  const BatchedWgradPlan wp = plan_batched_wgrad(batch, rows, C, K);
+  if (int rc = check_desc(&d, who)) return rc;
+  const BatchedWgradPlan wp = plan_batched_wgrad(batch, rows, C, K, max_chunk);
   const size_t need = (size_t)batch * wp.nsplit * K * C * sizeof(float);
-  if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "ssv_gemm_batched_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+  if (ws_bytes < need) SSV_FAIL(SSV_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_WGRAD, s);
   ConvKP p = make_kp(&d);
   p.bs_a = rows * C; p.bs_b = rows * K; p.bs_o = (long long)wp.nsplit * K * C;
   float* part = (float*)ws;
+  SSV_REQUIRE((int64_t)wp.tiles * wp.nsplit < (1ll << 31), "%s: too many workgroups", who);
   const dim3 grid((unsigned)(wp.tiles * wp.nsplit), (unsigned)batch);
 #define BWG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles)
   if (wp.bm == 128) { if (wp.bn == 64) BWG(128, 64, 2, 2); else BWG(128, 128, 2, 2); }
@@ -2725,9 +2753,21 @@ extern "C" int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, in
 #undef BWG
   SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(partial)");
   const int64_t n = (int64_t)K * C;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
+  if (max_chunk > 0) hipLaunchKernelGGL(wgrad_reduce64_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
+  else hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
   SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(reduce)");
   return SSV_OK;
+}
+
+extern "C" int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, 0, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad");
+}
+
+extern "C" int ssv_gemm_batched_wgrad_blocked(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
+                                              int32_t max_chunk_rows, void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(max_chunk_rows >= 32, "ssv_gemm_batched_wgrad_blocked: max_chunk_rows must be >= 32 (got %d)", max_chunk_rows);
+  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, max_chunk_rows, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad_blocked");
 }
 
 #ifdef SSV_STAMP

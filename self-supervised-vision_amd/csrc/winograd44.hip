@@ -55,6 +55,22 @@ __device__ __forceinline__ void g3(const float (&g)[3], float (&u)[6]) {
   u[5] = g[2];
 }
 
+// A (6x4) = (A^T)^T applied to a 4-vector: the weight gradient's dY transform  dM = A dY A^T
+template <class T> __device__ __forceinline__ void a6(const T (&y)[4], T (&m)[6]) {
+  m[0] = y[0];
+  m[1] = y[0] + y[1] + y[2] + y[3];
+  m[2] = y[0] - y[1] + y[2] - y[3];
+  m[3] = y[0] + 0.5f * y[1] + 0.25f * y[2] + 0.125f * y[3];
+  m[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+  m[5] = y[3];
+}
+// G^T (3x6) applied to a 6-vector: the filter gradient's back transform  dg = G^T dU G
+__device__ __forceinline__ void gt3(const float (&u)[6], float (&r)[3]) {
+  r[0] = u[0] + (u[1] - u[2]) * (1.f / 3.f) + (u[4] - 16.f * u[3]) * (1.f / 15.f);
+  r[1] = (u[1] + u[2]) * (1.f / 3.f) - (8.f * u[3] + 2.f * u[4]) * (1.f / 15.f);
+  r[2] = (u[1] - u[2]) * (1.f / 3.f) + (4.f * u[4] - 4.f * u[3]) * (1.f / 15.f) + u[5];
+}
+
 // ---- filter: U[p][k][c] = (G g G^T)[xi][nu] --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 wino44_filter_k(int K, int C, const float* __restrict__ g, float* __restrict__ U) {
@@ -78,6 +94,74 @@ wino44_filter_k(int K, int C, const float* __restrict__ g, float* __restrict__ U
     g3(t[a], u);
 #pragma unroll
     for (int b = 0; b < 6; ++b) U[(size_t)(a * 6 + b) * ps + (size_t)k * C + c] = u[b];
+  }
+}
+
+// dg[k][r][s][c] (+)= (G^T dU G)[r][s]
+__global__ void __launch_bounds__(256)
+wino44_dfilter_k(int K, int C, const float* __restrict__ dU, float* __restrict__ dg, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)K * C) return;
+  const int k = (int)(idx / C), c = (int)(idx - (int64_t)k * C);
+  const size_t ps = (size_t)K * C;
+  float t[3][6];                                   // G^T dU : per transformed column b
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    float col[6], r[3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) col[a] = dU[(size_t)(a * 6 + b) * ps + (size_t)k * C + c];
+    gt3(col, r);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) t[q][b] = r[q];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float d[3];
+    gt3(t[r], d);
+    float* o = dg + ((size_t)k * 9 + r * 3) * C + c;
+    if (accumulate) { o[0] += d[0]; o[C] += d[1]; o[2 * (size_t)C] += d[2]; }
+    else { o[0] = d[0]; o[C] = d[1]; o[2 * (size_t)C] = d[2]; }
+  }
+}
+
+// ---- weight gradient operand: dM[p][t][k] = (A dY A^T)[xi][nu] over the 4x4 OUTPUT tile t (rows 4i .. 4i+3; zero past the edge of the map) ------------------------
+// One thread = one tile x 4 channels, lanes along the channels.  dU_p = dM_p^T . V_p with the V the forward's input transform left (ssv_gemm_batched_wgrad, 36 products).
+__global__ void __launch_bounds__(256)
+wino44_dy_k(int N, int H, int W, int K, int th, int tw, const float* __restrict__ dy, float* __restrict__ dM, int64_t T) {
+  const int K4 = K >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * K4) return;
+  const int64_t t = idx / K4;
+  const int k = (int)(idx - t * K4) * 4;
+  const int n = (int)(t / (th * tw));
+  const int r = (int)(t - (int64_t)n * th * tw);
+  const int i = r / tw, j = r - i * tw;
+  f32x4 y[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ho = 4 * i + a, wo = 4 * j + b;
+      y[a][b] = (ho < H && wo < W) ? ld4(dy + (((size_t)n * H + ho) * W + wo) * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  f32x4 s[6][4];                                   // A y, column by column
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    f32x4 col[4], m[6];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) col[a] = y[a][b];
+    a6(col, m);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) s[a][b] = m[a];
+  }
+  const size_t ps = (size_t)T * K;
+  float* o = dM + (size_t)t * K + k;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    f32x4 m[6];
+    a6(s[a], m);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) st4(o + (size_t)(a * 6 + b) * ps, m[b]);
   }
 }
 
@@ -329,6 +413,29 @@ extern "C" int ssv_wino44_filter_transform(int32_t K, int32_t C, const float* w,
   ProfScope ps(SSV_PROF_MISC, s);
   hipLaunchKernelGGL(wino44_filter_k, dim3((unsigned)cdiv64((int64_t)K * C, 256)), dim3(256), 0, s, K, C, w, U);
   SSV_CHECK_LAUNCH("ssv_wino44_filter_transform");
+  return SSV_OK;
+}
+
+// dw (+)= G^T dU G for dU [36][K][C] (the 36 products of ssv_gemm_batched_wgrad on V and the transformed output gradient)
+extern "C" int ssv_wino44_filter_grad(int32_t K, int32_t C, const float* dU, float* dw, int accumulate, void* stream) {
+  SSV_REQUIRE(K > 0 && C > 0 && dU && dw, "ssv_wino44_filter_grad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_WGRAD, s);
+  hipLaunchKernelGGL(wino44_dfilter_k, dim3((unsigned)cdiv64((int64_t)K * C, 256)), dim3(256), 0, s, K, C, dU, dw, accumulate);
+  SSV_CHECK_LAUNCH("ssv_wino44_filter_grad");
+  return SSV_OK;
+}
+
+// dM [36][ssv_wino44_tiles][K] = A dY A^T per 4x4 output tile: the weight gradient's second operand
+extern "C" int ssv_wino44_dy_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, float* dM, void* stream) {
+  if (int rc = check_shape44(N, H, W, K, "ssv_wino44_dy_transform")) return rc;
+  SSV_REQUIRE(dy && dM && (((uintptr_t)dy | (uintptr_t)dM) & 15) == 0, "ssv_wino44_dy_transform: null or unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_WGRAD, s);
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  const int64_t T = (int64_t)N * th * tw;
+  hipLaunchKernelGGL(wino44_dy_k, dim3((unsigned)cdiv64(T * (K / 4), 256)), dim3(256), 0, s, N, H, W, K, th, tw, dy, dM, T);
+  SSV_CHECK_LAUNCH("ssv_wino44_dy_transform");
   return SSV_OK;
 }
 

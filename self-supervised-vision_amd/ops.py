@@ -1077,6 +1077,13 @@ WINOGRAD44_MAX_CHANNELS = 512
 # ... and only for launches with enough tiles: 36 small GEMMs of a few row tiles each buy nothing over 16 (B = 64: 7x7 x 512, 256 tiles: 0.109 vs 0.116 ms) while
 # the larger rounding error stays - small batches keep F(2x2)
 WINOGRAD44_MIN_TILES = 1024
+# The weight gradient of a layer whose FORWARD ran F(4x4) takes F(4x4) too (round 5): its operand is the V the forward's input transform wrote anyway (no second,
+# F(2x2) transformed input), 36 products over a quarter of the tiles, a 2.25x dY transform.  Error against fp64 1.1 - 1.6e-6 relative (bar 2e-6: a weight gradient's
+# error never crosses a ReLU gate).  SSV_WINOGRAD44_WGRAD=0: those layers keep the F(2x2) operand and weight gradient (round 4's selection).
+WINOGRAD44_WGRAD = os.environ.get("SSV_WINOGRAD44_WGRAD", "1") == "1"
+# ... with BLOCKED accumulation of its 36 transformed-domain sums: fp32 chains of at most this many tiles, the chunks folded in fp64 (ssv_gemm_batched_wgrad_blocked);
+# 0 = the plain split (diagnostic: how the error grows with the chain length)
+WINOGRAD44_WGRAD_CHUNK = int(os.environ.get("SSV_WINOGRAD44_WGRAD_CHUNK", "256"))
 
 
 # Which Winograd form each product took (launch counts by name), recorded while DISPATCH is a dict: bench.py's parity gate prints it so that the line
@@ -1130,9 +1137,10 @@ def _wino44_filter(w, wshape, transposed=False):
 
 
 def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
-    """wino_conv2d_fwd through F(4x4, 3x3): 36 transformed-domain GEMMs over a quarter of the tiles.  ``keep_v``: the input transform also leaves the
-    F(2x2) transformed input (the weight gradient's operand - wino_conv2d_wgrad takes it unchanged).  Statistics partials: one per row of tiles
-    (H % 4 == 0) or per image."""
+    """wino_conv2d_fwd through F(4x4, 3x3): 36 transformed-domain GEMMs over a quarter of the tiles.  ``keep_v``: the weight gradient's operand comes back as
+    the third result - the transformed input V [36][T][C] itself (WINOGRAD44_WGRAD: the weight gradient runs F(4x4) too), or the F(2x2) transformed input
+    [16][T2][C] the input transform then also leaves (wino_conv2d_wgrad tells them apart by the leading dimension).  Statistics partials: one per row of
+    tiles (H % 4 == 0) or per image."""
     _note("wino44_fwd")
     _lib._dev(x, w)
     w, wshape = _ohwi(w)
@@ -1143,8 +1151,10 @@ def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     u = _wino44_filter(w, wshape)
     sc, sh = in_affine if in_affine is not None else (None, None)
     v = torch.empty((36, t, c), dtype=torch.float32, device=x.device)
-    v2 = torch.empty((16, int(lib.ssv_wino_tiles(n, h, w_)), c), dtype=torch.float32, device=x.device) if keep_v else None
+    v2 = torch.empty((16, int(lib.ssv_wino_tiles(n, h, w_)), c), dtype=torch.float32, device=x.device) if (keep_v and not WINOGRAD44_WGRAD) else None
     call("ssv_wino44_input_transform", n, h, w_, c, ptr(x), ptr(sc), ptr(sh), ptr(v), ptr(v2), stream())
+    if keep_v and WINOGRAD44_WGRAD:
+        v2 = v
     m = torch.empty((36, t, k), dtype=torch.float32, device=x.device)
     call("ssv_gemm_batched", 36, t, c, k, ptr(v), ptr(u), ptr(m), stream())
     y = _empty((n, h, w_, k), x)
@@ -1238,7 +1248,9 @@ def wino_conv2d_dgrad(dy, w, gate=None):
 
 
 def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
-    """dw (+)= weight gradient of the 3x3 convolution whose transformed input V was kept by wino_conv2d_fwd."""
+    """dw (+)= weight gradient of the 3x3 convolution whose transformed input V was kept by wino_conv2d_fwd ([16][T2][C]: F(2x2); [36][T][C]: F(4x4))."""
+    if v.shape[0] == 36:
+        return wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate)
     _note("wino22_wgrad")
     _lib._dev(v, dy, dw)
     _, wshape = _ohwi(w_like)
@@ -1252,6 +1264,30 @@ def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     du = torch.empty((16, k, c), dtype=torch.float32, device=dy.device)
     call("ssv_gemm_batched_wgrad", 16, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
     call("ssv_wino_filter_grad", k, c, ptr(du), ptr(dw), int(accumulate), stream())
+    return dw
+
+
+def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
+    """wino_conv2d_wgrad through F(4x4, 3x3): dM = A dY A^T, 36 products dU_p = dM_p^T V_p over the tiles, dw (+)= G^T dU G."""
+    _note("wino44_wgrad")
+    _lib._dev(v, dy, dw)
+    _, wshape = _ohwi(w_like)
+    n, h, w_, k = dy.shape
+    c = wshape[1]
+    lib = _lib.load()
+    t = int(lib.ssv_wino44_tiles(n, h, w_))
+    if tuple(v.shape) != (36, t, c):
+        raise _lib.SsvError(f"wino44_conv2d_wgrad: transformed input {tuple(v.shape)} does not belong to a {n}x{h}x{w_}x{c} activation")
+    dm = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
+    call("ssv_wino44_dy_transform", n, h, w_, k, ptr(dy), ptr(dm), stream())
+    du = torch.empty((36, k, c), dtype=torch.float32, device=dy.device)
+    if WINOGRAD44_WGRAD_CHUNK > 0:
+        ws = workspace.get(lib.ssv_gemm_batched_wgrad_blocked_workspace_bytes(36, t, c, k, WINOGRAD44_WGRAD_CHUNK), dy.device)
+        call("ssv_gemm_batched_wgrad_blocked", 36, t, c, k, ptr(v), ptr(dm), ptr(du), WINOGRAD44_WGRAD_CHUNK, ptr(ws), ws.numel(), stream())
+    else:
+        ws = workspace.get(lib.ssv_gemm_batched_wgrad_workspace_bytes(36, t, c, k), dy.device)
+        call("ssv_gemm_batched_wgrad", 36, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
+    call("ssv_wino44_filter_grad", k, c, ptr(du), ptr(dw), int(accumulate), stream())
     return dw
 
 

@@ -45,7 +45,11 @@ def test_forward_statistics_and_the_f22_operand_it_leaves(dev, n, h, w_, c, k, a
     ref = F.conv2d(a.permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
     xd, wd = x.to(dev), w.contiguous(memory_format=torch.channels_last).to(dev)
     affd = (aff[0].to(dev), aff[1].to(dev)) if affine else None
-    y, part, v2 = ops.wino44_conv2d_fwd(xd, wd, in_affine=affd, want_stats=True, keep_v=True)
+    prev44, ops.WINOGRAD44_WGRAD = ops.WINOGRAD44_WGRAD, False            # round 4's selection: the forward leaves the F(2x2) operand for the weight gradient
+    try:
+        y, part, v2 = ops.wino44_conv2d_fwd(xd, wd, in_affine=affd, want_stats=True, keep_v=True)
+    finally:
+        ops.WINOGRAD44_WGRAD = prev44
     assert rel(y, ref) < (4e-6 if max(c, k) <= 512 else 8e-6), rel(y, ref)        # beyond 512 channels (not dispatched: ops.WINOGRAD44_MAX_CHANNELS) the sums are longer
     np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), rtol=1e-4, atol=4e-5 * float(ref.abs().max()))
     # statistics partials: one per row of tiles (4 x W pixels) when H % 4 == 0, else one per image - equal groups either way
@@ -74,6 +78,52 @@ def test_forward_statistics_and_the_f22_operand_it_leaves(dev, n, h, w_, c, k, a
     # without the statistics and without the kept operand: the same y
     y2, none, nov = ops.wino44_conv2d_fwd(xd, wd, in_affine=affd, want_stats=False, keep_v=False)
     assert none is None and nov is None and torch.equal(y2, y)
+    # the shipped selection (ops.WINOGRAD44_WGRAD): the kept operand is F(4x4)'s own transformed input, the weight gradient runs through F(4x4) on it
+    assert ops.WINOGRAD44_WGRAD
+    y3, _, v4 = ops.wino44_conv2d_fwd(xd, wd, in_affine=affd, want_stats=False, keep_v=True)
+    assert torch.equal(y3, y) and tuple(v4.shape) == (36, n * ((h + 3) // 4) * ((w_ + 3) // 4), c)
+    dw4 = torch.zeros_like(wd)
+    ops.wino_conv2d_wgrad(v4, dy.to(dev), wd, dw4, accumulate=False)                 # told apart by the leading dimension
+    assert rel(dw4, wr.grad) < (4e-6 if max(c, k) <= 512 else 8e-6), rel(dw4, wr.grad)
+    ops.wino_conv2d_wgrad(v4, dy.to(dev), wd, dw4, accumulate=True)
+    assert rel(dw4, 2 * wr.grad) < (4e-6 if max(c, k) <= 512 else 8e-6)
+    with pytest.raises(_lib.SsvError):
+        ops.wino44_conv2d_wgrad(v4[:, :-1], dy.to(dev), wd, dw4)
+
+
+def _wgrad64(a, dy):
+    """fp64 weight gradient [K][C][3][3] of a 3x3 / padding 1 convolution from NHWC device operands: nine fp64 GEMMs (test infrastructure)."""
+    n, h, w_, c = a.shape
+    k = dy.shape[3]
+    ap = torch.zeros((n, h + 2, w_ + 2, c), dtype=torch.float64, device=a.device)
+    ap[:, 1:-1, 1:-1] = a.double()
+    d2 = dy.double().reshape(-1, k)
+    out = torch.empty((k, c, 3, 3), dtype=torch.float64, device=a.device)
+    for r in range(3):
+        for s in range(3):
+            out[:, :, r, s] = d2.t() @ ap[:, r:r + h, s:s + w_].reshape(-1, c)
+    return out
+
+
+@pytest.mark.parametrize("h,c", [(28, 128), (14, 256), (7, 512)])
+def test_weight_gradient_through_f44_at_batch_512_within_2e6_of_fp64(dev, h, c):
+    """The bar the F(4x4) weight gradient ships under (round-4 review): relative l2 error of dW against fp64 <= 2e-6 on the three ResNet-50 Winograd shapes AT THE
+    BENCH BATCH (the transformed-domain sums run over 25,088 / 8,192 / 2,048 tiles), the tolerance the F(2x2) weight gradient is held to above.  Operand: a
+    BatchNorm + ReLU output (non-negative, as in the network), formed on load by the forward's input transform."""
+    from ssv_amd import ops
+    n = 512
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, h, h, c, device=dev, generator=g)
+    w = (torch.randn(c, c, 3, 3, device=dev, generator=g) * (2.0 / (9 * c)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, h, h, c, device=dev, generator=g)
+    aff = (torch.rand(c, device=dev, generator=g) + 0.5, torch.randn(c, device=dev, generator=g) * 0.1)
+    ref = _wgrad64(torch.relu(x * aff[0] + aff[1]), dy)
+    _, _, v4 = ops.wino44_conv2d_fwd(x, w, in_affine=aff, want_stats=False, keep_v=True)
+    assert v4.shape[0] == 36
+    dw = torch.zeros_like(w)
+    ops.wino_conv2d_wgrad(v4, dy, w, dw, accumulate=False)
+    err = float((dw.double() - ref).norm() / ref.norm())
+    assert err <= 2e-6, err
 
 
 @pytest.mark.parametrize("n,h,w_,c,k", SHAPES)
