@@ -231,11 +231,13 @@ int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const fl
 size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K);
 int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x /*[batch][rows][C]*/, const float* dy /*[batch][rows][K]*/,
                            float* dw /*[batch][K][C]*/, void* ws, size_t ws_bytes, void* stream);
-/* The same products with BLOCKED accumulation: no fp32 accumulator chain runs over more than max_chunk_rows (>= 32) rows, the row chunks' slabs are folded in fp64
- * in fixed order.  For sums whose rounding error must not grow with their length: the Winograd F(4x4) weight gradient (ops.wino44_conv2d_wgrad). */
+/* The same products with BLOCKED accumulation, for sums whose rounding error must not grow with their length (the Winograd F(4x4) weight gradient,
+ * ops.wino44_conv2d_wgrad).  Two independent means: max_chunk_rows (0 or >= 32) caps the rows one workgroup accumulates (more, shorter row chunks); flush_rows
+ * (0 or 128) makes the kernel add its MFMA accumulators into a second register set every 128 rows (no fp32 chain of products longer than that, whatever the chunk).
+ * Either way the chunks' slabs are folded in fp64, in fixed order. */
 size_t ssv_gemm_batched_wgrad_blocked_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K, int32_t max_chunk_rows);
 int ssv_gemm_batched_wgrad_blocked(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
-                                   int32_t max_chunk_rows, void* ws, size_t ws_bytes, void* stream);
+                                   int32_t max_chunk_rows, int32_t flush_rows, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm (training mode, batch statistics) over rows of an [M][C] matrix ------------
  * replaces nn.BatchNorm2d / nn.BatchNorm1d (+ReLU, + residual add) at networks/resnet.py:39-44,

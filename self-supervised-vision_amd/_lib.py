@@ -103,7 +103,7 @@ SIGNATURES = {
     "ssv_gemm_batched_wgrad_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "ssv_gemm_batched_wgrad": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_gemm_batched_wgrad_blocked_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32, _i32]),
-    "ssv_gemm_batched_wgrad_blocked": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "ssv_gemm_batched_wgrad_blocked": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "ssv_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ssv_bn_train_fwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_bn_train_bwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),

@@ -302,10 +302,15 @@ __device__ __forceinline__ void mma_frags(const Frags<TM, TN>& f, f32x16 (&acc)[
 // the tile is stored to LDS.  (Measured: issuing it under the last substep's MFMAs instead is SLOWER, 254.3 -> 256.0 ms per step - its
 // s_waitcnt for the prefetched loads then stalls that wave's MFMA stream one substep early.)
 struct NoXform { __device__ __forceinline__ void operator()() const {} };
-template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int NLD, class LoadTile, class StoreTile, class Xform = NoXform>
+// FLUSH > 0 (the blocked weight gradient, ssv_gemm_batched_wgrad_blocked): two-level accumulation - every FLUSH k-tiles the MFMA accumulators are added into a
+// second set and cleared, so no fp32 chain of products is longer than FLUSH * BK rows (a chain's rounding error grows with its length); the second set sums
+// nkt / FLUSH block results.  Costs TM * TN * 16 registers and as many v_add_f32 per FLUSH k-tiles.
+template <int TM, int TN, bool A_ROWK, bool B_ROWK, int LDA, int LDB, int BK, int NLD, int FLUSH = 0, class LoadTile, class StoreTile, class Xform = NoXform>
 __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs, int wr0, int wc0, int lane,
                                        f32x16 (&acc)[TM][TN], LoadTile&& load_tile, StoreTile&& store_tile, Xform&& xform_tile = NoXform()) {
   if (nkt <= 0) return;
+  f32x16 hi[FLUSH > 0 ? TM : 1][FLUSH > 0 ? TN : 1];
+  if constexpr (FLUSH > 0) zero_acc<TM, TN>(hi);
   constexpr int NS = BK / 8;
   constexpr int NM = 4 * TM * TN;            // MFMAs per substep
   load_tile();
@@ -355,8 +360,26 @@ __device__ __forceinline__ void k_loop(int nkt, const float* As, const float* Bs
         mma_frags<TM, TN>(fr, acc);
       }
       if constexpr (SSV_EXP_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+      if constexpr (FLUSH > 0) {
+        if ((kt + 1) % FLUSH == 0) {               // uniform
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              hi[tm][tn] += acc[tm][tn];
+#pragma unroll
+              for (int j = 0; j < 16; ++j) acc[tm][tn][j] = 0.f;
+            }
+        }
+      }
       __syncthreads();
       if (kt + 1 < nkt) { xform_tile(); store_tile(0); __syncthreads(); }
+    }
+    if constexpr (FLUSH > 0) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = hi[tm][tn] + acc[tm][tn];
     }
 #endif
 #ifdef SSV_STAMP
@@ -1380,7 +1403,8 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // DYF (LIN gather only): the dY operand is formed on load from (g, x of the BatchNorm behind this convolution, coefficients) - see conv_fwd_k.
 // BIAS (LIN gather): the workgroups of column tile 0 also sum the dY rows they stage - the bias gradient's column sums, one partial row per split
 //       (p.aux_out [nsplit][K]), reduced with the weight gradient's slabs in the same fixed order: the stand-alone column-sum pass over dY disappears.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false, bool BIAS = false>
+// FLUSH: two-level accumulation, see k_loop (the blocked batched weight gradient only).
+template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false, bool BIAS = false, int FLUSH = 0>
 __global__ void __launch_bounds__(256)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -1608,7 +1632,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
       else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
-  k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0)>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
+  k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0), FLUSH>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
 
   if constexpr (BIAS) {
     static_assert(STAGE >= (256 / (BM / 4)) * BM, "the bias partials are folded through the stage buffer");
@@ -2722,7 +2746,7 @@ extern "C" size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t 
   return (size_t)batch * w.nsplit * K * C * sizeof(float);
 }
 extern "C" size_t ssv_gemm_batched_wgrad_blocked_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K, int32_t max_chunk_rows) {
-  if (batch <= 0 || rows <= 0 || C <= 0 || K <= 0 || max_chunk_rows < 32) return 0;
+  if (batch <= 0 || rows <= 0 || C <= 0 || K <= 0 || (max_chunk_rows != 0 && max_chunk_rows < 32)) return 0;
   const BatchedWgradPlan w = plan_batched_wgrad(batch, rows, C, K, max_chunk_rows);
   return (size_t)batch * w.nsplit * K * C * sizeof(float);
 }
@@ -2730,7 +2754,7 @@ extern "C" size_t ssv_gemm_batched_wgrad_blocked_workspace_bytes(int32_t batch, 
 // dw[b] [K][C] = dy[b]^T [K][rows] . x[b] [rows][C] for b < batch: one launch of the weight-gradient kernel (split over the rows, fixed-order reduce).
 // max_chunk > 0 (ssv_gemm_batched_wgrad_blocked): BLOCKED accumulation - no fp32 accumulator chain runs over more than max_chunk rows, and the slabs are
 // folded in fp64 (still fixed order): the error of a long transformed-domain sum (Winograd F(4x4): 25,088 tiles at 28x28 / batch 512) stops growing with its length.
-static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw, int max_chunk,
+static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw, int max_chunk, int flush_rows,
                               void* ws, size_t ws_bytes, void* stream, const char* who) {
   SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "%s: bad shape", who);
   SSV_REQUIRE(C % 4 == 0 && K % 4 == 0, "%s: needs C %% 4 == 0 and K %% 4 == 0 (got C=%d K=%d)", who, C, K);
@@ -2747,13 +2771,18 @@ static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K,
   float* part = (float*)ws;
   SSV_REQUIRE((int64_t)wp.tiles * wp.nsplit < (1ll << 31), "%s: too many workgroups", who);
   const dim3 grid((unsigned)(wp.tiles * wp.nsplit), (unsigned)batch);
-#define BWG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles)
-  if (wp.bm == 128) { if (wp.bn == 64) BWG(128, 64, 2, 2); else BWG(128, 128, 2, 2); }
-  else              { if (wp.bn == 64) BWG(64, 64, 2, 2); else BWG(64, 128, 1, 4); }
+#define BWG(BM_, BN_, WM_, WN_, FL_) hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false, false, false, FL_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles)
+  if (flush_rows > 0) {                       // two-level accumulation: blocks of 4 k-tiles = 128 rows
+    if (wp.bm == 128) { if (wp.bn == 64) BWG(128, 64, 2, 2, 4); else BWG(128, 128, 2, 2, 4); }
+    else              { if (wp.bn == 64) BWG(64, 64, 2, 2, 4); else BWG(64, 128, 1, 4, 4); }
+  } else {
+    if (wp.bm == 128) { if (wp.bn == 64) BWG(128, 64, 2, 2, 0); else BWG(128, 128, 2, 2, 0); }
+    else              { if (wp.bn == 64) BWG(64, 64, 2, 2, 0); else BWG(64, 128, 1, 4, 0); }
+  }
 #undef BWG
   SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(partial)");
   const int64_t n = (int64_t)K * C;
-  if (max_chunk > 0) hipLaunchKernelGGL(wgrad_reduce64_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
+  if (max_chunk > 0 || flush_rows > 0) hipLaunchKernelGGL(wgrad_reduce64_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
   else hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
   SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(reduce)");
   return SSV_OK;
@@ -2761,13 +2790,15 @@ static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K,
 
 extern "C" int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
                                       void* ws, size_t ws_bytes, void* stream) {
-  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, 0, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad");
+  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, 0, 0, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad");
 }
 
 extern "C" int ssv_gemm_batched_wgrad_blocked(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
-                                              int32_t max_chunk_rows, void* ws, size_t ws_bytes, void* stream) {
-  SSV_REQUIRE(max_chunk_rows >= 32, "ssv_gemm_batched_wgrad_blocked: max_chunk_rows must be >= 32 (got %d)", max_chunk_rows);
-  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, max_chunk_rows, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad_blocked");
+                                              int32_t max_chunk_rows, int32_t flush_rows, void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(max_chunk_rows == 0 || max_chunk_rows >= 32, "ssv_gemm_batched_wgrad_blocked: max_chunk_rows must be 0 (the plain split) or >= 32 (got %d)", max_chunk_rows);
+  SSV_REQUIRE(flush_rows == 0 || flush_rows == 128, "ssv_gemm_batched_wgrad_blocked: flush_rows must be 0 or 128 (got %d)", flush_rows);
+  SSV_REQUIRE(max_chunk_rows > 0 || flush_rows > 0, "ssv_gemm_batched_wgrad_blocked: nothing blocked - use ssv_gemm_batched_wgrad");
+  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, max_chunk_rows, flush_rows, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad_blocked");
 }
 
 #ifdef SSV_STAMP

@@ -1070,6 +1070,10 @@ WINOGRAD44 = os.environ.get("SSV_WINOGRAD44", "1") == "1"
 # inputs (its own and the weight gradient's), so it switches only when the work halves; the data gradient already wins at 0.735 (tools/probe/wino44_stages.py,
 # profiles/r04_probe_wino44_stages.txt: 14x14 forward 1.07x, data gradient 1.28x; go / no-go bar 1.25x).
 WINOGRAD44_MAX_RATIO_FWD, WINOGRAD44_MAX_RATIO_DGRAD = 0.6, 0.75
+# Round 5: with the weight gradient on F(4x4) too (WINOGRAD44_WGRAD) the forward no longer writes the second, F(2x2) transformed input - its input transform drops from
+# 0.209 to 0.133 ms on 14x14 x 256 - and the weight gradient it feeds is 0.485 instead of 0.548 ms: the forward then switches at the data gradient's ratio
+# (14x14: 0.70 -> 0.57 ms forward; profiles/r05_probe_winograd44_wgrad.txt, r04_probe_wino44_stages.txt).
+WINOGRAD44_MAX_RATIO_FWD_NO_V2 = float(os.environ.get("SSV_WINOGRAD44_FWD_RATIO", "0.75"))
 # ... and only up to the contraction length the numerics bar was measured for: the transformed-domain sums run over the channels and F(4x4)'s error grows with
 # their count like any fp32 sum, but from a 3x higher base - 128 / 256 / 512 channels: 2.97x / 2.84x / 2.85x the direct kernel's error against fp64 (bar: 3x),
 # 1024 channels (wide_resnet's layer4): 3.8x.  Wider layers stay on F(2x2).
@@ -1083,7 +1087,9 @@ WINOGRAD44_MIN_TILES = 1024
 WINOGRAD44_WGRAD = os.environ.get("SSV_WINOGRAD44_WGRAD", "1") == "1"
 # ... with BLOCKED accumulation of its 36 transformed-domain sums: fp32 chains of at most this many tiles, the chunks folded in fp64 (ssv_gemm_batched_wgrad_blocked);
 # 0 = the plain split (diagnostic: how the error grows with the chain length)
-WINOGRAD44_WGRAD_CHUNK = int(os.environ.get("SSV_WINOGRAD44_WGRAD_CHUNK", "256"))
+WINOGRAD44_WGRAD_CHUNK = int(os.environ.get("SSV_WINOGRAD44_WGRAD_CHUNK", "512"))
+# ... or / and inside the kernel: the MFMA accumulators flushed into a second register set every 128 tiles (0 = off)
+WINOGRAD44_WGRAD_FLUSH = int(os.environ.get("SSV_WINOGRAD44_WGRAD_FLUSH", "128"))
 
 
 # Which Winograd form each product took (launch counts by name), recorded while DISPATCH is a dict: bench.py's parity gate prints it so that the line
@@ -1194,7 +1200,7 @@ def wino44_conv2d_dgrad(dy, w, gate=None):
 def wino_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     """y = conv3x3(act(x), w) (stride 1, padding 1) through F(2x2, 3x3).  Returns (y, (pmean, pm2) | None, V | None): the statistics
     partials are one per 16 tiles = 64 output rows (needs even H, W); V is the transformed input, kept for the weight gradient."""
-    if _use_wino44(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], WINOGRAD44_MAX_RATIO_FWD):
+    if _use_wino44(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], WINOGRAD44_MAX_RATIO_FWD_NO_V2 if WINOGRAD44_WGRAD else WINOGRAD44_MAX_RATIO_FWD):
         return wino44_conv2d_fwd(x, w, in_affine, want_stats, keep_v)
     _note("wino22_fwd")
     _lib._dev(x, w)
@@ -1281,9 +1287,9 @@ def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     dm = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
     call("ssv_wino44_dy_transform", n, h, w_, k, ptr(dy), ptr(dm), stream())
     du = torch.empty((36, k, c), dtype=torch.float32, device=dy.device)
-    if WINOGRAD44_WGRAD_CHUNK > 0:
+    if WINOGRAD44_WGRAD_CHUNK > 0 or WINOGRAD44_WGRAD_FLUSH > 0:
         ws = workspace.get(lib.ssv_gemm_batched_wgrad_blocked_workspace_bytes(36, t, c, k, WINOGRAD44_WGRAD_CHUNK), dy.device)
-        call("ssv_gemm_batched_wgrad_blocked", 36, t, c, k, ptr(v), ptr(dm), ptr(du), WINOGRAD44_WGRAD_CHUNK, ptr(ws), ws.numel(), stream())
+        call("ssv_gemm_batched_wgrad_blocked", 36, t, c, k, ptr(v), ptr(dm), ptr(du), WINOGRAD44_WGRAD_CHUNK, WINOGRAD44_WGRAD_FLUSH, ptr(ws), ws.numel(), stream())
     else:
         ws = workspace.get(lib.ssv_gemm_batched_wgrad_workspace_bytes(36, t, c, k), dy.device)
         call("ssv_gemm_batched_wgrad", 36, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())

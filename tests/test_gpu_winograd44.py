@@ -158,10 +158,12 @@ def test_data_gradient_with_the_relu_gate_epilogue(dev, n, h, w_, c, k):
 
 
 def test_which_product_takes_f44(dev):
-    """Per product, by the transformed-domain work F(4x4) leaves (36 x tiles of 4 against 16 x tiles of 2): 28x28 and 7x7 (0.5625) switch forward and data gradient,
-    14x14 (0.735: F(2x2) tiles it exactly) only the data gradient; SSV_WINOGRAD44=0 / ops.WINOGRAD44 = False restores F(2x2) everywhere."""
+    """Per product, by the transformed-domain work F(4x4) leaves (36 x tiles of 4 against 16 x tiles of 2): 28x28 and 7x7 (0.5625) switch forward and data gradient;
+    14x14 (0.735: F(2x2) tiles it exactly) the data gradient and - since the weight gradient runs F(4x4) on the forward's own transformed input (ops.WINOGRAD44_WGRAD,
+    no second operand to write) - the forward as well; with round 4's selection (WINOGRAD44_WGRAD off) its forward stays on F(2x2).
+    SSV_WINOGRAD44=0 / ops.WINOGRAD44 = False restores F(2x2) everywhere."""
     from ssv_amd import ops
-    assert ops.WINOGRAD44
+    assert ops.WINOGRAD44 and ops.WINOGRAD44_WGRAD
     assert abs(ops._wino44_ratio(28, 28) - 0.5625) < 1e-9 and abs(ops._wino44_ratio(7, 7) - 0.5625) < 1e-9 and abs(ops._wino44_ratio(14, 14) - 36 * 16 / (16 * 49)) < 1e-9
     calls = {"f": 0, "d": 0}
     inner_f, inner_d = ops.wino44_conv2d_fwd, ops.wino44_conv2d_dgrad
@@ -175,13 +177,20 @@ def test_which_product_takes_f44(dev):
         return inner_d(*a, **k)
     ops.wino44_conv2d_fwd, ops.wino44_conv2d_dgrad = cf, cd
     try:
-        for hw, ch, f44, d44 in ((28, 128, 1, 1), (14, 256, 0, 1), (7, 512, 1, 1)):
+        for hw, ch, f44, d44, f44_r4 in ((28, 128, 1, 1, 1), (14, 256, 1, 1, 0), (7, 512, 1, 1, 1)):
             x = seeded_randn(5, 1024 // ((hw + 3) // 4) ** 2 + 1, hw, hw, ch).to(dev)         # just past ops.WINOGRAD44_MIN_TILES tiles
             w = (seeded_randn(6, ch, ch, 3, 3) * 0.02).contiguous(memory_format=torch.channels_last).to(dev)
             calls.update(f=0, d=0)
-            ops.wino_conv2d_fwd(x, w, keep_v=True)
+            v = ops.wino_conv2d_fwd(x, w, keep_v=True)[2]
             ops.wino_conv2d_dgrad(x, w)
-            assert (calls["f"], calls["d"]) == (f44, d44), (hw, calls)
+            assert (calls["f"], calls["d"]) == (f44, d44) and v.shape[0] == (36 if f44 else 16), (hw, calls)
+            ops.WINOGRAD44_WGRAD = False
+            try:
+                calls.update(f=0, d=0)
+                v = ops.wino_conv2d_fwd(x, w, keep_v=True)[2]
+                assert calls["f"] == f44_r4 and v.shape[0] == 16, (hw, calls)
+            finally:
+                ops.WINOGRAD44_WGRAD = True
         prev, ops.WINOGRAD44 = ops.WINOGRAD44, False
         try:
             calls.update(f=0, d=0)

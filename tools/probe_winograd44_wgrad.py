@@ -14,7 +14,7 @@ from ssv_amd import ops  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 REP = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
-CHUNK0 = ops.WINOGRAD44_WGRAD_CHUNK
+CHUNK0, FLUSH0 = ops.WINOGRAD44_WGRAD_CHUNK, ops.WINOGRAD44_WGRAD_FLUSH
 
 
 def timeit(fn):
@@ -76,7 +76,11 @@ for name, H, Cc in (("p128.1.conv2 28x28x128", 28, 128), ("p256.1.conv2 14x14x25
     for chunk in (0, 2048, 1024, 512, 256, 128):
         ops.WINOGRAD44_WGRAD_CHUNK = chunk
         sweep.append((chunk, timeit(lambda: ops.wino44_conv2d_wgrad(v4, dy, w, dw, accumulate=False)), rel(dw, ref)))
-    ops.WINOGRAD44_WGRAD_CHUNK = CHUNK0
+    ops.WINOGRAD44_WGRAD_FLUSH = 128
+    for chunk in (0, 2048, 1024, 512):
+        ops.WINOGRAD44_WGRAD_CHUNK = chunk
+        sweep.append((f"flush128+{chunk}", timeit(lambda: ops.wino44_conv2d_wgrad(v4, dy, w, dw, accumulate=False)), rel(dw, ref)))
+    ops.WINOGRAD44_WGRAD_CHUNK, ops.WINOGRAD44_WGRAD_FLUSH = CHUNK0, FLUSH0
     t_44 = timeit(lambda: ops.wino44_conv2d_wgrad(v4, dy, w, dw, accumulate=False))
     e_44 = rel(dw, ref)
     dm = torch.empty((36, t44, Cc), device=dev)
