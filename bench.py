@@ -382,8 +382,49 @@ def parity_gate_and_cpu_baseline(device, algo, tf, source, sample_ids, rows, bat
             ok = ok and (e_hip <= 1e-4 or e_hip <= 3 * e_cpu + 1e-5)
         else:
             ok = ok and dz <= 1e-4
+    if algo == "barlow":
+        gate["update_at_config_lr"] = update_check(device, algo, v1, v2)
+        ok = ok and gate["update_at_config_lr"]["pass"]
     gate["pass"] = bool(ok)
     return gate, base
+
+
+def update_check(device, algo, v1, v2):
+    """The UPDATE path at the config's own learning rate, gated apart from the trajectory (Barlow Twins' loss gate runs at config lr / 10^4, where three steps
+    barely move the weights): ONE step from the common initialisation on both sides - CPU oracle and HIP trainer, config lr, weight decay, Nesterov
+    momentum (first step: buf = g) - and the weight DELTA compared per tensor.  A delta is lr * (gradient + decay): its error is the gradient's, i.e.
+    ReLU-flip sized (1e-3 .. 1e-2 per tensor at batch 32) - the bar is that size class, median and worst; an optimizer that applied the wrong
+    learning rate, sign, decay or momentum rule would be O(1) off."""
+    import oracle
+    base = BENCH_CFG[algo]["optimizer"]
+    lr = 1e-12 + base["lr"] / 10
+    make = {"byol": lambda: oracle.BYOLOracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"], max_steps=1000 * 1000),
+            "barlow": lambda: oracle.BarlowOracle("resnet50", False, 4096, lr=lr, weight_decay=base["weight_decay"], normalize=True),
+            "simclr": lambda: oracle.SimCLROracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"])}[algo]
+    m = make()
+    before = oracle.snapshot(m)["params"]
+    m.train_step(v1.cpu().contiguous(), v2.cpu().contiguous(), **({"step": 0} if algo == "byol" else {}))
+    after = oracle.snapshot(m)["params"]
+    del m
+    hip_step, _ = build(device, algo)
+    arena = hip_step.trainer.optim.arena
+    start = [p.detach().float().cpu().clone() for p in arena.params]
+    hip_step({"aug_1": v1, "aug_2": v2})
+    torch.cuda.synchronize()
+    errs = []
+    for p, s0, b0, a0 in zip(arena.params, start, before, after):
+        d_cpu = (a0 - b0).double()
+        if float(d_cpu.norm()) < 1e-12:
+            continue
+        d_hip = (p.detach().float().cpu() - s0).double()
+        errs.append(float((d_hip - d_cpu).norm() / d_cpu.norm()))
+    del hip_step
+    torch.cuda.empty_cache()
+    errs.sort()
+    med, worst = errs[len(errs) // 2], errs[-1]
+    return {"workload": f"{algo}: one step at the config's learning rate (lr {lr:.3g}) from the common initialisation, weight delta per tensor, relative l2 vs the CPU oracle",
+            "tensors": len(errs), "delta_rel_l2_median": float(f"{med:.2e}"), "delta_rel_l2_worst": float(f"{worst:.2e}"),
+            "bar": "median <= 2e-2 and worst <= 0.3 (ReLU-flip size of a batch-32 gradient; a wrong update rule is O(1))", "pass": bool(med <= 2e-2 and worst <= 0.3)}
 
 
 def read_committed_counters(profiles_dir, fname):

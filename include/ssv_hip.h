@@ -181,6 +181,9 @@ int ssv_stem_conv_fwd(const ssv_conv_desc* d, const float* x /*[N][H][W][3]*/, c
  * (the rows-in-LDS kernel: M is a multiple of it).  pmean / pm2 hold ceil(M / that) rows of K floats. */
 int64_t ssv_stem_conv_fwd_stats_rows_per_group(const ssv_conv_desc* d);
 size_t ssv_stem_conv_wgrad_workspace_bytes(const ssv_conv_desc* d);
+/* Which kernel ssv_stem_conv_wgrad takes for this shape: whole output rows per workgroup of the rows-in-LDS kernel, 0 = the row-taps gather (tools/bench_conv.py labels
+ * its rows from this and from ssv_stem_conv_fwd_stats_rows_per_group != 64). */
+int64_t ssv_stem_conv_wgrad_rows_per_group(const ssv_conv_desc* d);
 int ssv_stem_conv_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dwrows, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Winograd F(2x2, 3x3) for stride-1 / padding-1 3x3 convolutions (csrc/winograd.hip) -------------------------------------

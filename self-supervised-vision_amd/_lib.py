@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSV_HIP_LIB") or os.path.join(_HERE, "csrc", "libssv_hip.so")   # override: diagnostic builds only
 
+ABI_VERSION = 110        # ssv_version() of the library this binding was written against (include/ssv_hip.h)
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc", "attn", "norm")
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "ssv_conv2d_wgrad_bias": (C.c_int, [_cd, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "ssv_stem_conv_fwd": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_stem_conv_fwd_stats_rows_per_group": (_i64, [_cd]),
+    "ssv_stem_conv_wgrad_rows_per_group": (_i64, [_cd]),
     "ssv_stem_conv_wgrad_workspace_bytes": (_sz, [_cd]),
     "ssv_stem_conv_wgrad": (C.c_int, [_cd, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_wino_tiles": (_i64, [_i32, _i32, _i32]),
@@ -191,6 +193,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    if lib.ssv_version() < ABI_VERSION:
+        raise SsvError(f"{LIB_PATH} is ABI version {lib.ssv_version()}, this package binds version {ABI_VERSION}: rebuild it (make -C {os.path.dirname(LIB_PATH)})")
     _lib = lib
     return lib
 

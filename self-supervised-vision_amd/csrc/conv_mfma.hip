@@ -2648,6 +2648,12 @@ extern "C" size_t ssv_stem_conv_wgrad_workspace_bytes(const ssv_conv_desc* d) {
   return gather > rows ? gather : rows;
 }
 
+// which kernel ssv_stem_conv_wgrad takes for this shape: output rows per workgroup of the rows-in-LDS kernel, or 0 = the row-taps gather (a count, not a status)
+extern "C" int64_t ssv_stem_conv_wgrad_rows_per_group(const ssv_conv_desc* d) {
+  if (!d || d->K <= 0 || d->R <= 0 || d->N <= 0) return 0;
+  return stem_rows_ok(d) ? (int64_t)stem_rows_plan(d).rows_per_wg : 0;
+}
+
 // dwrows [K][R][24] = weight gradient in the row-taps layout (columns >= 3 S are zero); overwritten, not accumulated
 extern "C" int ssv_stem_conv_wgrad(const ssv_conv_desc* d, const float* x, const float* dy, float* dwrows, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_desc(d, "ssv_stem_conv_wgrad")) return rc;

@@ -11,9 +11,11 @@ neither fork GPU workers nor replace itself (``os.exec*``) - on the MI355X pool 
 parent stays a thin waiter and ``spawn_ranks`` refuses to run once ``torch`` is in ``sys.modules``.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
+import time
 
 
 def in_process_group():
@@ -43,7 +45,43 @@ def spawn_ranks(script, argv, nproc, runner=None):
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, nproc))))
     env["SSV_LAUNCHED_BY"] = str(os.getpid())
     cmd = rank_command(script, list(argv), nproc)
-    return (runner or subprocess.call)(cmd, env=env)
+    return (runner or run_and_forward_signals)(cmd, env=env)
+
+
+def run_and_forward_signals(cmd, env=None, grace=10.0):
+    """``subprocess.call`` for a waiting parent that may itself be told to stop (``timeout -k 10 400 python bench.py --gpus N``, a harness watchdog): the
+    child - torch.distributed.run and, below it, the N ranks holding the GPUs and the rendezvous port - runs in its OWN session, and SIGTERM / SIGINT /
+    SIGHUP to the parent are passed on to that whole process group (TERM, then KILL after ``grace`` seconds), so no rank outlives the command that
+    started it.  Returns the child's exit code (128 + signal when it was stopped this way).  Still no exec, no HIP in this process."""
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    got = []                                                     # [(signal number, time it arrived)]
+
+    def signal_group(sig):
+        try:
+            os.killpg(child.pid, sig)                            # the session leader's pid is the group id
+        except ProcessLookupError:
+            pass
+
+    def forward(signum, _frame):
+        got.append((signum, time.monotonic()))
+        signal_group(signal.SIGTERM)
+
+    previous = {s: signal.signal(s, forward) for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    try:
+        while True:
+            try:
+                rc = child.wait(timeout=0.25)
+                break
+            except subprocess.TimeoutExpired:
+                if got and time.monotonic() - got[0][1] > grace:
+                    signal_group(signal.SIGKILL)
+    finally:
+        for s, h in previous.items():
+            signal.signal(s, h)
+    if got:
+        signal_group(signal.SIGKILL)                             # whatever is left of the group after its leader has gone
+        return 128 + got[0][0]
+    return rc
 
 
 def maybe_spawn_ranks(script, argv, nproc):

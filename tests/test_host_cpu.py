@@ -3,6 +3,7 @@ header declares, parameter init reproduces the reference's RNG stream and state_
 product refuses to run without a GPU (no silent fallback)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -204,3 +205,20 @@ def test_host_run_ahead_helpers_are_inert_without_a_gpu():
         assert not ins.enabled
         ins.publish(t, None, 5)
     assert hnn.input_stream("cpu").enabled is False
+
+
+def test_profiling_aggregators_classify_every_kernel_like_the_scope_it_runs_under():
+    """tools/kernel_classes.py (one table for pmc_traffic / pmc_mfma / kstats_steady) against the sources: every kernel a host function launches under a
+    ProfScope classifies into that scope's class - bench.py divides a class's replayed counters by that class's HIP-event time (round 4: the stem's
+    rows-in-LDS kernels were timed as conv_fwd / conv_wgrad and counted as 'other')."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_classes as kc
+    rows = kc.launches_by_scope(os.path.join(ROOT, "self-supervised-vision_amd", "csrc"))
+    assert len(rows) > 60 and sum(len(k) for _, _, _, k in rows) > 150                    # the parser still finds the launches
+    bad = [(f, fn, k, kc.classify(k), sc) for f, fn, sc, ks in rows if fn not in kc.SCOPE_EXCEPTIONS for k in ks if kc.classify(k) not in sc]
+    assert not bad, bad
+    from ssv_amd import _lib
+    assert {kc.classify(k) for _, _, _, ks in rows for k in ks} <= set(_lib.PROF_CLASSES)
+    for name, cls in (("stem_fwd_rows_k<true>", "conv_fwd"), ("stem_wgrad_rows_k", "conv_wgrad"), ("wino44_dy_k", "conv_wgrad"), ("wgrad_reduce64_k", "conv_wgrad"),
+                      ("void (anonymous namespace)::wino44_output_k<2>(int, int)", "conv_dgrad"), ("wino44_output_k<1>", "conv_fwd"), ("ntxent_merge_k", "loss")):
+        assert kc.classify(name) == cls and kc.in_conv_family(name) == cls.startswith("conv_"), name

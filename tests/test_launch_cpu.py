@@ -96,22 +96,57 @@ def test_bench_replays_counters_only_with_their_build_identity(tmp_path):
 
 
 def test_committed_counters_were_measured_on_the_current_sources():
-    """The build identity is the sha256 over the kernel sources in link order + the two headers (csrc/Makefile: SRC_SHA).  When the sources have moved on since the
+    """The build identity is the sha256 over the kernel sources in link order + the two headers + the compile flags (csrc/Makefile: SRC_SHA).  When the sources have moved on since the
     counters under profiles/ were measured, bench.py prints `counters_stale: true` - this test then SKIPS with the reason (a reminder to re-run tools/profile_step.sh
     and tools/bench_conv.py), it does not fail: stale counters are withheld, never wrong."""
-    import hashlib
-    import re
     sys.path.insert(0, ROOT)
     import bench
     csrc = os.path.join(ROOT, "self-supervised-vision_amd", "csrc")
-    srcs = re.search(r"^SRCS\s*:=\s*(.+)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).split()
-    h = hashlib.sha256()
-    for f in [os.path.join(csrc, s) for s in srcs] + [os.path.join(csrc, "common.h"), os.path.join(ROOT, "include", "ssv_hip.h")]:
-        h.update(open(f, "rb").read())
-    now = h.hexdigest()[:16]
+    # the Makefile's own recipe (sources in link order + the two headers + the compile flags): `make print-src-sha`
+    now = subprocess.run(["make", "-s", "-C", csrc, "print-src-sha"], capture_output=True, text=True, check=True).stdout.strip()
+    assert len(now) == 16
     from ssv_amd import _lib
     assert _lib.source_sha16() == now, "libssv_hip.so was not rebuilt after the last source change (run make -C self-supervised-vision_amd/csrc)"
     stale = [f for f in (bench.PMC_FILES["simclr"] % 512, bench.PMC_MFMA_FILES["simclr"] % 512, bench.CONV_LAYER_FILE % 512)
              if bench.read_committed_counters(os.path.join(ROOT, "profiles"), f)[1] != now]
     if stale:
         pytest.skip(f"counters under profiles/ were measured on another build than the current sources ({now}): {stale} - bench.py will print counters_stale")
+
+
+def test_a_stopped_parent_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to the waiting parent (``timeout -k`` around ``python bench.py --gpus N``, a harness watchdog) reaches the launcher's whole process group: the
+    child runs in its own session and the parent forwards TERM, then KILL - no rank is left holding the GPUs and the rendezvous port."""
+    import signal
+    import time
+    pidfile = tmp_path / "pids.txt"
+    grandchild = tmp_path / "rank.py"
+    grandchild.write_text("import os, sys, time\nopen(sys.argv[1], 'a').write(str(os.getpid()) + '\\n')\ntime.sleep(120)\n")
+    child = tmp_path / "launcher.py"         # stands in for torch.distributed.run: starts two 'ranks' and waits for them
+    child.write_text("import subprocess, sys\nps = [subprocess.Popen([sys.executable, sys.argv[1], sys.argv[2]]) for _ in range(2)]\n[p.wait() for p in ps]\n")
+    parent = tmp_path / "parent.py"
+    parent.write_text(f"import sys\nsys.path.insert(0, {ROOT!r})\nfrom ssv_amd import launch\n"
+                      f"sys.exit(launch.run_and_forward_signals([sys.executable, {str(child)!r}, {str(grandchild)!r}, {str(pidfile)!r}], grace=2.0))\n")
+    p = subprocess.Popen([sys.executable, str(parent)])
+    for _ in range(100):
+        if pidfile.exists() and len(pidfile.read_text().split()) == 2:
+            break
+        time.sleep(0.1)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.3)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+            with open(f"/proc/{pid}/stat") as fh:
+                alive = fh.read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, f"rank {pid} outlived its parent"
+    # an undisturbed run hands back the child's own exit code
+    ok = tmp_path / "ok.py"
+    ok.write_text("import sys\nsys.exit(7)\n")
+    from ssv_amd import launch
+    assert launch.run_and_forward_signals([sys.executable, str(ok)]) == 7

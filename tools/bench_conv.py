@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer table of the conv implicit-GEMM kernels on the ResNet-50 @224 shapes (all 53 convolutions, identical shapes merged):
 for forward, data gradient and weight gradient - the variant the training step really launches (statistics epilogue, fused input
-BatchNorm, gated epilogue), its time, TFLOP/s of algorithmic work, and how its grid quantises onto the chip
+BatchNorm, gated epilogue; the Winograd form and the stem kernel are read off the dispatcher / the library, not assumed), its time, TFLOP/s of algorithmic work, and how its grid quantises onto the chip
 (workgroups / (3 resident per CU x 256 CUs) = "waves of 768").
 
     python tools/bench_conv.py [batch per view = 512] [repeats = 5] [out.csv]
@@ -61,6 +61,18 @@ def timeit(fn):
     return e0.elapsed_time(e1) / REP
 
 
+def wino_form(fn):
+    """Which Winograd form(s) a call dispatches to, from the dispatcher's own log (ops.DISPATCH): '' | 'F(4x4)' | 'F(2x2)' | both."""
+    prev, ops.DISPATCH = ops.DISPATCH, {}
+    try:
+        fn()
+        keys = set(ops.DISPATCH)
+    finally:
+        ops.DISPATCH = prev
+    forms = [f for f, tag in (("F(4x4)", "wino44_"), ("F(2x2)", "wino22_")) if any(k.startswith(tag) for k in keys)]
+    return "+".join(forms)
+
+
 def grid_fwd(m, k):
     return -(-m // 128) * -(-k // 128) if k >= 128 else -(-m // 256) * -(-k // 64)
 
@@ -110,7 +122,12 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     dyl = ops.LazyGrad(dy, torch.randn_like(y), torch.randn(4, K, device=dev).contiguous()) if (big and C != 3 and ops.can_lazy_dy(w.shape, s, p)) else None
     sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= 784 and ops.can_form_closing_sum(w.shape, s, p)
     if C == 3:
-        fv = wv = "row-taps"
+        # which stem kernels the library takes for this shape: asked of the library itself (rows-in-LDS from 224-pixel image rows, else the row-taps gather)
+        import ctypes
+        dsc = ops.conv_desc(x.shape, tuple(w.shape), s, p)
+        lib = _lib.load()
+        fv = "rows-in-LDS" if int(lib.ssv_stem_conv_fwd_stats_rows_per_group(ctypes.byref(dsc))) != 64 else "row-taps"
+        wv = "rows-in-LDS" if int(lib.ssv_stem_conv_wgrad_rows_per_group(ctypes.byref(dsc))) > 0 else "row-taps"
         wrows = ops.stem_weight_rows(w)
         t_f = timeit(lambda: ops.stem_conv_fwd(x, wrows, tuple(w.shape), s, p, want_stats=True))
         t_w = timeit(lambda: ops.stem_conv_wgrad(x, dy, tuple(w.shape), s, p))
@@ -123,10 +140,13 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         del res
     elif lazy_in:
         wino = ops.use_winograd(tuple(w.shape), s, p, x.shape, True)        # stride-1 3x3 layers of the deep stages: Winograd F(2x2, 3x3)
-        fv = "stats+bn_in" + ("+winograd" if wino else "")
+        form = wino_form(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True, keep_v=True))
+        assert bool(form) == bool(wino)
+        fv = "stats+bn_in" + (f"+winograd {form}" if form else "")
         t_f = timeit(lambda: ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True, keep_v=True))
         vkeep = getattr(ops.conv2d_fwd_fused(x, w, s, p, in_affine=aff, want_stats=True, keep_v=True)[0], "_wino_v", None)
-        wv = "bn_in" + ("+dy_in" if dyl is not None else "") + ("+winograd" if vkeep is not None else "")
+        form = wino_form(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True, in_affine=aff, wino_v=vkeep))
+        wv = "bn_in" + ("+dy_in" if dyl is not None else "") + (f"+winograd {form}" if form else "")
         t_w = timeit(lambda: ops.conv2d_wgrad(x, dyl if dyl is not None else dy, w, dw, s, p, accumulate=True, in_affine=aff, wino_v=vkeep))
         del vkeep
     else:
@@ -145,8 +165,9 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         else:
             gate = ops.BnGateCtx(gx, mean, invstd, mask=torch.randint(0, 16, (x.numel() // 4,), device=dev, dtype=torch.uint8))
         addend = torch.randn_like(x) if kind == "plain" else None
-        dv = ("winograd" if (addend is None and dyl is None and lazy_in and ops.use_winograd((C, K, R, R), s, p, dy.shape, False)) else
-              ("fwd-kernel" if s == 1 else "dgrad-kernel")) + "+gate" + ("+addend" if addend is not None else "") + ("+dy_in" if dyl is not None else "")
+        form = wino_form(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate))
+        dv = ((f"winograd {form}" if form else ("fwd-kernel" if s == 1 else "dgrad-kernel")) + "+gate" + ("+addend" if addend is not None else "") +
+              ("+dy_in" if dyl is not None else ""))
         t_d = timeit(lambda: ops.conv2d_dgrad(dyl if dyl is not None else dy, w, x.shape, s, p, addend=addend, gate=gate))
         if ".1.conv1" in name and kind == "plain" and s == 1:
             # the first of these units sits behind a projection shortcut: its gate also reduces against that BatchNorm's input (GATE 3)

@@ -6,9 +6,11 @@ Reconciles the two family times a reader meets: `rocprofv3 --stats` totals divid
 touches, one-off initialisation kernels), bench.py's `roofline.kernel_ms_per_step` is measured over steady-state steps after the timed region.
     python tools/kstats_steady.py <kernel_trace.csv> [optimizer kernel substring = sgd_nesterov|adamw_k]"""
 import csv
+import os
 import sys
 
-FAMILY = ("conv_fwd_k", "conv_dgrad_k", "conv_wgrad_k", "wgrad_reduce_k", "wino_", "wino44_")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_classes import in_conv_family  # noqa: E402
 
 
 def main():
@@ -21,7 +23,7 @@ def main():
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         cur[1] += d
         cur[2] += 1
-        if any(k in r["Kernel_Name"] for k in FAMILY):
+        if in_conv_family(r["Kernel_Name"]):
             cur[0] += d
         if any(m in r["Kernel_Name"] for m in marks):
             steps.append(cur)

@@ -9,6 +9,8 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 
 def build_identity():
     """Which build the profiled run loaded (SSV_HIP_LIB or the in-tree library): {"src_sha16": the sources it was compiled from, as the binary
@@ -23,18 +25,7 @@ def build_identity():
     return {"src_sha16": fn().decode(), "lib_sha16": file_sha}
 
 
-# Winograd transforms belong to the convolution they serve: input / plain or statistics output -> forward (the transformed-domain GEMMs ARE conv_fwd_k
-# launches), gated output (<2>, <3>) -> data gradient side of the forward-kernel family, dy / filter-gradient transforms -> weight gradient
-CLASSES = (("conv_fwd", "conv_fwd_k"), ("conv_dgrad", "conv_dgrad_k"), ("conv_wgrad", "conv_wgrad_k"), ("conv_wgrad", "wgrad_reduce_k"),
-           ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_fwd", "wino_"), ("conv_fwd", "wino44_"),
-           ("bn_fwd", "bn_stats"), ("bn_fwd", "bn_apply"), ("bn_bwd", "bn_bwd"), ("attn", "attn_"), ("norm", "ln_"), ("gelu", "gelu_"))
-
-
-def classify(name):
-    for cls, key in CLASSES:
-        if key in name:
-            return cls
-    return "other"
+from kernel_classes import classify  # noqa: E402  (one table for every aggregator)
 
 
 def total(path, counter):
