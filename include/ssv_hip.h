@@ -228,6 +228,12 @@ int ssv_wino44_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, cons
  * 2e-6 relative l2 on the ResNet-50 shapes (tests/test_gpu_winograd44.py). */
 int ssv_wino44_dy_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, float* dM /*[36][T][K]*/, void* stream);
 int ssv_wino44_filter_grad(int32_t K, int32_t C, const float* dU /*[36][K][C]*/, float* dw /*[K][3][3][C]*/, int accumulate, void* stream);
+/* Both operands a layer's backward takes from its output gradient in ONE pass over it: Vd = what ssv_wino44_input_transform(dy) writes (the data gradient's transformed
+ * input) and dM = what ssv_wino44_dy_transform writes, bit for bit.  dyin != NULL: `dy` is g, the gradient w.r.t. the BatchNorm output behind this convolution, and the
+ * output gradient A g + B (x - mean) + D is formed per element on load (ssv_bn_bwd_coef's coefficients; zero outside the image): the BatchNorm backward's element-wise
+ * pass over this layer's output - one read of g and x, one write and two reads of dy - does not exist. */
+int ssv_wino44_dy_transform_both(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, const ssv_bn_dyin* dyin /* or NULL */,
+                                 float* Vd /*[36][T][K]*/, float* dM /*[36][T][K]*/, void* stream);
 /* batched GEMMs on the implicit-GEMM kernels, ONE launch: y[b] = a[b] . w[b]^T   /   dw[b] = dy[b]^T . x[b]   (b < batch) */
 int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
                      float* y /*[batch][rows][K]*/, void* stream);

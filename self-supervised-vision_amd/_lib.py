@@ -101,6 +101,7 @@ SIGNATURES = {
     "ssv_wino44_output_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(BnGate), _vp]),
     "ssv_wino44_dy_transform": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssv_wino44_filter_grad": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int, _vp]),
+    "ssv_wino44_dy_transform_both": (C.c_int, [_i32, _i32, _i32, _i32, _vp, C.POINTER(BnDyin), _vp, _vp, _vp]),
     "ssv_gemm_batched": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ssv_gemm_batched_wgrad_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "ssv_gemm_batched_wgrad": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -165,6 +165,86 @@ wino44_dy_k(int N, int H, int W, int K, int th, int tw, const float* __restrict_
   }
 }
 
+// ---- BOTH operands the backward of a layer takes from its output gradient, from ONE pass over it: Vd = B^T P B of the 6x6 patch (the data gradient's transformed
+// input, wino44_input_k<.., false, false>'s arithmetic bit for bit) and dM = A Y A^T of the patch's inner 4x4 tile (wino44_dy_k's, bit for bit).
+// DYF: the output gradient is never written - it is formed per element from the BatchNorm backward's operands, dy = A[k] g + B[k] (x - mean[k]) + D[k]
+// (coef = [A | mean | B | D], ssv_bn_bwd_coef; the same fmaf form as the implicit-GEMM kernels' formed-on-load operand), zero outside the image.
+template <int VW, bool DYF>
+__global__ void __launch_bounds__(256)
+wino44_dy_both_k(int N, int H, int W, int K, int th, int tw, const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ coef,
+                 float* __restrict__ Vd, float* __restrict__ dM, int64_t T) {
+  using vt = vecf<VW>;
+  const int KV = K / VW;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * KV) return;
+  const int64_t t = idx / KV;
+  const int k = (int)(idx - t * KV) * VW;
+  const int n = (int)(t / (th * tw));
+  const int r = (int)(t - (int64_t)n * th * tw);
+  const int i = r / tw, j = r - i * tw;
+  vt cA = {}, cM = {}, cB = {}, cD = {};
+  if constexpr (DYF) { cA = ldv<VW>(coef + k); cM = ldv<VW>(coef + (size_t)K + k); cB = ldv<VW>(coef + 2 * (size_t)K + k); cD = ldv<VW>(coef + 3 * (size_t)K + k); }
+  vt d[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int hi = 4 * i - 1 + a;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const int wi = 4 * j - 1 + b;
+      vt v = {};
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+        const size_t off = (((size_t)n * H + hi) * W + wi) * K + k;
+        v = ldv<VW>(dy + off);
+        if constexpr (DYF) {
+          const vt xv = ldv<VW>(x + off);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[e] = __builtin_fmaf(v[e], cA[e], __builtin_fmaf(xv[e] - cM[e], cB[e], cD[e]));
+        }
+      }
+      d[a][b] = v;
+    }
+  }
+  const size_t ps = (size_t)T * K;
+  {                                                // the weight gradient's operand: A Y A^T, Y = d[1..4][1..4]
+    vt s[6][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      vt col[4], m[6];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) col[a] = d[1 + a][1 + b];
+      a6(col, m);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s[a][b] = m[a];
+    }
+    float* o = dM + (size_t)t * K + k;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      vt m[6];
+      a6(s[a], m);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) stv<VW>(o + (size_t)(a * 6 + b) * ps, m[b]);
+    }
+  }
+  // the data gradient's operand: B^T d B, column by column in place, then row by row
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    vt col[6], v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) col[a] = d[a][b];
+    bt6(col, v);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a][b] = v[a];
+  }
+  float* o = Vd + (size_t)t * K + k;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    vt v[6];
+    bt6(d[a], v);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) stv<VW>(o + (size_t)(a * 6 + b) * ps, v[b]);
+  }
+}
+
 // ---- input: V[p][t][c] = (B^T d B)[xi][nu] over the 6x6 patch of tile t (rows 4i-1 .. 4i+4, zero outside the image) ---------------------------------
 // One thread = one tile x VW channels, lanes along the channels.  XF: x is the producer's raw conv output and the operand is relu(x * scale[c] + shift[c])
 // (the fmaf / fmaxf of bn_apply_k; padding stays 0).  BOTH: the four F(2x2) input tiles that lie inside this patch - tiles (2i + a, 2j + b) of winograd.hip's
@@ -436,6 +516,24 @@ extern "C" int ssv_wino44_dy_transform(int32_t N, int32_t H, int32_t W, int32_t 
   const int64_t T = (int64_t)N * th * tw;
   hipLaunchKernelGGL(wino44_dy_k, dim3((unsigned)cdiv64(T * (K / 4), 256)), dim3(256), 0, s, N, H, W, K, th, tw, dy, dM, T);
   SSV_CHECK_LAUNCH("ssv_wino44_dy_transform");
+  return SSV_OK;
+}
+
+// Vd [36][T][K] = B^T P B (what ssv_wino44_input_transform(dy) writes) and dM [36][T][K] = A dY A^T (what ssv_wino44_dy_transform writes) from ONE pass over the
+// output gradient.  dyin != NULL: dy is g, the gradient w.r.t. the BatchNorm output behind this convolution, and the output gradient is formed on load from
+// (g, dyin->x, dyin->coef [4][K]) - the BatchNorm backward's element-wise pass never runs for this layer.
+extern "C" int ssv_wino44_dy_transform_both(int32_t N, int32_t H, int32_t W, int32_t K, const float* dy, const ssv_bn_dyin* dyin, float* Vd, float* dM, void* stream) {
+  if (int rc = check_shape44(N, H, W, K, "ssv_wino44_dy_transform_both")) return rc;
+  SSV_REQUIRE(dy && Vd && dM && (((uintptr_t)dy | (uintptr_t)Vd | (uintptr_t)dM) & 15) == 0, "ssv_wino44_dy_transform_both: null or unaligned pointer");
+  SSV_REQUIRE(!dyin || (dyin->x && dyin->coef && (((uintptr_t)dyin->x | (uintptr_t)dyin->coef) & 15) == 0), "ssv_wino44_dy_transform_both: the formed-on-load operand needs x and coef (16-byte aligned)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_WGRAD, s);
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  const int64_t T = (int64_t)N * th * tw;
+  const dim3 grid((unsigned)cdiv64(T * (K / 2), 256));
+  if (dyin) hipLaunchKernelGGL((wino44_dy_both_k<2, true>), grid, dim3(256), 0, s, N, H, W, K, th, tw, dy, dyin->x, dyin->coef, Vd, dM, T);
+  else hipLaunchKernelGGL((wino44_dy_both_k<2, false>), grid, dim3(256), 0, s, N, H, W, K, th, tw, dy, (const float*)nullptr, (const float*)nullptr, Vd, dM, T);
+  SSV_CHECK_LAUNCH("ssv_wino44_dy_transform_both");
   return SSV_OK;
 }
 

@@ -416,6 +416,9 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
     if (tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW
             and weight.shape[0] >= _BN_DY_MIN_K):
         y._lazy_dy_ok = True       # a BatchNorm behind this output may hand its backward over as an ops.LazyGrad (formed by wgrad / dgrad)
+    if (tape is not None and lazy is not None and bias is None and _FUSE_BN_DY and _FUSE_BN_BWD
+            and ops.wino44_lazy_dy_ok(y, tuple(weight.shape), src.shape)):
+        y._lazy_dy_ok = True       # all three products of this layer run Winograd F(4x4): its dY transform forms the BatchNorm backward on load (ops.WINOGRAD44_DY_BOTH)
     if tape is not None:
         need_dx = lazy is not None or tape.needs_grad(x)
 

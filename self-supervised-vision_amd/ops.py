@@ -212,10 +212,11 @@ class LazyGrad:
     convolution's weight and data gradient form it while they stage their dY operand (ssv_conv2d_wgrad_dyin / ssv_conv2d_fwd_dyin), so the
     element-wise pass of the BatchNorm backward does not run (1x1 / stride-1 convolutions: conv3 and the stride-1 projection shortcut of
     networks/resnet.py:66-75, the widest tensors of a residual unit)."""
-    __slots__ = ("g", "x", "coef")
+    __slots__ = ("g", "x", "coef", "wino_vd")
 
     def __init__(self, g, x, coef):
         self.g, self.x, self.coef = g, x, coef
+        self.wino_vd = None              # Winograd F(4x4) layers: the data gradient's transformed input, left by the weight gradient's pass over (g, x)
 
     @property
     def shape(self):
@@ -299,6 +300,11 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     _lib._dev(dy, w, addend)
     w, wshape = _ohwi(w)
     k, c, r, s_ = wshape
+    if lazy is not None and lazy.wino_vd is not None:            # a Winograd F(4x4) layer: the weight gradient's pass over (g, x) left this product's transformed input
+        if not (addend is None and out is None and (gate is None or gate.x2 is None) and groups == 1):
+            raise _lib.SsvError("conv2d_dgrad: a LazyGrad of a Winograd layer reached a data gradient with an addend / second gate target (nn.conv marks such layers only "
+                                "behind a fused input chain, where neither exists)")
+        return wino44_conv2d_dgrad(lazy, w, gate=gate)
     if lazy is not None and not can_lazy_dy(wshape, stride, pad):
         raise _lib.SsvError("conv2d_dgrad: a LazyGrad reached a convolution that cannot form it (the producer must check ops.can_lazy_dy)")
     dx = out if out is not None else _empty(tuple(x_shape), dy)
@@ -408,7 +414,7 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=
             ws = workspace.get(lib.ssv_conv2d_wgrad_grouped_workspace_bytes(C.byref(d), int(groups)), x.device)
             call("ssv_conv2d_wgrad_grouped", C.byref(d), int(groups), ptr(x[n0:n1]), ptr(dy[n0:n1]), ptr(dw), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
         return dw
-    if wino_v is not None and not isinstance(dy, LazyGrad):
+    if wino_v is not None and (not isinstance(dy, LazyGrad) or (wino_v.shape[0] == 36 and WINOGRAD44_DY_BOTH)):
         return wino_conv2d_wgrad(wino_v, dy, w_like, dw, accumulate=accumulate)
     lazy = dy if isinstance(dy, LazyGrad) else None
     if lazy is not None:
@@ -1090,6 +1096,20 @@ WINOGRAD44_WGRAD = os.environ.get("SSV_WINOGRAD44_WGRAD", "1") == "1"
 WINOGRAD44_WGRAD_CHUNK = int(os.environ.get("SSV_WINOGRAD44_WGRAD_CHUNK", "512"))
 # ... or / and inside the kernel: the MFMA accumulators flushed into a second register set every 128 tiles (0 = off)
 WINOGRAD44_WGRAD_FLUSH = int(os.environ.get("SSV_WINOGRAD44_WGRAD_FLUSH", "128"))
+# The backward of such a layer reads its output gradient ONCE: the weight gradient's dY transform also writes the data gradient's transformed input
+# (ssv_wino44_dy_transform_both; the data gradient that follows picks it up), and behind a fused input chain the output gradient is never written at all - the
+# BatchNorm backward hands over (g, x, coefficients) as a LazyGrad and the transform forms it on load (`wino44_lazy_dy_ok`).  SSV_WINOGRAD44_DY_BOTH=0: separate passes.
+WINOGRAD44_DY_BOTH = os.environ.get("SSV_WINOGRAD44_DY_BOTH", "1") == "1"
+
+
+def wino44_lazy_dy_ok(y, w_shape, x_shape):
+    """May the BatchNorm behind this convolution output hand its backward over as a LazyGrad?  Only when forward, data gradient and weight gradient all run F(4x4):
+    the output carries F(4x4)'s own transformed input (the weight gradient will take the (g, x) operand) and the data gradient's dispatch rule holds for dy's shape
+    (= the output's: 3x3 / stride 1 / padding 1)."""
+    v = getattr(y, "_wino_v", None)
+    k, c, _, _ = w_shape
+    return (WINOGRAD44_DY_BOTH and WINOGRAD44_WGRAD and v is not None and v.shape[0] == 36
+            and _use_wino44(y.shape[0], y.shape[1], y.shape[2], c, k, WINOGRAD44_MAX_RATIO_DGRAD))
 
 
 # Which Winograd form each product took (launch counts by name), recorded while DISPATCH is a dict: bench.py's parity gate prints it so that the line
@@ -1173,8 +1193,16 @@ def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
 
 
 def wino44_conv2d_dgrad(dy, w, gate=None):
-    """wino_conv2d_dgrad through F(4x4, 3x3); the gate's partial sums come one per row of tiles."""
+    """wino_conv2d_dgrad through F(4x4, 3x3); the gate's partial sums come one per row of tiles.  ``dy`` may be the LazyGrad / tensor whose transformed input
+    the weight gradient's pass already wrote (`wino44_conv2d_wgrad`): the input transform is then skipped."""
     _note("wino44_dgrad")
+    vd = None
+    if isinstance(dy, LazyGrad):
+        vd, dy.wino_vd, dy = dy.wino_vd, None, dy.g
+        if vd is None:
+            raise _lib.SsvError("wino44_conv2d_dgrad: a LazyGrad without the transformed input the weight gradient leaves")
+    else:
+        vd = dy.__dict__.pop("_wino44_vd", None)
     _lib._dev(dy, w)
     w, wshape = _ohwi(w)
     n, h, w_, k = dy.shape
@@ -1182,8 +1210,11 @@ def wino44_conv2d_dgrad(dy, w, gate=None):
     lib = _lib.load()
     t = int(lib.ssv_wino44_tiles(n, h, w_))
     u = _wino44_filter(w, wshape, transposed=True)                # [36][C][K]
-    v = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
-    call("ssv_wino44_input_transform", n, h, w_, k, ptr(dy), None, None, ptr(v), None, stream())
+    if vd is not None and tuple(vd.shape) == (36, t, k):
+        v = vd
+    else:
+        v = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
+        call("ssv_wino44_input_transform", n, h, w_, k, ptr(dy), None, None, ptr(v), None, stream())
     m = torch.empty((36, t, c), dtype=torch.float32, device=dy.device)
     call("ssv_gemm_batched", 36, t, k, c, ptr(v), ptr(u), ptr(m), stream())
     dx = _empty((n, h, w_, c), dy)
@@ -1276,7 +1307,7 @@ def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
 def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     """wino_conv2d_wgrad through F(4x4, 3x3): dM = A dY A^T, 36 products dU_p = dM_p^T V_p over the tiles, dw (+)= G^T dU G."""
     _note("wino44_wgrad")
-    _lib._dev(v, dy, dw)
+    _lib._dev(v, dy.g if isinstance(dy, LazyGrad) else dy, dw)
     _, wshape = _ohwi(w_like)
     n, h, w_, k = dy.shape
     c = wshape[1]
@@ -1284,8 +1315,23 @@ def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     t = int(lib.ssv_wino44_tiles(n, h, w_))
     if tuple(v.shape) != (36, t, c):
         raise _lib.SsvError(f"wino44_conv2d_wgrad: transformed input {tuple(v.shape)} does not belong to a {n}x{h}x{w_}x{c} activation")
-    dm = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
-    call("ssv_wino44_dy_transform", n, h, w_, k, ptr(dy), ptr(dm), stream())
+    lazy = dy if isinstance(dy, LazyGrad) else None
+    g = lazy.g if lazy is not None else dy
+    dm = torch.empty((36, t, k), dtype=torch.float32, device=g.device)
+    # the data gradient of the same layer follows (nn.conv: weight gradient first): when it will run F(4x4) too, its transformed input comes out of this pass
+    both = WINOGRAD44_DY_BOTH and (lazy is not None or _use_wino44(n, h, w_, c, k, WINOGRAD44_MAX_RATIO_DGRAD))
+    if both:
+        vd = torch.empty((36, t, k), dtype=torch.float32, device=g.device)
+        dyin = _dyin_struct(lazy, 0, n) if lazy is not None else None
+        _note("wino44_dy_both_formed_on_load" if lazy is not None else "wino44_dy_both")
+        call("ssv_wino44_dy_transform_both", n, h, w_, k, ptr(g), None if dyin is None else C.byref(dyin), ptr(vd), ptr(dm), stream())
+        if lazy is not None:
+            lazy.wino_vd = vd
+        else:
+            dy._wino44_vd = vd
+    else:
+        call("ssv_wino44_dy_transform", n, h, w_, k, ptr(g), ptr(dm), stream())
+    dy = g
     du = torch.empty((36, k, c), dtype=torch.float32, device=dy.device)
     if WINOGRAD44_WGRAD_CHUNK > 0 or WINOGRAD44_WGRAD_FLUSH > 0:
         ws = workspace.get(lib.ssv_gemm_batched_wgrad_blocked_workspace_bytes(36, t, c, k, WINOGRAD44_WGRAD_CHUNK), dy.device)

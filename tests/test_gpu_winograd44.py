@@ -213,3 +213,47 @@ def test_which_product_takes_f44(dev):
         assert calls == {"f": 0, "d": 0}
     finally:
         ops.wino44_conv2d_fwd, ops.wino44_conv2d_dgrad = inner_f, inner_d
+
+
+@pytest.mark.parametrize("n,h,w_,c,k", SHAPES[:6])
+def test_one_pass_over_dy_leaves_both_backward_operands(dev, n, h, w_, c, k):
+    """ssv_wino44_dy_transform_both: the data gradient's transformed input and the weight gradient's transformed dY from ONE pass over dy - bit for bit what the two
+    separate transforms write; with the formed-on-load operand (g, x, coefficients of the BatchNorm backward) equal to the transforms of the materialised dy."""
+    from ssv_amd import _lib, ops
+    lib = _lib.load()
+    dy = seeded_randn(41, n, h, w_, k).to(dev)
+    t = int(lib.ssv_wino44_tiles(n, h, w_))
+    vd, dm = torch.empty((36, t, k), device=dev), torch.empty((36, t, k), device=dev)
+    _lib.call("ssv_wino44_dy_transform_both", n, h, w_, k, _lib.ptr(dy), None, _lib.ptr(vd), _lib.ptr(dm), _lib.stream())
+    vd_ref, dm_ref = torch.empty_like(vd), torch.empty_like(dm)
+    _lib.call("ssv_wino44_input_transform", n, h, w_, k, _lib.ptr(dy), None, None, _lib.ptr(vd_ref), None, _lib.stream())
+    _lib.call("ssv_wino44_dy_transform", n, h, w_, k, _lib.ptr(dy), _lib.ptr(dm_ref), _lib.stream())
+    assert torch.equal(vd, vd_ref) and torch.equal(dm, dm_ref)
+    # formed on load: dy = A g + B (x - mean) + D per channel
+    g, x = seeded_randn(42, n, h, w_, k), seeded_randn(43, n, h, w_, k)
+    coef = torch.stack([seeded_randn(44, k) * 0.5 + 1.0, seeded_randn(45, k) * 0.1, seeded_randn(46, k) * 0.3, seeded_randn(47, k) * 0.05])
+    want = (coef[0].double() * g.double() + coef[2].double() * (x.double() - coef[1].double()) + coef[3].double()).float().to(dev).contiguous()
+    _lib.call("ssv_wino44_input_transform", n, h, w_, k, _lib.ptr(want), None, None, _lib.ptr(vd_ref), None, _lib.stream())
+    _lib.call("ssv_wino44_dy_transform", n, h, w_, k, _lib.ptr(want), _lib.ptr(dm_ref), _lib.stream())
+    gd, xd, cd = g.to(dev), x.to(dev), coef.to(dev).contiguous()
+    dyin = _lib.BnDyin(_lib.ptr(xd), _lib.ptr(cd))
+    import ctypes
+    _lib.call("ssv_wino44_dy_transform_both", n, h, w_, k, _lib.ptr(gd), ctypes.byref(dyin), _lib.ptr(vd), _lib.ptr(dm), _lib.stream())
+    for got, ref in ((vd, vd_ref), (dm, dm_ref)):
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), float((got - ref).abs().max() / ref.abs().max())
+    # ... and through the host path: the weight gradient leaves the data gradient's operand on the LazyGrad, the data gradient picks it up
+    w = (seeded_randn(48, k, c, 3, 3) * (2.0 / (9 * c)) ** 0.5).contiguous(memory_format=torch.channels_last).to(dev)
+    xin = seeded_randn(49, n, h, w_, c).to(dev)
+    _, _, v4 = ops.wino44_conv2d_fwd(xin, w, want_stats=False, keep_v=True)
+    lazy = ops.LazyGrad(gd, xd, cd)
+    dw = torch.zeros_like(w)
+    ops.conv2d_wgrad(xin, lazy, w, dw, 1, 1, accumulate=False, wino_v=v4)
+    assert lazy.wino_vd is not None
+    dx = ops.conv2d_dgrad(lazy, w, xin.shape, 1, 1)
+    assert lazy.wino_vd is None
+    dw_ref = torch.zeros_like(w)
+    ops.wino44_conv2d_wgrad(v4, want, w, dw_ref, accumulate=False)
+    dx_ref = ops.wino44_conv2d_dgrad(want, w)
+    assert rel(dw, dw_ref.cpu().double()) < 2e-5 and rel(dx, dx_ref.cpu().double()) < 2e-5
+    with pytest.raises(_lib.SsvError):                      # a LazyGrad that the weight gradient has not visited cannot feed the Winograd data gradient
+        ops.wino44_conv2d_dgrad(ops.LazyGrad(gd, xd, cd), w)
