@@ -473,7 +473,18 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
     for _ in range(gpu_steps):
         hip_step({"aug_1": v1, "aug_2": v2})
     torch.cuda.synchronize()
+    eager_dt = (time.perf_counter() - t0) / gpu_steps
+    # the same trainer's step through TwoViewTrainer.step: replayed as ONE HIP graph at this size (ssv_amd.graph.StepGraph, SSV_STEP_GRAPH=auto)
+    t = hip_step.trainer
+    for _ in range(3):
+        t.step({"aug_1": v1, "aug_2": v2})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(gpu_steps):
+        t.step({"aug_1": v1, "aug_2": v2})
+    torch.cuda.synchronize()
     gpu_dt = (time.perf_counter() - t0) / gpu_steps
+    graph_state = t._step_graph.describe()
     del hip_step
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     m = oracle.SimCLROracle("resnet18", True, 128, lr=lr, weight_decay=1e-4)
@@ -487,8 +498,11 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
             "cpu": {"value": round(batch / cpu_dt, 1), "unit": "images/sec", "ms_per_step": round(cpu_dt * 1e3, 2), "cores": torch.get_num_threads(), "kind": "port",
                     "sample": f"{cpu_steps} timed steps (1 warm-up) of the oracle, torch fp32 CPU"},
             "gpu": {"value": round(batch / gpu_dt, 1), "unit": "images/sec", "ms_per_step": round(gpu_dt * 1e3, 3),
-                    "sample": f"{gpu_steps} timed steps (5 warm-up) of the HIP trainer on the same views, loss read every step; at this size the step is bound by the "
-                              "host's kernel enqueue (tools/bench_cifar.py: bs 512 of the same network runs 35.8 k images/s)"},
+                    "sample": f"{gpu_steps} timed steps of the HIP trainer's step() on the same views, loss read every step: the step replayed as one HIP graph "
+                              "(ssv_amd.graph.StepGraph; ~490 launches whose host enqueue time equals the GPU's work at this size)",
+                    "step_graph": graph_state,
+                    "eager": {"value": round(batch / eager_dt, 1), "ms_per_step": round(eager_dt * 1e3, 3),
+                              "sample": f"{gpu_steps} timed steps (5 warm-up) of train_step() launched kernel by kernel"}},
             "loss_step0": {"hip": round(hip0, 7), "cpu": round(cpu0, 7), "rel_err": float(f"{abs(hip0 - cpu0) / abs(cpu0):.2e}")}}
 
 

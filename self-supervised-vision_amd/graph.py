@@ -1,0 +1,127 @@
+"""The training step as ONE HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm), for the regime the reference actually ships: resnet18 on 32 x 32 images
+(configs/*.yaml), where a step is ~500 kernel launches of a few microseconds each and the host's enqueue time (Python -> ctypes -> hipLaunchKernel, ~18 us per
+launch) is as long as the GPU's work (tools/bench_cifar.py, profiles/r05_cifar_r18_*).  Replaying the captured step costs the host one hipGraphLaunch.
+
+What is captured is the trainer's own ``train_step(batch)`` (models/simclr.py:86-95 and its siblings) - both view passes on their two streams, the loss, the
+backward pass through torch.autograd, the fused optimizer update - called once under stream capture on STATIC input buffers; every later step copies its
+batch into those buffers and replays.  Nothing of the step lives on the host:
+
+  * the loss leaves through a device-to-host copy node into a pinned buffer (``nn.early_item`` under capture), read after the replay has finished;
+  * BatchNorm running statistics / num_batches_tracked, the optimizer state and the gradient slabs are device memory that the kernels update in place;
+  * the learning rate and weight decay are kernel ARGUMENTS, baked into the graph: a graph is keyed by (input shapes, lr, weight decay, momentum) and a new one
+    is captured when the schedule moves them (once per epoch with the reference's schedulers); the optimizer's first-step flag is why capture waits for the
+    optimizer's first update;
+  * scratch (ops.workspace) used by captured kernels is allocated inside the capture, in the graph's private pool, so no later eager allocation can move it.
+
+Not graphed (the call falls back to the eager step): a process group (collectives stay eager), AdamW (its bias-correction step count is a kernel argument:
+DINO), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
+"""
+import os
+
+import torch
+
+from . import distributed as hdist
+from . import nn as hnn
+from . import ops
+
+# SSV_STEP_GRAPH: "1" always (where possible), "0" never, "auto" (default) for small images only - where the step is launch-bound
+MODE = os.environ.get("SSV_STEP_GRAPH", "auto")
+AUTO_MAX_PIXELS = 64 * 64            # per image: CIFAR (32 x 32) and the like; at 224 x 224 the step is GPU-bound and the static input copies cost more than the launches
+WARMUP_STEPS = 2                     # eager steps before a capture: the optimizer's first update (its first-step flag is a kernel argument), allocator warm-up
+
+
+class StepGraph:
+    """``sg = StepGraph(trainer); metrics = sg(batch)`` - the drop-in for ``trainer.train_step(batch)``."""
+
+    def __init__(self, trainer, keys=None, mode=None):
+        self.trainer = trainer
+        self.keys = keys
+        self.mode = MODE if mode is None else mode
+        self.graphs = {}             # key -> (graph, static inputs, pinned loss, workspace buffers kept alive)
+        self.eager_steps = 0
+        self.seen = {}               # input-shape signature -> times met without a graph
+        self.disabled = None         # reason, once capture has failed or the trainer is not graphable
+        self.replays = 0
+
+    # ---- eligibility ---------------------------------------------------------------------------------------------------------
+    def _tensors(self, batch):
+        keys = self.keys or getattr(self.trainer, "graph_inputs", None) or [k for k, v in batch.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 3]
+        return {k: batch[k] for k in keys}
+
+    def _why_not(self, ins):
+        from .utils.train_utils import FusedSGD
+        if self.mode == "0":
+            return "SSV_STEP_GRAPH=0"
+        if not getattr(self.trainer, "graph_safe", False):
+            return f"{type(self.trainer).__name__}.train_step keeps per-step state on the host (graph_safe is False)"
+        if hdist.is_on():
+            return "a process group is active (collectives stay eager)"
+        if not isinstance(getattr(self.trainer, "optim", None), FusedSGD):
+            return "the optimizer is not the fused SGD (AdamW's step count is a kernel argument)"
+        if not ins or not all(t.is_cuda for t in ins.values()):
+            return "the batch is not on the GPU"
+        if self.mode == "auto" and max(t.shape[-1] * t.shape[-2] for t in ins.values()) > AUTO_MAX_PIXELS:
+            return "images larger than 64 x 64: the step is GPU-bound (SSV_STEP_GRAPH=1 forces the graph)"
+        return None
+
+    def _key(self, ins):
+        g = self.trainer.optim.param_groups[0]
+        return (tuple((k, tuple(t.shape), t.stride()) for k, t in sorted(ins.items())), float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]))
+
+    # ---- the step ------------------------------------------------------------------------------------------------------------
+    def __call__(self, batch):
+        if self.disabled is not None:
+            return self.trainer.train_step(batch)
+        ins = self._tensors(batch)
+        why = self._why_not(ins)
+        if why is not None:
+            if self.mode == "0" or not hdist.is_on():
+                self.disabled = why          # permanent reasons; a process group may come and go in tests
+            return self.trainer.train_step(batch)
+        key = self._key(ins)
+        rec = self.graphs.get(key)
+        if rec is None:
+            shape_sig = key[0]
+            self.seen[shape_sig] = self.seen.get(shape_sig, 0) + 1
+            # eager until the optimizer has made its first update; a shape met for the first time runs eagerly too (the ragged last batch of an epoch)
+            if self.trainer.optim._steps < 1 or self.eager_steps < WARMUP_STEPS or (self.seen[shape_sig] < 2 and any(k[0] != shape_sig for k in self.graphs)):
+                self.eager_steps += 1
+                return self.trainer.train_step(batch)
+            try:
+                rec = self._capture(batch, ins, key)
+            except Exception as exc:         # never take the training run down: the eager step is always there
+                self.disabled = f"capture failed: {type(exc).__name__}: {exc}"
+                torch.cuda.synchronize()
+                return self.trainer.train_step(batch)
+            for old in [k for k in self.graphs if k[0] == key[0] and k != key]:
+                del self.graphs[old]         # the schedule moved on: one graph per input shape
+            self.graphs[key] = rec
+        graph, static, host, _ = rec
+        for k, t in ins.items():
+            static[k].copy_(t, non_blocking=True)
+        graph.replay()
+        torch.cuda.current_stream().synchronize()
+        self.replays += 1
+        return {"loss": float(host.item())}
+
+    def _capture(self, batch, ins, key):
+        static = {k: torch.empty_like(t) for k, t in ins.items()}
+        for k, t in ins.items():
+            static[k].copy_(t)
+        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        sbatch = dict(batch)
+        sbatch.update(static)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        eager_ws, ops.workspace.buf = ops.workspace.buf, {}
+        prev = hnn.begin_capture(host)
+        try:
+            with torch.cuda.graph(graph):
+                self.trainer.train_step(sbatch)
+        finally:
+            hnn.end_capture(prev)
+            graph_ws, ops.workspace.buf = ops.workspace.buf, eager_ws
+        return graph, static, host, graph_ws
+
+    def describe(self):
+        return {"mode": self.mode, "graphs": len(self.graphs), "replays": self.replays, "eager_steps": self.eager_steps, "disabled": self.disabled}

@@ -52,6 +52,7 @@ class _Tracker:
 
 class TwoViewTrainer:
     algo = None          # "simclr" | "byol" | "barlow" | "dino": names the outputs/<algo>/ directory
+    graph_safe = False   # may train_step be replayed as a HIP graph (graph.StepGraph)?  Only steps whose every per-step quantity lives in device memory
     archs = tuple(NETWORKS)
 
     def __init__(self, args):
@@ -164,10 +165,19 @@ class TwoViewTrainer:
         self.logger.write("Test linear eval accuracy: {:.4f}".format(acc), mode="info")
 
     # ---- training loop --------------------------------------------------------------------------------------------
+    def step(self, batch):
+        """``train_step(batch)``, replayed as one HIP graph where that pays (graph.StepGraph: small images - the launch-bound regime of the reference's own
+        CIFAR configurations - fused SGD, single process; SSV_STEP_GRAPH=0|1|auto).  Same result, same side effects."""
+        sg = self.__dict__.get("_step_graph")
+        if sg is None:
+            from ..graph import StepGraph
+            sg = self._step_graph = StepGraph(self)
+        return sg(batch)
+
     def _run_epoch(self, tag):
         meter, total = common.AverageMeter(), len(self.train_loader)
         for step, batch in enumerate(self.train_loader):
-            metrics = self.train_step(batch)
+            metrics = self.step(batch)
             self._tracker.log({"Train loss": metrics["loss"]})
             meter.add(metrics)
             if hdist.rank() == 0:

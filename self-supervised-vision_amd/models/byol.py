@@ -44,6 +44,8 @@ class TargetNetwork(hnn.HipModule):
 
 class BYOL(TwoViewTrainer):
     algo = "byol"
+    graph_safe = True    # the step holds no per-step host state: inputs, loss, BatchNorm statistics, optimizer state are device memory
+    graph_inputs = ("aug_1", "aug_2")
 
     def _build(self, arch):
         encoder, encoder_dim = NETWORKS[arch].values()

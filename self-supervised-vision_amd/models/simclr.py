@@ -7,6 +7,8 @@ from .heads import SimclrProjectionHead as ProjectionHead  # noqa: F401  (refere
 
 class SimCLR(TwoViewTrainer):
     algo = "simclr"
+    graph_safe = True    # the step holds no per-step host state: inputs, loss, BatchNorm statistics, optimizer state are device memory
+    graph_inputs = ("aug_1", "aug_2")
 
     def _build(self, arch):
         encoder, encoder_dim = NETWORKS[arch].values()

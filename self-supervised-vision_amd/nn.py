@@ -191,6 +191,20 @@ class input_stream:
 
 
 _EARLY_LOSS = os.environ.get("SSV_LATE_LOSS_READ", "0") != "1"      # diagnostic switch: read the loss with .item() after the update (drains the queue)
+_CAPTURE_HOST = None     # while graph.StepGraph captures a step: the pinned float the step's loss is copied to by a node of the graph
+
+
+def begin_capture(host):
+    """The step that follows is recorded into a HIP graph, not executed: ``early_item`` must neither synchronise nor allocate - it copies the scalar into
+    ``host`` (pinned, owned by the graph's record) and ``get()`` returns a placeholder; the replaying caller reads ``host`` after the graph has run."""
+    global _CAPTURE_HOST
+    prev, _CAPTURE_HOST = _CAPTURE_HOST, host
+    return prev
+
+
+def end_capture(prev):
+    global _CAPTURE_HOST
+    _CAPTURE_HOST = prev
 
 
 class early_item:
@@ -203,6 +217,10 @@ class early_item:
     def __init__(self, t):
         self.t = t.detach()
         self.ev = None
+        self.captured = _CAPTURE_HOST is not None and self.t.is_cuda
+        if self.captured:
+            _CAPTURE_HOST.copy_(self.t.reshape(1), non_blocking=True)          # a device-to-host copy node of the graph being captured
+            return
         if self.t.is_cuda and _EARLY_LOSS:
             self.host = torch.empty(1, dtype=self.t.dtype, pin_memory=True)
             self.host.copy_(self.t.reshape(1), non_blocking=True)
@@ -210,6 +228,8 @@ class early_item:
             self.ev.record(torch.cuda.current_stream(self.t.device))
 
     def get(self):
+        if self.captured:
+            return float("nan")              # nothing has executed yet: the value exists after the replay (graph.StepGraph reads the pinned buffer)
         if self.ev is None:
             return self.t.item()
         self.ev.synchronize()
