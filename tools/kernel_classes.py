@@ -9,7 +9,7 @@ CLASSES = (
     ("conv_fwd", "conv_fwd_k"), ("conv_fwd", "stem_fwd_rows_k"),
     ("conv_dgrad", "conv_dgrad_k"), ("conv_dgrad", "wino_output_k<2"), ("conv_dgrad", "wino_output_k<3"), ("conv_dgrad", "wino44_output_k<2"), ("conv_dgrad", "wino44_output_k<3"),
     ("conv_wgrad", "conv_wgrad_k"), ("conv_wgrad", "stem_wgrad_rows_k"), ("conv_wgrad", "wgrad_reduce"),
-    ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_wgrad", "wino44_dy_k"), ("conv_wgrad", "wino44_dfilter_k"),
+    ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_wgrad", "wino44_dy_k"), ("conv_wgrad", "wino44_dy_both_k"), ("conv_wgrad", "wino44_dfilter_k"),
     ("conv_fwd", "wino_input_k"), ("conv_fwd", "wino_output_k"), ("conv_fwd", "wino44_input_k"), ("conv_fwd", "wino44_output_k"),
     ("misc", "wino_filter_k"), ("misc", "wino44_filter_k"),
     ("bn_fwd", "bn_stats"), ("bn_fwd", "bn_apply"), ("bn_fwd", "bn_partials_coarsen"), ("bn_fwd", "bn_relu_maxpool_fwd"),
