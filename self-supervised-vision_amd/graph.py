@@ -13,6 +13,10 @@ batch into those buffers and replays.  Nothing of the step lives on the host:
     optimizer's first update;
   * scratch (ops.workspace) used by captured kernels is allocated inside the capture, in the graph's private pool, so no later eager allocation can move it.
 
+On small images the captured step also takes another kernel SELECTION than the eager one (ops.graph_dispatch): with no host cost per launch the Winograd forms pay
+from 64 tiles and 64 channels, which is what turns batch 64 from 6.8 into 5.2 ms per step; ``graph_floors=False`` captures the eager selection (then the replayed
+steps are the eager steps bit for bit - tests/test_gpu_graph.py checks both).
+
 Not graphed (the call falls back to the eager step): a process group (collectives stay eager), AdamW (its bias-correction step count is a kernel argument:
 DINO), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
 """
@@ -33,9 +37,10 @@ WARMUP_STEPS = 2                     # eager steps before a capture: the optimiz
 class StepGraph:
     """``sg = StepGraph(trainer); metrics = sg(batch)`` - the drop-in for ``trainer.train_step(batch)``."""
 
-    def __init__(self, trainer, keys=None, mode=None):
+    def __init__(self, trainer, keys=None, mode=None, graph_floors=True):
         self.trainer = trainer
         self.keys = keys
+        self.graph_floors = graph_floors   # small images: the captured step takes the Winograd forms from fewer tiles / channels (ops.graph_dispatch); False = the eager selection, bit for bit
         self.mode = MODE if mode is None else mode
         self.graphs = {}             # key -> (graph, static inputs, pinned loss, workspace buffers kept alive)
         self.eager_steps = 0
@@ -115,10 +120,16 @@ class StepGraph:
         graph = torch.cuda.CUDAGraph()
         eager_ws, ops.workspace.buf = ops.workspace.buf, {}
         prev = hnn.begin_capture(host)
+        small = max(t.shape[-1] * t.shape[-2] for t in ins.values()) <= AUTO_MAX_PIXELS
+        floors = ops.graph_dispatch() if (self.graph_floors and small) else None
         try:
+            if floors is not None:
+                floors.__enter__()
             with torch.cuda.graph(graph):
                 self.trainer.train_step(sbatch)
         finally:
+            if floors is not None:
+                floors.__exit__(None, None, None)
             hnn.end_capture(prev)
             graph_ws, ops.workspace.buf = ops.workspace.buf, eager_ws
         return graph, static, host, graph_ws

@@ -1047,7 +1047,7 @@ WINOGRAD = os.environ.get("SSV_NO_WINOGRAD", "0") != "1"          # diagnostic s
 # gradient 1.97x; 7x7 x 512: 1.76 / 1.73 / 1.72; 28x28 x 128: 1.13 / 1.10 / 1.54; 56x56 x 64: 0.79 / 0.71 (the transforms move 9x the tensors
 # and that layer is HBM-heavy already) - so: at least 128 channels on both sides.
 WINOGRAD_MIN_CHANNELS = int(os.environ.get("SSV_WINOGRAD_MIN_CHANNELS", "128"))
-WINOGRAD_MIN_TILES = 256                                           # below that the three launches cost more than they save
+WINOGRAD_MIN_TILES = int(os.environ.get("SSV_WINOGRAD_MIN_TILES", "256"))     # below that the three launches cost more than they save
 
 
 def _lanes_ok(ch):
@@ -1086,7 +1086,7 @@ WINOGRAD44_MAX_RATIO_FWD_NO_V2 = float(os.environ.get("SSV_WINOGRAD44_FWD_RATIO"
 WINOGRAD44_MAX_CHANNELS = 512
 # ... and only for launches with enough tiles: 36 small GEMMs of a few row tiles each buy nothing over 16 (B = 64: 7x7 x 512, 256 tiles: 0.109 vs 0.116 ms) while
 # the larger rounding error stays - small batches keep F(2x2)
-WINOGRAD44_MIN_TILES = 1024
+WINOGRAD44_MIN_TILES = int(os.environ.get("SSV_WINOGRAD44_MIN_TILES", "1024"))
 # The weight gradient of a layer whose FORWARD ran F(4x4) takes F(4x4) too (round 5): its operand is the V the forward's input transform wrote anyway (no second,
 # F(2x2) transformed input), 36 products over a quarter of the tiles, a 2.25x dY transform.  Error against fp64 1.1 - 1.6e-6 relative (bar 2e-6: a weight gradient's
 # error never crosses a ReLU gate).  SSV_WINOGRAD44_WGRAD=0: those layers keep the F(2x2) operand and weight gradient (round 4's selection).
@@ -1136,6 +1136,26 @@ class large_batch_dispatch:
     def __exit__(self, *exc):
         global WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH
         WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES, DISPATCH = self.prev
+        return False
+
+
+class graph_dispatch:
+    """The kernel selection for a step that is being captured into a HIP graph (graph.StepGraph) on SMALL images: without a per-launch host cost the Winograd forms
+    pay from far fewer tiles and from 64 channels - their 16 / 36 batched products put 16 / 36 times the workgroups of the direct kernel on maps whose direct
+    launch fills a fraction of the chip (resnet18 at 32 x 32, batch 64: layer4's 3x3 is 32 workgroups walking 144 k-tiles each).  Measured through the graph,
+    ms per step at batch 64 / 512 (profiles/r05_cifar_wino_floors.txt): default floors 6.79 / 9.47, these 5.17 / 9.31; launched kernel by kernel the same
+    selection is SLOWER (10.6 vs 9.2 at batch 64: more launches) - hence only under capture."""
+    CHANNELS, TILES, TILES44 = 64, 64, 256
+
+    def __enter__(self):
+        global WINOGRAD_MIN_CHANNELS, WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES
+        self.prev = (WINOGRAD_MIN_CHANNELS, WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES)
+        WINOGRAD_MIN_CHANNELS, WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES = (min(self.prev[0], self.CHANNELS), min(self.prev[1], self.TILES), min(self.prev[2], self.TILES44))
+        return self
+
+    def __exit__(self, *exc):
+        global WINOGRAD_MIN_CHANNELS, WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES
+        WINOGRAD_MIN_CHANNELS, WINOGRAD_MIN_TILES, WINOGRAD44_MIN_TILES = self.prev
         return False
 
 

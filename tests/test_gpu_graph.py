@@ -39,7 +39,7 @@ def test_replayed_steps_are_bitwise_the_eager_steps(dev, algo):
     runs = {}
     for mode in ("eager", "graph"):
         t = _trainer(dev, algo)
-        sg = StepGraph(t, mode="1" if mode == "graph" else "0")
+        sg = StepGraph(t, mode="1" if mode == "graph" else "0", graph_floors=False)          # the eager kernel selection: bitwise comparable
         losses = []
         for i, batch in enumerate(batches):
             if i == 5:                                           # the schedule moves the learning rate: a new graph
@@ -57,6 +57,33 @@ def test_replayed_steps_are_bitwise_the_eager_steps(dev, algo):
     assert info["disabled"] is None and info["graphs"] >= 1 and info["replays"] >= 5, info
     assert all(np.isfinite(le)) and le == lg, (le, lg)
     assert torch.equal(pe, pg) and torch.equal(me, mg)
+
+
+def test_graph_kernel_selection_trains_like_the_eager_one(dev):
+    """The shipped graph (ops.graph_dispatch: Winograd from 64 tiles / 64 channels on small images) runs OTHER kernels than the eager step - same mathematics:
+    step 0..2 losses within 1e-4 relative of the eager run's (two fp32 evaluations of one trajectory), and the selection really differs."""
+    from ssv_amd import ops
+    from ssv_amd.graph import StepGraph
+    batches = _batches(dev, 6)
+    runs = {}
+    for mode in ("eager", "graph"):
+        t = _trainer(dev, "simclr")
+        sg = StepGraph(t, mode="1" if mode == "graph" else "0")
+        losses = [sg(b)["loss"] for b in batches[:2]]
+        prev, ops.DISPATCH = ops.DISPATCH, {}                                 # step 2: the capture in the graph run, one eager step in the other
+        try:
+            losses.append(sg(batches[2])["loss"])
+            one_step = dict(ops.DISPATCH)
+        finally:
+            ops.DISPATCH = prev
+        losses += [sg(b)["loss"] for b in batches[3:]]
+        runs[mode] = (losses, one_step, sg.describe())
+    (le, de, _), (lg, dg, info) = runs["eager"], runs["graph"]
+    assert info["replays"] >= 3 and info["disabled"] is None
+    assert sum(dg.values()) > sum(de.values()), (de, dg)                     # more products on the Winograd forms under capture
+    for a, b in zip(le[:4], lg[:4]):                                          # steps 0-1 are eager in both; 2-3 differ by the selection only
+        assert abs(a - b) <= 1e-4 * abs(a), (le, lg)
+    assert all(np.isfinite(lg))
 
 
 def test_auto_mode_graphs_small_images_only_and_unsafe_trainers_never(dev):
