@@ -31,9 +31,9 @@ import torch  # noqa: E402
 # rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh) and the per-layer operand-stream table of
 # tools/bench_conv.py.  Each file records the build it was measured on (src_sha16 = ssv_source_sha16() of the profiled library); counters of another
 # build are NOT replayed: the line then carries traffic: null and counters_stale: true.
-PMC_FILES = {"simclr": "r04_simclr_b%d_pmc_hbm_traffic.json", "dino": "r04_dino_b%d_pmc_hbm_traffic.json"}
-CONV_LAYER_FILE = "r04_conv_layers_b%d.csv"
-PMC_MFMA_FILES = {"simclr": "r04_simclr_b%d_pmc_mfma.json", "dino": "r04_dino_b%d_pmc_mfma.json"}
+PMC_FILES = {"simclr": "r05_simclr_b%d_pmc_hbm_traffic.json", "dino": "r05_dino_b%d_pmc_hbm_traffic.json"}
+CONV_LAYER_FILE = "r05_conv_layers_b%d.csv"
+PMC_MFMA_FILES = {"simclr": "r05_simclr_b%d_pmc_mfma.json", "dino": "r05_dino_b%d_pmc_mfma.json"}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -414,8 +414,8 @@ def update_check(device, algo, v1, v2):
     errs = []
     for p, s0, b0, a0 in zip(arena.params, start, before, after):
         d_cpu = (a0 - b0).double()
-        if float(d_cpu.norm()) < 1e-12:
-            continue
+        if float(d_cpu.norm()) <= 1e-6 * float(b0.double().norm()):      # a delta that is nothing but lr * decay * p plus rounding noise of an analytically zero
+            continue                                                     # gradient (a Linear bias in front of a BatchNorm): no statement to make about it
         d_hip = (p.detach().float().cpu() - s0).double()
         errs.append(float((d_hip - d_cpu).norm() / d_cpu.norm()))
     del hip_step
@@ -592,7 +592,7 @@ def config3_rank_emulation(device, train_step, step, b, n1_ms, world=8, warmup=2
                          "slot, all-reduce(SUM) = x world on the exchange stream; every kernel of the rank's step is the real one"}
 
 
-def other_config_leg(device, algo, tf, source, sample_ids, rows, cfg, warmup=2, steps=5):
+def other_config_leg(device, algo, tf, source, sample_ids, rows, cfg, warmup=3, steps=8):
     """BASELINE configs 4 (BYOL resnet50 bs 512 / GPU) and 5 (DINO ViT-S/16 multi-crop bs 128 / GPU) in the driver's default line: a fresh trainer,
     `warmup` + `steps` timed steps of its per-GPU workload, and a short parity gate against the CPU oracle at a small batch."""
     from ssv_amd.utils import augmentations
