@@ -510,6 +510,10 @@ int ssv_dino_center_update(int32_t K, int32_t rows1, const float* t1, int32_t ro
  * reference's clamp hooks torch.clamp(grad, -clip, clip) (models/dino.py:76-79) to the summed gradient first.  step >= 1. */
 int ssv_adamw(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float lr, float beta1, float beta2,
               float eps, float weight_decay, int64_t step, float clip, void* stream);
+/* The same update with the step count in device memory (*step_dev += 1 first; bc_dev: two floats of caller-owned scratch for the bias corrections): no launch
+ * argument changes from step to step, so the step can be replayed as a HIP graph. */
+int ssv_adamw_counted(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int64_t* step_dev, float* bc_dev, float clip, void* stream);
 
 /* MultiCrop (utils/augmentations.py:156-173): RandomResizedCrop(scale, ratio 3/4..4/3, BICUBIC) boxes drawn from the Philox
  * stream (seed, step, sample, view_base + crop), view_base >= 16; then crop + bicubic resize (align_corners = False, A = -0.75,

@@ -164,6 +164,7 @@ SIGNATURES = {
     "ssv_dino_loss": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "ssv_dino_center_update": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _f32, _vp, _vp]),
     "ssv_adamw": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "ssv_adamw_counted": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
     "ssv_multicrop_params": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, _vp, _i64, _vp, _vp]),
     "ssv_multicrop": (C.c_int, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ssv_negdot_pair_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -133,9 +133,10 @@ __global__ void __launch_bounds__(256) wn_bwd_k(int rows, int cols, const float*
 // ---- AdamW (torch.optim.AdamW semantics) with optional second gradient slab and element-wise clamp
 __global__ void adamw_k(int64_t n, float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g2,
                         float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
-                        float bc1, float rsqrt_bc2, float clip) {
+                        float bc1, float rsqrt_bc2, const float* __restrict__ bc_dev, float clip) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (bc_dev) { bc1 = bc_dev[0]; rsqrt_bc2 = bc_dev[1]; }      // ssv_adamw_counted: the bias corrections of a step count that lives in device memory
   float gi = g[i];
   if (g2) gi += g2[i];
   if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
@@ -145,6 +146,17 @@ __global__ void adamw_k(int64_t n, float* __restrict__ p, const float* __restric
   const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
   pi -= (lr / bc1) * (mi / denom);
   p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// one thread: step += 1, then the two bias-correction factors of that step (the arithmetic of ssv_adamw's host side, in double)
+__global__ void adamw_tick_k(int64_t* __restrict__ step, float b1, float b2, float* __restrict__ bc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    bc[0] = (float)bc1;
+    bc[1] = (float)(1.0 / sqrt(bc2));
+  }
 }
 
 }  // namespace
@@ -210,7 +222,21 @@ extern "C" int ssv_adamw(int64_t n, float* p, const float* g, const float* g2, f
   ProfScope ps(SSV_PROF_OPTIM, s);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, n, p, g, g2, m, v, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)(1.0 / sqrt(bc2)), clip);
+                     (float)bc1, (float)(1.0 / sqrt(bc2)), (const float*)nullptr, clip);
   SSV_CHECK_LAUNCH("adamw_k");
+  return SSV_OK;
+}
+
+// The same update with the step count in DEVICE memory: *step_dev is incremented and the bias corrections of the new count are formed on the device (bc_dev: two
+// floats of scratch the caller owns), so no argument of the launch changes from step to step - what a step replayed as a HIP graph needs (ssv_amd/graph.py).
+extern "C" int ssv_adamw_counted(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int64_t* step_dev, float* bc_dev, float clip, void* stream) {
+  SSV_REQUIRE(n > 0 && p && g && m && v && step_dev && bc_dev, "ssv_adamw_counted: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_OPTIM, s);
+  hipLaunchKernelGGL(adamw_tick_k, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev);
+  hipLaunchKernelGGL(adamw_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, n, p, g, g2, m, v, lr, beta1, beta2, eps, weight_decay,
+                     1.f, 1.f, (const float*)bc_dev, clip);
+  SSV_CHECK_LAUNCH("adamw_k(counted)");
   return SSV_OK;
 }

@@ -17,8 +17,9 @@ On small images the captured step also takes another kernel SELECTION than the e
 from 64 tiles and 64 channels, which is what turns batch 64 from 6.8 into 5.2 ms per step; ``graph_floors=False`` captures the eager selection (then the replayed
 steps are the eager steps bit for bit - tests/test_gpu_graph.py checks both).
 
-Not graphed (the call falls back to the eager step): a process group (collectives stay eager), AdamW (its bias-correction step count is a kernel argument:
-DINO), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
+Not graphed (the call falls back to the eager step): a process group (collectives stay eager), trainers that keep per-step state on the host (``graph_safe``
+False: MoCo's queue pointer), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
+AdamW is graphable because its step count lives in device memory (``ssv_adamw_counted``); DINO's per-epoch scalars (temperatures, weight decay) are part of the key.
 """
 import os
 
@@ -54,15 +55,15 @@ class StepGraph:
         return {k: batch[k] for k in keys}
 
     def _why_not(self, ins):
-        from .utils.train_utils import FusedSGD
+        from .utils.train_utils import FusedAdamW, FusedSGD
         if self.mode == "0":
             return "SSV_STEP_GRAPH=0"
         if not getattr(self.trainer, "graph_safe", False):
             return f"{type(self.trainer).__name__}.train_step keeps per-step state on the host (graph_safe is False)"
         if hdist.is_on():
             return "a process group is active (collectives stay eager)"
-        if not isinstance(getattr(self.trainer, "optim", None), FusedSGD):
-            return "the optimizer is not the fused SGD (AdamW's step count is a kernel argument)"
+        if not isinstance(getattr(self.trainer, "optim", None), (FusedSGD, FusedAdamW)):
+            return "the optimizer is neither the fused SGD nor the fused AdamW"
         if not ins or not all(t.is_cuda for t in ins.values()):
             return "the batch is not on the GPU"
         if self.mode == "auto" and max(t.shape[-1] * t.shape[-2] for t in ins.values()) > AUTO_MAX_PIXELS:
@@ -70,8 +71,13 @@ class StepGraph:
         return None
 
     def _key(self, ins):
+        """Everything a captured step bakes in: the input shapes and every scalar that reaches a kernel as an ARGUMENT - the optimizer's learning rate / weight
+        decay / momentum (or betas, epsilon, clamp), plus whatever the trainer names in ``graph_key()`` (DINO: temperatures, centre momentum)."""
         g = self.trainer.optim.param_groups[0]
-        return (tuple((k, tuple(t.shape), t.stride()) for k, t in sorted(ins.items())), float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]))
+        opt = tuple(sorted((k, float(v) if isinstance(v, (int, float)) else tuple(float(x) for x in v)) for k, v in g.items()
+                           if k in ("lr", "weight_decay", "momentum", "betas", "eps")))
+        extra = tuple(self.trainer.graph_key()) if hasattr(self.trainer, "graph_key") else ()
+        return (tuple((k, tuple(t.shape), t.stride()) for k, t in sorted(ins.items())), opt, float(getattr(self.trainer.optim, "clip", 0.0)), extra)
 
     # ---- the step ------------------------------------------------------------------------------------------------------------
     def __call__(self, batch):

@@ -91,6 +91,8 @@ class _DinoLossFn(torch.autograd.Function):
 
 class DINO(TwoViewTrainer):
     algo = "dino"
+    graph_safe = True    # every per-step quantity is device memory (AdamW's step count included: ssv_adamw_counted); per-epoch scalars are part of graph_key()
+    graph_inputs = ("global_1", "global_2", "local_1", "local_2")
     archs = tuple(NETWORKS)
 
     def _make_loaders(self):
@@ -145,6 +147,10 @@ class DINO(TwoViewTrainer):
         self.update_teacher_model(epoch)
         self.update_weight_decay(epoch)
         self.update_temperature(epoch)
+
+    def graph_key(self):
+        """Scalars that reach kernels as arguments and move with the epoch schedules: a HIP graph of the step is valid for one value of each (graph.StepGraph)."""
+        return (float(self.temp_student), float(self.temp_teacher), float(self.m))
 
     # ---- the step -------------------------------------------------------------------------------------------------
     def train_step(self, batch):

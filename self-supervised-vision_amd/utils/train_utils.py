@@ -101,6 +101,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = ops.fill_(torch.empty_like(self.arena.data), 0.0)
         self.clip = float(clip)
         self._steps = 0
+        # the step count lives in device memory (ssv_adamw_counted): nothing in the update's launch changes from step to step, so the training step can be
+        # replayed as a HIP graph (graph.StepGraph); _steps mirrors it on the host for readers
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.arena.data.device)
+        self._bc_dev = ops.fill_(torch.empty(4, dtype=torch.float32, device=self.arena.data.device), 0.0)
         self.grad_sync = None
 
     def zero_grad(self, set_to_none=False):
@@ -118,9 +122,9 @@ class FusedAdamW(torch.optim.Optimizer):
             g2 = None
         self._steps += 1
         ops.invalidate_weight_caches()
-        _lib.call("ssv_adamw", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._steps,
-                  self.clip, _lib.stream())
+        _lib.call("ssv_adamw_counted", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self._step_dev),
+                  _lib.ptr(self._bc_dev), self.clip, _lib.stream())
 
 
 def get_optimizer(config, params):

@@ -106,3 +106,57 @@ def test_auto_mode_graphs_small_images_only_and_unsafe_trainers_never(dev):
     t2 = _trainer(dev, "simclr")
     out = [t2.step(b)["loss"] for b in _batches(dev, 5)]
     assert all(np.isfinite(out)) and t2._step_graph.describe()["replays"] >= 2
+
+
+def test_adamw_with_the_step_count_in_device_memory_is_the_by_value_update(dev):
+    """ssv_adamw_counted (step count and bias corrections in device memory: what lets DINO's step be a graph) against ssv_adamw, three steps."""
+    from ssv_amd import _lib
+    n = 10_000
+    p0, g = seeded_randn(1, n).to(dev), [seeded_randn(2 + i, n).to(dev) for i in range(3)]
+    runs = []
+    for counted in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        step_dev, bc = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(4, device=dev)
+        for i in range(3):
+            if counted:
+                _lib.call("ssv_adamw_counted", n, _lib.ptr(p), _lib.ptr(g[i]), None, _lib.ptr(m), _lib.ptr(v), 1e-3, 0.9, 0.999, 1e-6, 0.04, _lib.ptr(step_dev), _lib.ptr(bc), 3.0, _lib.stream())
+            else:
+                _lib.call("ssv_adamw", n, _lib.ptr(p), _lib.ptr(g[i]), None, _lib.ptr(m), _lib.ptr(v), 1e-3, 0.9, 0.999, 1e-6, 0.04, i + 1, 3.0, _lib.stream())
+        runs.append((p, m, v))
+        if counted:
+            assert int(step_dev.item()) == 3
+    for a, b in zip(*runs):
+        assert float((a - b).abs().max()) <= 1e-7 * float(b.abs().max())
+
+
+def test_dino_step_replays_as_a_graph_through_an_epoch_schedule_change(dev):
+    """DINO (models/dino.py:143-169) on a small ViT: AdamW's step count lives in device memory, the per-epoch scalars (temperatures, weight decay) are part of the
+    graph's key - the replayed steps are bitwise the eager ones, before and after `_after_epoch` moves the schedules (a new capture)."""
+    import bench
+    from ssv_amd.graph import StepGraph
+    enc = {"hidden_dim": 128, "embedding_dim": 16, "intermediate_dim": 256, "num_attention_heads": 2, "patch_size": 4,
+           "num_local_patches": 4, "num_global_patches": 64, "num_encoder_layers": 2}
+    mk = lambda seed, v, sz: seeded_randn(seed, 8, v, 3, sz, sz).to(dev)
+    batches = [{"global_1": mk(10 * i, 2, 32), "global_2": mk(10 * i + 1, 2, 32), "local_1": mk(10 * i + 2, 4, 8), "local_2": mk(10 * i + 3, 4, 8)} for i in range(8)]
+    saved = bench.BENCH_CFG["dino"]
+    bench.BENCH_CFG["dino"] = dict(saved, encoder=enc, proj_head={"hidden_dim": 64, "proj_dim": 128})
+    try:
+        runs = {}
+        for mode in ("eager", "graph"):
+            step, _ = bench.build(dev, "dino")
+            t = step.trainer
+            t.config.update(epochs=10, temp_warmup_epochs=3)
+            sg = StepGraph(t, mode="1" if mode == "graph" else "0", graph_floors=False)
+            losses = []
+            for i, b in enumerate(batches):
+                if i == 5:
+                    t._after_epoch(1)                                  # teacher EMA, weight decay and teacher temperature move
+                losses.append(sg(b)["loss"])
+            torch.cuda.synchronize()
+            runs[mode] = (losses, t.optim.arena.data.clone(), t.teacher_center.clone(), sg.describe())
+    finally:
+        bench.BENCH_CFG["dino"] = saved
+    (le, pe, ce, _), (lg, pg, cg, info) = runs["eager"], runs["graph"]
+    assert info["disabled"] is None and info["replays"] >= 4, info
+    assert all(np.isfinite(le)) and le == lg, (le, lg)
+    assert torch.equal(pe, pg) and torch.equal(ce, cg)
