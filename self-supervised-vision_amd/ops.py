@@ -1340,6 +1340,8 @@ def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     dm = torch.empty((36, t, k), dtype=torch.float32, device=g.device)
     # the data gradient of the same layer follows (nn.conv: weight gradient first): when it will run F(4x4) too, its transformed input comes out of this pass
     both = WINOGRAD44_DY_BOTH and (lazy is not None or _use_wino44(n, h, w_, c, k, WINOGRAD44_MAX_RATIO_DGRAD))
+    if lazy is not None and not both:
+        raise _lib.SsvError("wino44_conv2d_wgrad: a LazyGrad needs the one-pass transform (ops.WINOGRAD44_DY_BOTH was switched off after the forward marked this layer)")
     if both:
         vd = torch.empty((36, t, k), dtype=torch.float32, device=g.device)
         dyin = _dyin_struct(lazy, 0, n) if lazy is not None else None
