@@ -222,3 +222,47 @@ def test_profiling_aggregators_classify_every_kernel_like_the_scope_it_runs_unde
     for name, cls in (("stem_fwd_rows_k<true>", "conv_fwd"), ("stem_wgrad_rows_k", "conv_wgrad"), ("wino44_dy_k", "conv_wgrad"), ("wgrad_reduce64_k", "conv_wgrad"),
                       ("void (anonymous namespace)::wino44_output_k<2>(int, int)", "conv_dgrad"), ("wino44_output_k<1>", "conv_fwd"), ("ntxent_merge_k", "loss")):
         assert kc.classify(name) == cls and kc.in_conv_family(name) == cls.startswith("conv_"), name
+
+
+def test_step_graph_falls_back_to_the_eager_step_where_a_graph_cannot_be(monkeypatch):
+    """graph.StepGraph's host logic without a GPU: the reasons it refuses (mode 0, unsafe trainer, wrong optimizer, CPU batch, large images under auto) all end in
+    trainer.train_step(batch) being called - the step never disappears - and the graph's key carries every scalar a captured step would bake in."""
+    from ssv_amd import graph
+    from ssv_amd.utils import train_utils
+
+    class _Opt:
+        param_groups = [{"lr": 0.2, "weight_decay": 1e-4, "momentum": 0.9, "nesterov": True}]
+        _steps, clip = 3, 0.0
+
+    class _T:
+        graph_safe, graph_inputs = True, ("aug_1", "aug_2")
+        optim = _Opt()
+        calls = 0
+
+        def train_step(self, batch):
+            self.calls += 1
+            return {"loss": 1.5}
+
+        def graph_key(self):
+            return (0.1, 0.04)
+
+    batch = {"aug_1": torch.zeros(2, 3, 8, 8), "aug_2": torch.zeros(2, 3, 8, 8), "label": torch.zeros(2)}
+    t = _T()
+    sg = graph.StepGraph(t, mode="1")
+    assert sg(batch) == {"loss": 1.5} and t.calls == 1 and "neither the fused SGD" in sg.describe()["disabled"]
+    monkeypatch.setattr(train_utils, "FusedSGD", _Opt)                       # now the optimizer qualifies: the CPU batch is what stops it
+    sg = graph.StepGraph(t, mode="1")
+    assert sg(batch) == {"loss": 1.5} and "not on the GPU" in sg.describe()["disabled"]
+    assert sg(batch) == {"loss": 1.5} and t.calls == 3                       # disabled: straight to the eager step
+    t.graph_safe = False
+    sg = graph.StepGraph(t, mode="1")
+    sg(batch)
+    assert "graph_safe" in sg.describe()["disabled"]
+    t.graph_safe = True
+    sg = graph.StepGraph(t, mode="0")
+    sg(batch)
+    assert sg.describe()["disabled"] == "SSV_STEP_GRAPH=0"
+    key = graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs})
+    assert key[1] == (("lr", 0.2), ("momentum", 0.9), ("weight_decay", 1e-4)) and key[3] == (0.1, 0.04) and key[0][0][1] == (2, 3, 8, 8)
+    t.optim.param_groups[0]["lr"] = 0.1
+    assert graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs}) != key     # the schedule moved: another graph
