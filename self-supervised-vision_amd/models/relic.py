@@ -16,6 +16,8 @@ from .byol import OnlineNetwork, TargetNetwork          # same MLP heads (models
 
 class ReLIC(TwoViewTrainer):
     algo = "relic"
+    graph_safe = True    # the step holds no per-step host state (tau / EMA run between steps, eagerly)
+    graph_inputs = ("img", "aug_1", "aug_2")
 
     def _build(self, arch):
         encoder, encoder_dim = NETWORKS[arch].values()
@@ -59,7 +61,13 @@ class ReLIC(TwoViewTrainer):
                 online_2 = self.online_network(img_2)
                 with torch.no_grad():
                     target_2 = self.target_network(img_2)
-        orig_features = self.online_network(img_orig)
+        # the third pass (the un-augmented image) accumulates its parameter gradients into view 0's slab: it runs on view 0's STREAM, behind both views (the
+        # reference's order of the BatchNorm running-statistics updates), so that its backward is serialised with view 0's on that stream - on the ambient stream
+        # the two backward passes walked the same layers at the same time and both read-modified-wrote the same gradient slab (found by the step-graph test:
+        # replays summed in another order than the eager run)
+        with hnn.parallel_views(self.device) as pv3:
+            with pv3.view(0):
+                orig_features = self.online_network(img_orig)
         loss = self.loss_fn(online_1, target_2, orig_features) + self.loss_fn(online_2, target_1, orig_features)
         loss_now = hnn.early_item(loss)                  # the scalar leaves for the host now; the backward does not wait for it, nor it for the backward
         self.optim.zero_grad()

@@ -58,6 +58,8 @@ class TargetNetwork(hnn.HipModule):
 
 class SimSiam(TwoViewTrainer):
     algo = "simsiam"
+    graph_safe = True    # the step holds no per-step host state (tau / EMA run between steps, eagerly)
+    graph_inputs = ("aug_1", "aug_2")
 
     def _build(self, arch):
         encoder, encoder_dim = NETWORKS[arch].values()

@@ -160,3 +160,30 @@ def test_dino_step_replays_as_a_graph_through_an_epoch_schedule_change(dev):
     assert info["disabled"] is None and info["replays"] >= 4, info
     assert all(np.isfinite(le)) and le == lg, (le, lg)
     assert torch.equal(pe, pg) and torch.equal(ce, cg)
+
+
+@pytest.mark.parametrize("algo", ["simsiam", "relic"])
+def test_sibling_steps_replay_bitwise(dev, algo):
+    """SimSiam (models/simsiam.py:122-132) and ReLIC (models/relic.py:124-135: three forwards, the un-augmented image as third input) through the step graph."""
+    from test_gpu_siblings import BASE, _bare
+    from ssv_amd.graph import StepGraph
+    from ssv_amd.models.relic import ReLIC
+    from ssv_amd.models.simsiam import SimSiam
+    cls, cfg = {"simsiam": (SimSiam, {**BASE, "proj_dim": 256, "bottleneck_dim": 64, "optimizer": {"name": "sgd", "lr": 0.05, "weight_decay": 1e-4}}),
+                "relic": (ReLIC, {**BASE, "proj_dim": 128, "tau": 0.996, "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1e-4},
+                                  "loss_fn": {"normalize": True, "temperature": 1.0, "alpha": 0.5}})}[algo]
+    batches = [{"img": seeded_randn(300 + 3 * i, 32, 3, 32, 32).to(dev), "aug_1": seeded_randn(301 + 3 * i, 32, 3, 32, 32).to(dev),
+                "aug_2": seeded_randn(302 + 3 * i, 32, 3, 32, 32).to(dev)} for i in range(6)]
+    runs = {}
+    for mode in ("eager", "graph"):
+        t = _bare(cls, dev, dict(cfg), loader_len=20)
+        sg = StepGraph(t, mode="1" if mode == "graph" else "0", graph_floors=False)
+        losses = []
+        for i, b in enumerate(batches):
+            losses.append(sg(b)["loss"])
+            t._after_step(i)
+        torch.cuda.synchronize()
+        runs[mode] = (losses, t.optim.arena.data.clone(), sg.describe())
+    (le, pe, _), (lg, pg, info) = runs["eager"], runs["graph"]
+    assert info["disabled"] is None and info["replays"] >= 3, info
+    assert all(np.isfinite(le)) and le == lg and torch.equal(pe, pg), (le, lg)
