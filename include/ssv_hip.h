@@ -206,11 +206,11 @@ int ssv_wino_dy_transform(int32_t N, int32_t H, int32_t W, int32_t K, const floa
 int ssv_wino_output_transform(int32_t N, int32_t H, int32_t W, int32_t K, const float* M, float* y, float* pmean, float* pm2,
                               const ssv_bn_gate* gate, void* stream);
 
-/* ---- Winograd F(4x4, 3x3) for the forward and the data gradient of the same layers (csrc/winograd44.hip) ------------------------------
+/* ---- Winograd F(4x4, 3x3) for the forward, the data gradient and (round 5, below) the weight gradient of the same layers (csrc/winograd44.hip) -----
  * 36 multiplies per channel pair and 4x4 output tile instead of 144 (F(2x2): 64), transformed input 2.25x the input instead of 4x; interpolation points
  * {0, 1, -1, 1/2, -2, inf}.  Its transforms multiply by constants (F(2x2)'s only add and halve): forward / data gradient are 2-3x the direct kernel's error
- * against fp64 (profiles/r04_probe_winograd44.txt), the weight gradient through it would be 7-8x and therefore stays on F(2x2) - ssv_wino44_input_transform
- * can leave that operand (V2, ssv_wino_input_transform's output) from the same pass over x.
+ * against fp64 (profiles/r04_probe_winograd44.txt).  ssv_wino44_input_transform can also leave the F(2x2) transformed input (V2, ssv_wino_input_transform's
+ * output) from the same pass over x - round 4's weight gradient ran on it; round 5's runs F(4x4) on V itself (ssv_wino44_dy_transform ... below).
  *   T = ssv_wino44_tiles = N * ceil(H/4) * ceil(W/4); V, M: [36][T][channels]; GEMMs: ssv_gemm_batched(36, T, C, K, V, U, M).
  *   Output-transform partials: one per ROW of tiles (4 x W pixels) - for the statistics only when H % 4 == 0, else one per image (equal groups required):
  *   ssv_wino44_groups(N, H, W, stats), ssv_wino44_stats_rows_per_group (the rows_per_group for ssv_bn_stats_finalize). */

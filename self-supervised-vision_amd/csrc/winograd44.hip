@@ -1,4 +1,5 @@
-// Winograd F(4x4, 3x3) for the forward and the data gradient of the stride-1 3x3 convolutions of the deep stages (networks/resnet.py:7-10, 56-58).
+// Winograd F(4x4, 3x3) for the forward, the data gradient and (round 5) the weight gradient of the stride-1 3x3 convolutions of the deep stages
+// (networks/resnet.py:7-10, 56-58).
 //
 // F(2x2, 3x3) (winograd.hip) runs these layers with 2.25x fewer multiplies than the direct convolution; F(4x4, 3x3) computes a 4x4 output tile from a 6x6
 // input tile with 36 multiplies per channel pair instead of 144 - 4x fewer (3.06x on 14x14 / 7x7 maps, whose tiles of 4 cover 16 / 8) - and its transformed
@@ -8,13 +9,16 @@
 //
 // Interpolation points {0, 1, -1, 1/2, -2, inf} - chosen for the smallest fp32 error among the sets tried (tools/probe/wino44_numerics.py): the transforms multiply
 // by constants up to 8 and 16/15, so the result is NOT as close to fp64 as F(2x2)'s (whose transforms only add and halve).  Measured against an fp64 convolution
-// (tools/probe_winograd44.py, profiles/r04_probe_winograd44.txt): forward / data gradient 2-3x the direct kernel's error, inside the go / no-go bar of 3x; the
-// WEIGHT gradient through F(4x4) would be 7-8x and stays on F(2x2): the forward's input transform therefore leaves BOTH transformed inputs - V (6x6 tiles, its own
-// GEMM operand) and V2 (the F(2x2) operand the weight gradient wants, winograd.hip's layout) - from one pass over x.
+// (tools/probe_winograd44.py, profiles/r04_probe_winograd44.txt): forward / data gradient 2-3x the direct kernel's error, inside the go / no-go bar of 3x.  The
+// WEIGHT gradient through F(4x4) is 3.6-4.4e-6 from fp64 with a plain fp32 accumulation over the tiles (round 4 kept it on F(2x2) for that: the input transform can
+// still leave that second operand, V2, from the same pass over x) and 1.2e-6 - F(2x2)'s own error - with BLOCKED accumulation (round 5: ssv_gemm_batched_wgrad_blocked,
+// profiles/r05_probe_winograd44_wgrad.txt): it now runs on V, the forward's own transformed input, and no second operand is written.
 //
 //   wino44_filter_k   g [K][3][3][C] (OHWI)   -> U [36][K][C]
 //   wino44_input_k    x [N][H][W][C] (+ fused BatchNorm + ReLU)  -> V [36][T][C]  (+ V2 [16][T2][C])
 //   wino44_output_k   M [36][T][K]            -> y [N][H][W][K]  (+ statistics partials | + ReLU gate and its partial sums)
+//   wino44_dy_k       dy [N][H][W][K]         -> dM [36][T][K] = A dY A^T         weight gradient: dU_p = dM_p^T . V_p, dg (+)= G^T dU G (wino44_dfilter_k)
+//   wino44_dy_both_k  dy (or g, x, BatchNorm-backward coefficients) -> dM AND the data gradient's transformed input, one pass
 #include "common.h"
 
 namespace {
