@@ -11,7 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import SsvError
 
 
@@ -540,17 +540,15 @@ def grouped_conv(tape, x, weight, groups, stride, pad):
 
 
 def _bn_order_wait(bn, x):
-    if _STREAMS:                               # running-stat update order across the two view streams: slot 0 first
-        st = torch.cuda.current_stream(x.device)
-        if _SLOT == 1 and bn._order_event is not None:
-            st.wait_event(bn._order_event)
+    if _STREAMS and _SLOT == 1 and bn._order_event is not None:     # running-stat update order across the two view streams: slot 0 first
+        torch.cuda.current_stream(x.device).wait_event(bn._order_event)
 
 
 def _bn_order_record(bn, x):
-    if _STREAMS and _SLOT == 0 and torch.cuda.current_stream(x.device) != torch.cuda.default_stream(x.device):
+    if _STREAMS and _SLOT == 0 and _lib.stream() != 0:              # on a view stream (the default stream's raw handle is 0): no Stream object per BatchNorm call
         if bn._order_event is None:
             object.__setattr__(bn, "_order_event", torch.cuda.Event())
-        bn._order_event.record(torch.cuda.current_stream(x.device))
+        bn._order_event.record()                                   # on the current stream
 
 
 def batchnorm(tape, x, bn, relu=False, residual=None, lazy=False, defer=False):
