@@ -115,3 +115,42 @@ def test_full_size_augmentation_is_shard_invariant(dev):
     part = tf.apply(source, ids, tf.draw(source, ids, 3))
     assert torch.equal(full[:, 128:256], part)
     assert torch.isfinite(full).all() and float(full.std()) > 0.5
+
+
+def test_the_drivers_default_bench_command_carries_every_block_of_the_line():
+    """`python bench.py` as the driver runs it (single GPU, no flags but a small batch / image so that the test takes a minute): ONE JSON line with the headline
+    fields, `roofline`, `cpu_baseline`, `parity_gate` (teacher-forced pass, the batch-512 kernel selection recorded), `config1` (step graph beside the eager step),
+    `config3_rank_emulation` (one rank of eight, emulated) and `other_configs.{byol, dino}` - every extra leg without an error string; and `--emulate-world 8`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WANDB_MODE="disabled")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "SSV_DIST_FORCE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "32", "--size", "64", "--prof-steps", "1"],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "parity_gate", "config1", "config3_rank_emulation", "other_configs"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["dtype"] == "f32" and out["vs_baseline"] is None and out["value"] > 0
+    gate = out["parity_gate"]
+    assert gate["teacher_forced_pass"] and max(gate["loss_rel_err_teacher_forced"]) <= 1e-4, gate
+    assert "winograd_launches_per_step" in gate["dispatch"]
+    emu = out["config3_rank_emulation"]
+    assert "error" not in emu and emu["emulated_world"] == 8 and emu["global_batch"] == 8 * 32 and emu["ms_per_step"] > 0 and emu["ntxent"]["splits"] >= 1, emu
+    for name in ("byol", "dino"):
+        leg = out["other_configs"][name]
+        assert "error" not in leg and leg["value"] > 0 and isinstance(leg["pass"], bool), leg
+    c1 = out["config1"]
+    assert c1["gpu"]["step_graph"]["replays"] > 0 and c1["gpu"]["step_graph"]["disabled"] is None and c1["loss_step0"]["rel_err"] < 1e-4, c1
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--emulate-world", "8", "--steps", "2", "--warmup", "1", "--batch", "32", "--size", "64",
+                          "--prof-steps", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["emulated_world"]["emulated_world"] == 8 and out["emulated_world"]["global_batch"] == 256 and len(out["emulated_world"]["gradient_buckets"]) >= 5
