@@ -132,8 +132,10 @@ def build(device, algo, steps_per_epoch=1000, lr_scale=1.0, arch="resnet50", red
     hdist.attach_grad_sync(t.optim, t._sync_modules())
     state = {"i": 0}
 
+    via_step = os.environ.get("SSV_BENCH_VIA_STEP", "0") == "1"      # diagnostic: the trainer's step() (= the step graph where SSV_STEP_GRAPH allows it) instead of train_step()
+
     def step(batch):
-        loss = t.train_step(batch)["loss"]
+        loss = (t.step(batch) if via_step else t.train_step(batch))["loss"]
         t._after_step(state["i"])                                # BYOL: tau schedule + EMA of the target, as in the train loop
         state["i"] += 1
         return loss
