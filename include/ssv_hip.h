@@ -542,6 +542,8 @@ int ssv_moco_loss_fwd_bwd(int32_t N, int32_t D, int32_t K, int32_t ldk, const fl
                           float* loss, float* dq_init, void* ws, size_t ws_bytes, void* stream);
 /* MemoryBank.add_batch (models/moco.py:32-37): bank[(ptr+i) % K] = keys[i] / max(||keys[i]||, eps) for i < n */
 int ssv_queue_push(int32_t K, int32_t D, float* bank, int32_t ptr, int32_t n, const float* keys, float eps, void* stream);
+/* The same push with the queue pointer in device memory (read by the kernel, advanced behind it): no launch argument changes from step to step (HIP-graph replay). */
+int ssv_queue_push_counted(int32_t K, int32_t D, float* bank, int32_t* ptr_dev, int32_t n, const float* keys, float eps, void* stream);
 
 /* linear probe (utils/eval_utils.py:37-76): NLLLoss(log_softmax(logits)) and accuracy of a [N][ld] logit matrix (first C columns
  * valid) against int32 labels; stats[0] = mean loss, stats[1] = fraction of rows whose arg-max is the label; dlogits (may be NULL)

@@ -172,6 +172,7 @@ SIGNATURES = {
     "ssv_relic_kl_fwd_bwd": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_moco_loss_fwd_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
     "ssv_queue_push": (C.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _f32, _vp]),
+    "ssv_queue_push_counted": (C.c_int, [_i32, _i32, _vp, _vp, _i32, _vp, _f32, _vp]),
     "ssv_softmax_ce_workspace_bytes": (_sz, [_i32]),
     "ssv_softmax_ce_fwd_bwd": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_sgd": (C.c_int, [_i64, _vp, _vp, _vp, _f32, _f32, _f32, C.c_int, C.c_int, _vp]),

@@ -128,15 +128,23 @@ __global__ void moco_loss_sum_k(int N, const double* __restrict__ part, float* _
 }
 
 // bank[(ptr + i) % K] = keys[i] / max(||keys[i]||, eps), i in [first, n): the rows a sequential push of n keys leaves behind
-__global__ void __launch_bounds__(256) queue_push_k(int K, int D, float* __restrict__ bank, int ptr, int first, int n, const float* __restrict__ keys, float eps) {
+// ptr_dev != NULL (ssv_queue_push_counted): the write position is read from device memory (and advanced by queue_advance_k behind this kernel), so the launch
+// carries no argument that changes from step to step - the step can be replayed as a HIP graph.
+__global__ void __launch_bounds__(256) queue_push_k(int K, int D, float* __restrict__ bank, int ptr, const int* __restrict__ ptr_dev, int first, int n,
+                                                    const float* __restrict__ keys, float eps) {
   const int lane = threadIdx.x & 63, i = first + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
+  if (ptr_dev) ptr = *ptr_dev;
   const float* src = keys + (int64_t)i * D;
   float s = 0.f;
   for (int d = lane; d < D; d += 64) s += src[d] * src[d];
   const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), eps);
   float* dst = bank + (int64_t)((ptr + i) % K) * D;
   for (int d = lane; d < D; d += 64) dst[d] = src[d] * inv;
+}
+
+__global__ void queue_advance_k(int K, int n, int* __restrict__ ptr_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ptr_dev = (*ptr_dev + n) % K;
 }
 
 }  // namespace
@@ -189,7 +197,19 @@ extern "C" int ssv_queue_push(int32_t K, int32_t D, float* bank, int32_t ptr, in
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_MISC, s);
   const int first = n > K ? n - K : 0;                        // earlier rows would be overwritten by later ones of the same push
-  hipLaunchKernelGGL(queue_push_k, dim3(cdiv(n - first, 4)), dim3(256), 0, s, K, D, bank, ptr, first, n, keys, eps);
+  hipLaunchKernelGGL(queue_push_k, dim3(cdiv(n - first, 4)), dim3(256), 0, s, K, D, bank, ptr, (const int*)nullptr, first, n, keys, eps);
   SSV_CHECK_LAUNCH("ssv_queue_push");
+  return SSV_OK;
+}
+
+// The same push with the queue pointer in DEVICE memory: rows go to (*ptr_dev + i) % K, then *ptr_dev = (*ptr_dev + n) % K (models/moco.py:31-36's pointer walk).
+extern "C" int ssv_queue_push_counted(int32_t K, int32_t D, float* bank, int32_t* ptr_dev, int32_t n, const float* keys, float eps, void* stream) {
+  SSV_REQUIRE(K > 0 && D > 0 && bank && ptr_dev && n > 0 && keys, "ssv_queue_push_counted: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_MISC, s);
+  const int first = n > K ? n - K : 0;
+  hipLaunchKernelGGL(queue_push_k, dim3(cdiv(n - first, 4)), dim3(256), 0, s, K, D, bank, 0, (const int*)ptr_dev, first, n, keys, eps);
+  hipLaunchKernelGGL(queue_advance_k, dim3(1), dim3(64), 0, s, K, n, ptr_dev);
+  SSV_CHECK_LAUNCH("ssv_queue_push_counted");
   return SSV_OK;
 }

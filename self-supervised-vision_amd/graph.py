@@ -18,7 +18,7 @@ from 64 tiles and 64 channels, which is what turns batch 64 from 6.8 into 5.2 ms
 steps are the eager steps bit for bit - tests/test_gpu_graph.py checks both).
 
 Not graphed (the call falls back to the eager step): a process group (collectives stay eager), trainers that keep per-step state on the host (``graph_safe``
-False: MoCo's queue pointer), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
+False - none of the shipped trainers any more: MoCo's queue pointer lives in device memory), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
 AdamW is graphable because its step count lives in device memory (``ssv_adamw_counted``); DINO's per-epoch scalars (temperatures, weight decay) are part of the key.
 """
 import os

@@ -15,8 +15,14 @@ from .heads import _fresh_linear
 
 class MemoryBank:
     def __init__(self, queue_size, feature_size, device):
-        self.size, self.ptr = int(queue_size), 0
+        self.size = int(queue_size)
         self.bank = ops.fill_(torch.empty(((self.size + 15) // 16 * 16, feature_size), dtype=torch.float32, device=device), 0.0)
+        # the write pointer lives in device memory (ssv_queue_push_counted reads and advances it): a replayed step (graph.StepGraph) moves it like an eager one
+        self._ptr_dev = torch.zeros(1, dtype=torch.int32, device=device)
+
+    @property
+    def ptr(self):
+        return int(self._ptr_dev.item())
 
     def add_batch(self, batch):
         """Data parallel: the keys of ALL ranks enter every rank's queue, in rank order - the replicas stay identical."""
@@ -27,7 +33,7 @@ class MemoryBank:
             allk = torch.empty((b * world, keys.shape[1]), dtype=keys.dtype, device=keys.device)
             allk[hdist.rank() * b:(hdist.rank() + 1) * b].copy_(keys)
             keys = hdist.all_gather_rows(allk, b)
-        self.ptr = ops.queue_push(self.bank, self.size, self.ptr, keys)
+        ops.queue_push_counted(self.bank, self.size, self._ptr_dev, keys)
 
     def get_vectors(self):
         return self.bank
@@ -48,6 +54,8 @@ class EncoderModel(hnn.HipModule):
 
 class MoCo(TwoViewTrainer):
     algo = "moco"
+    graph_safe = True    # the queue pointer is device memory (MemoryBank); momentum update and queue push are part of the step and of its graph
+    graph_inputs = ("aug_1", "aug_2")
 
     def _build(self, arch):
         encoder, encoder_dim = NETWORKS[arch].values()
@@ -69,6 +77,9 @@ class MoCo(TwoViewTrainer):
 
     def _embed(self, img):
         return self.query_encoder(img)
+
+    def graph_key(self):
+        return (float(self.m),)
 
     def train_step(self, batch):
         img_1, img_2 = batch["aug_1"].to(self.device), batch["aug_2"].to(self.device)

@@ -930,6 +930,13 @@ def queue_push(bank, queue_size, pointer, keys, eps=1e-12):
     return (pointer + keys.shape[0]) % queue_size
 
 
+def queue_push_counted(bank, queue_size, pointer_dev, keys, eps=1e-12):
+    """queue_push with the pointer in device memory (an int32 tensor of one element, advanced by the call): what a replayed step needs."""
+    _lib._dev(bank, keys, pointer_dev)
+    invalidate_weight_caches()
+    call("ssv_queue_push_counted", int(queue_size), bank.shape[1], ptr(bank), ptr(pointer_dev), keys.shape[0], ptr(keys), float(eps), stream())
+
+
 def linear_gelu_fwd(x, w, bias, keep_h=True):
     """(h, gelu(h)) with h = x w^T + bias, both written by one GEMM epilogue.  x [M, C] dense, w [K, C].  ``keep_h`` False (a forward without
     a backward): only gelu(h) is written and h comes back as None."""

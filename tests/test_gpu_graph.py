@@ -162,14 +162,18 @@ def test_dino_step_replays_as_a_graph_through_an_epoch_schedule_change(dev):
     assert torch.equal(pe, pg) and torch.equal(ce, cg)
 
 
-@pytest.mark.parametrize("algo", ["simsiam", "relic"])
+@pytest.mark.parametrize("algo", ["simsiam", "relic", "moco"])
 def test_sibling_steps_replay_bitwise(dev, algo):
-    """SimSiam (models/simsiam.py:122-132) and ReLIC (models/relic.py:124-135: three forwards, the un-augmented image as third input) through the step graph."""
+    """SimSiam (models/simsiam.py:122-132), ReLIC (models/relic.py:124-135: three forwards, the un-augmented image as third input) and MoCo (models/moco.py:113-125:
+    the queue's write pointer lives in device memory, its push and the key encoder's EMA are part of the step) through the step graph."""
     from test_gpu_siblings import BASE, _bare
     from ssv_amd.graph import StepGraph
+    from ssv_amd.models.moco import MoCo
     from ssv_amd.models.relic import ReLIC
     from ssv_amd.models.simsiam import SimSiam
-    cls, cfg = {"simsiam": (SimSiam, {**BASE, "proj_dim": 256, "bottleneck_dim": 64, "optimizer": {"name": "sgd", "lr": 0.05, "weight_decay": 1e-4}}),
+    cls, cfg = {"moco": (MoCo, {**BASE, "proj_dim": 128, "queue_size": 40, "momentum": 0.999, "optimizer": {"name": "sgd", "lr": 0.03, "weight_decay": 1e-4},
+                                "loss_fn": {"normalize": True, "temperature": 0.07}}),
+                "simsiam": (SimSiam, {**BASE, "proj_dim": 256, "bottleneck_dim": 64, "optimizer": {"name": "sgd", "lr": 0.05, "weight_decay": 1e-4}}),
                 "relic": (ReLIC, {**BASE, "proj_dim": 128, "tau": 0.996, "optimizer": {"name": "sgd", "lr": 0.2, "weight_decay": 1e-4},
                                   "loss_fn": {"normalize": True, "temperature": 1.0, "alpha": 0.5}})}[algo]
     batches = [{"img": seeded_randn(300 + 3 * i, 32, 3, 32, 32).to(dev), "aug_1": seeded_randn(301 + 3 * i, 32, 3, 32, 32).to(dev),
@@ -183,7 +187,10 @@ def test_sibling_steps_replay_bitwise(dev, algo):
             losses.append(sg(b)["loss"])
             t._after_step(i)
         torch.cuda.synchronize()
-        runs[mode] = (losses, t.optim.arena.data.clone(), sg.describe())
-    (le, pe, _), (lg, pg, info) = runs["eager"], runs["graph"]
+        extra = (t.memory_bank.bank.clone(), t.memory_bank.ptr) if algo == "moco" else None
+        runs[mode] = (losses, t.optim.arena.data.clone(), sg.describe(), extra)
+    (le, pe, _, xe), (lg, pg, info, xg) = runs["eager"], runs["graph"]
     assert info["disabled"] is None and info["replays"] >= 3, info
     assert all(np.isfinite(le)) and le == lg and torch.equal(pe, pg), (le, lg)
+    if algo == "moco":
+        assert xe[1] == xg[1] == (6 * 32) % 40 and torch.equal(xe[0], xg[0])          # the queue and its pointer moved alike

@@ -21,7 +21,7 @@ CLASSES = (
     ("pool", "maxpool_"), ("pool", "gap_"),
     ("misc", "gelu_"), ("misc", "colsum_"), ("misc", "wn_fwd_k"), ("misc", "wn_bwd_k"), ("misc", "knn_agree_k"), ("misc", "zero_count_k"), ("misc", "scale_k"), ("misc", "add_k"),
     ("misc", "fill_k"), ("misc", "pad_channels_k"), ("misc", "group_expand_k"), ("misc", "group_extract_k"), ("misc", "filter_transpose_k"), ("misc", "nchw_to_nhwc_k"),
-    ("misc", "nhwc_to_nchw_k"), ("misc", "queue_push_k"), ("misc", "vit_embed_"),
+    ("misc", "nhwc_to_nchw_k"), ("misc", "queue_push_k"), ("misc", "queue_advance_k"), ("misc", "vit_embed_"),
 )
 CONV_FAMILY = ("conv_fwd", "conv_dgrad", "conv_wgrad")
 # host functions whose kernels run under another class's scope than the table gives them - both inside the conv family, so the family sums agree:
