@@ -447,7 +447,8 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
 
         def bwd(dy, existing):
             ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine, wino_v=wino_v,
-                             dbias=None if bias is None else grad_of(bias, slot))
+                             dbias=None if bias is None else grad_of(bias, slot),
+                             dgrad_follows=need_dx and existing[0] is None)      # a plain data gradient follows: the Winograd dY transform writes its operand too
             if not need_dx:
                 return (None,)
             ex = existing[0]

@@ -379,12 +379,15 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
 FUSE_BIAS_GRAD = os.environ.get("SSV_NO_BIAS_GRAD_FUSION", "0") != "1"      # diagnostic switch: bias gradients by the stand-alone column-sum pass
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None, groups=1, dbias=None):
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=None, wino_v=None, groups=1, dbias=None, dgrad_follows=None):
     """dw (+)= wgrad.  ``dw`` has the memory layout of ``w_like`` (OHWI).  ``in_affine = (scale, shift)``: x is a raw conv output and
     the operand is relu(x * scale + shift), formed on load (the fused chain's never-materialised activation).  ``wino_v``: the transformed
     input the Winograd forward of this convolution kept - the weight gradient is then 16 batched GEMMs on it (x / in_affine are not read).
     ``groups`` > 1: ``dw`` is the dense block-diagonal layout of a grouped convolution's bank and ONLY its diagonal blocks are defined afterwards
     (what group_extract reads); tiles no group touches are skipped.
+    ``dgrad_follows`` (Winograd F(4x4) layers): will a PLAIN data gradient of the same dy follow (no addend, no accumulation target)?  Then the dY transform also
+    writes that product's transformed input (one pass over dy); False spares the extra 2.25x write when the data gradient will take another kernel; None = decide by
+    the dispatch rule alone.
     ``dbias``: the layer's bias gradient, (+)= the column sums of dy - taken from the same pass over dy when the layer is a Linear / 1x1 / stride-1
     one (the weight-gradient workgroups of column tile 0 sum the rows they stage), by the stand-alone column-sum kernel otherwise."""
     if dbias is not None:
@@ -415,7 +418,7 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, accumulate=True, in_affine=
             call("ssv_conv2d_wgrad_grouped", C.byref(d), int(groups), ptr(x[n0:n1]), ptr(dy[n0:n1]), ptr(dw), int(accumulate or i > 0), ptr(ws), ws.numel(), stream())
         return dw
     if wino_v is not None and (not isinstance(dy, LazyGrad) or (wino_v.shape[0] == 36 and WINOGRAD44_DY_BOTH)):
-        return wino_conv2d_wgrad(wino_v, dy, w_like, dw, accumulate=accumulate)
+        return wino_conv2d_wgrad(wino_v, dy, w_like, dw, accumulate=accumulate, dgrad_follows=dgrad_follows)
     lazy = dy if isinstance(dy, LazyGrad) else None
     if lazy is not None:
         dy = lazy.g
@@ -1311,10 +1314,10 @@ def wino_conv2d_dgrad(dy, w, gate=None):
     return dx
 
 
-def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
+def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True, dgrad_follows=None):
     """dw (+)= weight gradient of the 3x3 convolution whose transformed input V was kept by wino_conv2d_fwd ([16][T2][C]: F(2x2); [36][T][C]: F(4x4))."""
     if v.shape[0] == 36:
-        return wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate)
+        return wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate, dgrad_follows=dgrad_follows)
     _note("wino22_wgrad")
     _lib._dev(v, dy, dw)
     _, wshape = _ohwi(w_like)
@@ -1331,7 +1334,7 @@ def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     return dw
 
 
-def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
+def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True, dgrad_follows=None):
     """wino_conv2d_wgrad through F(4x4, 3x3): dM = A dY A^T, 36 products dU_p = dM_p^T V_p over the tiles, dw (+)= G^T dU G."""
     _note("wino44_wgrad")
     _lib._dev(v, dy.g if isinstance(dy, LazyGrad) else dy, dw)
@@ -1346,7 +1349,7 @@ def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True):
     g = lazy.g if lazy is not None else dy
     dm = torch.empty((36, t, k), dtype=torch.float32, device=g.device)
     # the data gradient of the same layer follows (nn.conv: weight gradient first): when it will run F(4x4) too, its transformed input comes out of this pass
-    both = WINOGRAD44_DY_BOTH and (lazy is not None or _use_wino44(n, h, w_, c, k, WINOGRAD44_MAX_RATIO_DGRAD))
+    both = WINOGRAD44_DY_BOTH and (lazy is not None or (dgrad_follows is not False and _use_wino44(n, h, w_, c, k, WINOGRAD44_MAX_RATIO_DGRAD)))
     if lazy is not None and not both:
         raise _lib.SsvError("wino44_conv2d_wgrad: a LazyGrad needs the one-pass transform (ops.WINOGRAD44_DY_BOTH was switched off after the forward marked this layer)")
     if both:
