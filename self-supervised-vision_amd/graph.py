@@ -111,6 +111,10 @@ class StepGraph:
         for k, t in ins.items():
             static[k].copy_(t, non_blocking=True)
         graph.replay()
+        # the replay changed the weights without running a line of Python: whatever an EAGER forward between replays (feature extraction, a ragged batch) cached of
+        # them - transposed filters, Winograd-transformed filters - is stale now (found by test_graph_survives_eager_work_between_replays: the second extraction used
+        # the first one's transformed filters)
+        ops.invalidate_weight_caches()
         torch.cuda.current_stream().synchronize()
         self.replays += 1
         return {"loss": float(host.item())}

@@ -194,3 +194,34 @@ def test_sibling_steps_replay_bitwise(dev, algo):
     assert all(np.isfinite(le)) and le == lg and torch.equal(pe, pg), (le, lg)
     if algo == "moco":
         assert xe[1] == xg[1] == (6 * 32) % 40 and torch.equal(xe[0], xg[0])          # the queue and its pointer moved alike
+
+
+def test_graph_survives_eager_work_between_replays_over_many_steps(dev):
+    """60 steps with everything a real run interleaves: eager feature extraction (train-mode BatchNorm forward: running statistics move, the eager workspace and the
+    weight caches are used) every 10 steps, a learning-rate change every 20 (re-capture), one ragged batch - parameters, momentum and BatchNorm running statistics
+    end up BITWISE where the eager run's do."""
+    from ssv_amd.graph import StepGraph
+    batches = _batches(dev, 6)
+    probe = seeded_randn(999, 48, 3, 32, 32).to(dev)
+    runs = {}
+    for mode in ("eager", "graph"):
+        t = _trainer(dev, "simclr")
+        sg = StepGraph(t, mode="1" if mode == "graph" else "0", graph_floors=False)
+        feats = []
+        for i in range(60):
+            if i and i % 20 == 0:
+                for g in t.optim.param_groups:
+                    g["lr"] *= 0.7
+            if i % 10 == 5:
+                with torch.no_grad():
+                    feats.append(t._features(probe).clone())
+            if i == 33:
+                sg({k: v[:24] for k, v in batches[0].items()})
+            sg(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        bn = torch.cat([b.flatten() for n, b in t.encoder.named_buffers() if "running" in n])
+        runs[mode] = (t.optim.arena.data.clone(), t.optim.momentum_buffer.clone(), bn.clone(), torch.stack(feats), sg.describe())
+    e, g = runs["eager"], runs["graph"]
+    assert g[4]["graphs"] == 1 and g[4]["replays"] >= 50 and g[4]["disabled"] is None, g[4]
+    for a, b, what in zip(e[:4], g[:4], ("parameters", "momentum", "BatchNorm running statistics", "features extracted between replays")):
+        assert torch.equal(a, b), what
