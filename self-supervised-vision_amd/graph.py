@@ -48,6 +48,7 @@ class StepGraph:
         self.seen = {}               # input-shape signature -> times met without a graph
         self.disabled = None         # reason, once capture has failed or the trainer is not graphable
         self.replays = 0
+        self.captures = 0
 
     # ---- eligibility ---------------------------------------------------------------------------------------------------------
     def _tensors(self, batch):
@@ -98,7 +99,13 @@ class StepGraph:
             if self.trainer.optim._steps < 1 or self.eager_steps < WARMUP_STEPS or (self.seen[shape_sig] < 2 and any(k[0] != shape_sig for k in self.graphs)):
                 self.eager_steps += 1
                 return self.trainer.train_step(batch)
+            if self.captures >= 8 and self.replays < 4 * self.captures:
+                # a scalar of the key moves nearly every step (a per-step learning-rate schedule): capturing costs more than launching - stay eager
+                self.disabled = f"{self.captures} captures for {self.replays} replays: a scalar baked into the graph changes too often"
+                self.graphs.clear()
+                return self.trainer.train_step(batch)
             try:
+                self.captures += 1
                 rec = self._capture(batch, ins, key)
             except Exception as exc:         # never take the training run down: the eager step is always there
                 self.disabled = f"capture failed: {type(exc).__name__}: {exc}"
@@ -145,4 +152,4 @@ class StepGraph:
         return graph, static, host, graph_ws
 
     def describe(self):
-        return {"mode": self.mode, "graphs": len(self.graphs), "replays": self.replays, "eager_steps": self.eager_steps, "disabled": self.disabled}
+        return {"mode": self.mode, "graphs": len(self.graphs), "captures": self.captures, "replays": self.replays, "eager_steps": self.eager_steps, "disabled": self.disabled}

@@ -225,3 +225,20 @@ def test_graph_survives_eager_work_between_replays_over_many_steps(dev):
     assert g[4]["graphs"] == 1 and g[4]["replays"] >= 50 and g[4]["disabled"] is None, g[4]
     for a, b, what in zip(e[:4], g[:4], ("parameters", "momentum", "BatchNorm running statistics", "features extracted between replays")):
         assert torch.equal(a, b), what
+
+
+def test_a_per_step_schedule_sends_the_graph_back_to_the_eager_step(dev):
+    """A learning rate that moves EVERY step would re-capture every step (a capture costs more than the launches it saves): after 8 captures with too few replays
+    the wrapper gives up for good and the steps go on eagerly."""
+    from ssv_amd.graph import StepGraph
+    t = _trainer(dev, "simclr")
+    sg = StepGraph(t, mode="1")
+    b = _batches(dev, 1)[0]
+    losses = []
+    for i in range(16):
+        for g in t.optim.param_groups:
+            g["lr"] = 0.2 * (1.0 - 0.01 * i)
+        losses.append(sg(b)["loss"])
+    info = sg.describe()
+    assert info["captures"] == 8 and info["graphs"] == 0 and "changes too often" in info["disabled"], info
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
