@@ -615,6 +615,30 @@ def other_config_leg(device, algo, tf, source, sample_ids, rows, cfg, warmup=3, 
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # the same trainer as rank 0 of 8 (BASELINE configs 4 / 5 are quoted "on 8xMI355X"): every data-parallel code path, transport replaced by device copies
+    from ssv_amd import distributed as hdist
+    emu = None
+    try:
+        t_ = train_step.trainer
+        mods = t_._sync_modules()
+        prev = hdist.emulate_world(8, 0)
+        try:
+            hdist.attach_grad_sync(t_.optim, mods)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            ems = (time.perf_counter() - t0) / 4 * 1e3
+            emu = {"emulated_world": 8, "ms_per_step": round(ems, 3), "compute_side_scaling_ceiling": round(dt * 1e3 / ems, 4),
+                   "gradient_buckets": len(t_.optim.grad_sync.buckets), "steps": 4, "warmup": 2}
+        finally:
+            hdist.detach_grad_sync(t_.optim, mods)
+            hdist.restore_world(prev)
+    except Exception as exc:
+        emu = {"error": f"{type(exc).__name__}: {exc}"}
     del step, train_step
     torch.cuda.empty_cache()
     s = source.shape[1]
@@ -625,7 +649,7 @@ def other_config_leg(device, algo, tf, source, sample_ids, rows, cfg, warmup=3, 
         flop, _ = step_work(algo, s, s, b)
     out = {"metric": f"images/sec {algo} per-GPU workload of BASELINE config {'5' if algo == 'dino' else '4'}", "value": round(b / dt, 2), "unit": "images/sec",
            "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "per_gpu_batch": b, "params": nparams, "last_loss": loss, "dtype": "f32",
-           "whole_step_mfma_frac": round(flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+           "whole_step_mfma_frac": round(flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "rank_of_8_emulation": emu}
     if algo == "dino":
         base, cpu_losses = cpu_baseline_dino(batch=2, steps=2)
         gate = parity_gate_dino(device, cpu_losses, batch=2, steps=3)

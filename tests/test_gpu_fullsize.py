@@ -147,6 +147,7 @@ def test_the_drivers_default_bench_command_carries_every_block_of_the_line():
     for name in ("byol", "dino"):
         leg = out["other_configs"][name]
         assert "error" not in leg and leg["value"] > 0 and isinstance(leg["pass"], bool), leg
+        assert "error" not in leg["rank_of_8_emulation"] and leg["rank_of_8_emulation"]["ms_per_step"] > 0, leg["rank_of_8_emulation"]
     c1 = out["config1"]
     assert c1["gpu"]["step_graph"]["replays"] > 0 and c1["gpu"]["step_graph"]["disabled"] is None and c1["loss_step0"]["rel_err"] < 1e-4, c1
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--emulate-world", "8", "--steps", "2", "--warmup", "1", "--batch", "32", "--size", "64",
