@@ -121,12 +121,25 @@ class TransformerEncoder(hnn.HipModule):
             raise NotImplementedError("return_attn: the fused attention kernel never materialises the probabilities")
         return super().forward(img)
 
+    _LAYERS_PER_STAGE = 3        # gradient buckets of ~20 MB for ViT-S (6.5 MB per layer): a few large collectives, each under the rest of the backward
+
+    def grad_stages(self):
+        """Gradient buckets of the data-parallel exchange (distributed.BucketedGradSync): token embedding + input projection, then the encoder layers in runs of
+        three - contiguous parameter runs of the optimizer's arena in forward order, reduced last-run-first while the backward walks on (round 4 reduced the ViT's
+        85 MB in one call at step())."""
+        first = list(self.projection_fc.parameters()) + list(self.embedding.parameters())
+        n = self._LAYERS_PER_STAGE
+        return [first] + [[p for layer in self.enc_layers[i:i + n] for p in layer.parameters()] for i in range(0, len(self.enc_layers), n)]
+
     def _run(self, tape, x):
         batch = x.shape[0]
         num_patches = (x.shape[1] // self.patch_size) * (x.shape[2] // self.patch_size)
         pos = self.embedding.table_for(num_patches)
+        hnn.stage_mark(tape, self, 0)
         tok, tokens = hnn.vit_embed(tape, x, self.embedding.cls_embedding.weight, pos, self.patch_size)
         h = self.projection_fc._run(tape, tok)
-        for layer in self.enc_layers:
+        for i, layer in enumerate(self.enc_layers):
+            if i % self._LAYERS_PER_STAGE == 0:
+                hnn.stage_mark(tape, self, 1 + i // self._LAYERS_PER_STAGE)      # fires in backward once this run's weight gradients are enqueued
             h = layer._run(tape, h, batch, tokens)
         return hnn.take_cls(tape, h, batch, tokens)

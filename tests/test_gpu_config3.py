@@ -246,3 +246,41 @@ def test_replicated_peer_emulation_equals_the_oracle_on_the_repeated_batch(dev):
         ref32 = ref.item() if ref32 is None else ref32
     np.testing.assert_allclose(loss.item(), ref32, rtol=1e-5)
     _check_against_fp64(opt.arena.grad.cpu(), grads[0], grads[1], (z1.grad, z2.grad), dzs[0], dzs[1])
+
+
+def test_vit_gradient_buckets_launch_from_the_backward_and_change_nothing(dev):
+    """BASELINE config 5 on 8 GPUs: the ViT's gradient exchange in buckets (embedding + projection, encoder layers in runs of three, the head) launched from the backward
+    pass - both student passes of a DINO step (global and local crops, two view slots) must have reported a bucket before it is reduced - against ONE reduction at
+    step(): the same parameters, bit for bit (emulated world of 8: the reduction is x 8 on the exchange stream)."""
+    import bench
+    from ssv_amd import distributed as hdist
+    enc = {"hidden_dim": 128, "embedding_dim": 16, "intermediate_dim": 256, "num_attention_heads": 2, "patch_size": 4,
+           "num_local_patches": 4, "num_global_patches": 64, "num_encoder_layers": 6}
+    mk = lambda seed, v, sz: seeded_randn(seed, 8, v, 3, sz, sz).to(dev)
+    batch = {"global_1": mk(1, 2, 32), "global_2": mk(2, 2, 32), "local_1": mk(3, 4, 8), "local_2": mk(4, 4, 8)}
+    saved = bench.BENCH_CFG["dino"]
+    bench.BENCH_CFG["dino"] = dict(saved, encoder=enc, proj_head={"hidden_dim": 64, "proj_dim": 128})
+    prev = hdist.emulate_world(WORLD, 0)
+    try:
+        runs = {}
+        for bucketed in (True, False):
+            step, _ = bench.build(dev, "dino")
+            t = step.trainer
+            hdist.detach_grad_sync(t.optim, t._sync_modules())
+            hdist.attach_grad_sync(t.optim, t._sync_modules(), bucketed=bucketed)
+            names = [b[0] for b in t.optim.grad_sync.buckets]
+            launched = []
+            inner = t.optim.grad_sync._launch
+            t.optim.grad_sync._launch = lambda b, inner=inner, sync=t.optim.grad_sync: (launched.append(sync.buckets[b][0]), inner(b))[1]
+            losses = [step(batch) for _ in range(2)]
+            torch.cuda.synchronize()
+            runs[bucketed] = (names, launched, losses, t.optim.arena.data.clone())
+    finally:
+        hdist.restore_world(prev)
+        bench.BENCH_CFG["dino"] = saved
+    names, launched, losses, params = runs[True]
+    assert names == ["TransformerEncoder.stage0", "TransformerEncoder.stage1", "TransformerEncoder.stage2", "EncoderModel.rest"], names
+    # the deepest run of layers first, the embedding last of the encoder; the head's parameters are the outer module's "rest": complete when its whole tape has run
+    assert launched[:4] == ["TransformerEncoder.stage2", "TransformerEncoder.stage1", "TransformerEncoder.stage0", "EncoderModel.rest"], launched
+    assert runs[False][0] == [] and runs[False][1] == []
+    assert losses == runs[False][2] and torch.equal(params, runs[False][3])
