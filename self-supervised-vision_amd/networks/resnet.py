@@ -72,7 +72,7 @@ class _ResidualUnit(hnn.HipModule):
             h = h1 if i == 1 else getattr(self, f"conv{i}")._run(tape, h, bn_stats=True)      # every conv here is followed by its BatchNorm
             closing = i == self.depth
             nxt = None if closing else getattr(self, f"conv{i + 1}")
-            fuse = nxt is not None and nxt.can_fuse_input()
+            fuse = nxt is not None and nxt.can_fuse_input(h.shape)       # h = this conv's output = the next conv's input (NHWC)
             h = hnn.batchnorm(tape, h, getattr(self, f"bn{i}"), relu=True, residual=shortcut if closing else None, lazy=fuse, defer=closing)
         return h
 

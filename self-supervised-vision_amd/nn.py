@@ -344,6 +344,7 @@ _FUSE_CLOSING = os.environ.get("SSV_NO_CLOSING_FUSION", "0") != "1"        # dia
 _CLOSING_HW = tuple(int(v) for v in os.environ.get("SSV_CLOSING_HW", "784,1000000000").split(","))
 _FUSE_SHORTCUT_GATE = os.environ.get("SSV_NO_SHORTCUT_GATE", "0") != "1"   # diagnostic switch: the projection shortcut's BatchNorm backward reduces in its own pass
 _FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
+_FUSE_NARROW_WINO = os.environ.get("SSV_NO_NARROW_WINO_INPUT_FUSION", "0") != "1"   # diagnostic switch: narrow (< 128 channels) Winograd layers get a materialised input
 _COMPACT_S2_DGRAD = os.environ.get("SSV_NO_COMPACT_S2_DGRAD", "0") != "1"        # diagnostic switch: the stride-2 shortcut's data gradient at full resolution
 
 
@@ -978,13 +979,17 @@ class HipConv2d(HipModule):
         """True when this convolution's forward leaves the BatchNorm statistics partials of its output (ssv_conv2d_fwd_stats)."""
         return _FUSE_BN_STATS and self.groups == 1 and self.weight.shape[1] % 32 == 0 and self.weight.shape[0] % 4 == 0
 
-    def can_fuse_input(self):
-        """True when this convolution can take a LazyAct (a never-written conv -> BN -> ReLU output) as its input."""
+    def can_fuse_input(self, x_shape=None):
+        """True when this convolution can take a LazyAct (a never-written conv -> BN -> ReLU output) as its input.  ``x_shape`` (NHWC of that input, when the
+        caller knows it) lets a narrow k x k layer say yes where it will run Winograd."""
         # a k x k filter re-stages (and re-transforms) every input element k*k times: with the 256 x 64 tile of narrow layers (cout < 128,
         # twice the staged A rows per thread) that VALU work costs more than the apply pass it saves (measured: layer1's 3x3 forward at
-        # 99 TFLOP/s fused against 116 on a materialised input, profiles/r02_*_conv_layers_*.csv); wider layers keep the fusion
+        # 99 TFLOP/s fused against 116 on a materialised input, profiles/r02_*_conv_layers_*.csv); wider layers keep the fusion - and so do narrow ones that
+        # run Winograd (round 5): the input transform forms BatchNorm + ReLU once per loaded element, whatever the filter size
         if self.weight.shape[2] > 1 and (not _FUSE_BN_APPLY_3X3 or self.weight.shape[0] < 128):
-            return False
+            if not (_FUSE_BN_APPLY_3X3 and _FUSE_NARROW_WINO and x_shape is not None and self.groups == 1
+                    and ops.use_winograd(tuple(self.weight.shape), self.stride, self.pad, tuple(x_shape), True)):
+                return False
         return _FUSE_BN_APPLY and _FUSE_BN_STATS and ops.can_fuse_conv_input(self.weight.shape[1] * self.groups, self.weight.shape[0], self.groups)
 
     def _run(self, tape, x, bn_stats=False, compact_dx=False):

@@ -1057,6 +1057,10 @@ WINOGRAD = os.environ.get("SSV_NO_WINOGRAD", "0") != "1"          # diagnostic s
 # gradient 1.97x; 7x7 x 512: 1.76 / 1.73 / 1.72; 28x28 x 128: 1.13 / 1.10 / 1.54; 56x56 x 64: 0.79 / 0.71 (the transforms move 9x the tensors
 # and that layer is HBM-heavy already) - so: at least 128 channels on both sides.
 WINOGRAD_MIN_CHANNELS = int(os.environ.get("SSV_WINOGRAD_MIN_CHANNELS", "128"))
+# Round 5: that verdict was F(2x2)'s.  With all three products on F(4x4) (2.25x instead of 4x transformed tensors, no second transformed input, one pass over dY) the
+# 64-channel 3x3 layers of layer1 (56x56) win too: same-box A/B 215.9 -> 210.7 ms per step (profiles/r05_probe_wino64_step_ab.txt).  Narrower layers than
+# WINOGRAD_MIN_CHANNELS therefore take Winograd from this width on - but only where F(4x4) is what runs (`_use_wino44`), never F(2x2).
+WINOGRAD44_MIN_CHANNELS = int(os.environ.get("SSV_WINOGRAD44_MIN_CHANNELS", "64"))
 WINOGRAD_MIN_TILES = int(os.environ.get("SSV_WINOGRAD_MIN_TILES", "256"))     # below that the three launches cost more than they save
 
 
@@ -1068,10 +1072,12 @@ def use_winograd(wshape, stride, pad, x_shape, want_stats):
     """Does this convolution run through F(2x2, 3x3)?  3x3 / stride 1 / padding 1, channel counts the transforms' lane mapping takes, enough
     tiles, every operand slice below the per-launch limit, and - when the statistics epilogue is wanted - a map that partitions evenly."""
     k, c, r, s_ = wshape
-    if not (WINOGRAD and r == 3 and s_ == 3 and stride == 1 and pad == 1 and _lanes_ok(c) and _lanes_ok(k)
-            and min(c, k) >= WINOGRAD_MIN_CHANNELS):
+    if not (WINOGRAD and r == 3 and s_ == 3 and stride == 1 and pad == 1 and _lanes_ok(c) and _lanes_ok(k)):
         return False
     n, h, w_ = x_shape[0], x_shape[1], x_shape[2]
+    if min(c, k) < WINOGRAD_MIN_CHANNELS:          # narrow layers: only where every product runs F(4x4) (forward / data / weight gradient share the 0.75 ratio rule)
+        if not (min(c, k) >= WINOGRAD44_MIN_CHANNELS and WINOGRAD44_WGRAD and _use_wino44(n, h, w_, c, k, WINOGRAD44_MAX_RATIO_DGRAD)):
+            return False
     t = n * ((h + 1) // 2) * ((w_ + 1) // 2)
     if t < WINOGRAD_MIN_TILES or t * max(c, k) >= _MAX_ELEMS:
         return False
