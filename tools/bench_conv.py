@@ -117,7 +117,8 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     # closing activation of the previous unit formed and written by conv1 on such maps (every conv1 but the first one, whose input is the pool's)
     # the step hands a k x k convolution with fewer than 128 output channels a MATERIALISED activation (nn.HipConv2d.can_fuse_input: re-transforming each element
     # k*k times costs more than the apply pass saves there): layer1's 3x3 runs the plain statistics variant, its gate reads the byte mask
-    lazy_in = kind == "lazy" and ops.can_fuse_conv_input(Cx, K) and not (R > 1 and K < 128)
+    # ... unless that narrow layer runs Winograd (round 5: 64 channels on F(4x4)): its input transform forms BatchNorm + ReLU on load (nn.HipConv2d.can_fuse_input)
+    lazy_in = kind == "lazy" and ops.can_fuse_conv_input(Cx, K) and (not (R > 1 and K < 128) or ops.use_winograd(tuple(w.shape), s, p, x.shape, True))
     big = Ho * Ho >= 784
     dyl = ops.LazyGrad(dy, torch.randn_like(y), torch.randn(4, K, device=dev).contiguous()) if (big and C != 3 and ops.can_lazy_dy(w.shape, s, p)) else None
     sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= 784 and ops.can_form_closing_sum(w.shape, s, p)
