@@ -455,11 +455,7 @@ def read_committed_counters(profiles_dir, fname):
     return data, data.get("src_sha16"), rel
 
 
-def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
-    """BASELINE config 1 / BASELINE.md section 2: the reference's own CPU-runnable case - SimCLR resnet18 (reduce_bottom_conv) on 32 x 32 images at
-    batch 64 with configs/simclr.yaml's hyper-parameters (configs/simclr.yaml:38-39) - as `cpu_steps` timed steps of the CPU oracle on this
-    box's host cores, next to the same step on the HIP path (same views, fresh trainers on both sides; step-0 loss compared)."""
-    import oracle
+def _config1_views(device, batch):
     from ssv_amd.utils import augmentations
     g = torch.Generator(device=device).manual_seed(421)
     source = torch.randint(0, 256, (batch, 32, 32, 3), generator=g, device=device, dtype=torch.uint8)
@@ -469,7 +465,12 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
     cfg["normalize"] = {"mean": [0.4914, 0.4822, 0.4465], "std": [0.2470, 0.2435, 0.2616]}
     tf = augmentations.get_transform(cfg)
     views = tf.apply(source, ids, tf.draw(source, ids, 0))
-    v1, v2 = views[0], views[1]
+    return views[0], views[1]
+
+
+def config1_hip(device, batch=64, gpu_steps=50, graph=True):
+    """The HIP side of config 1: step-0 loss, `gpu_steps` timed eager steps, then (graph=True) the same trainer's step() replayed as one HIP graph."""
+    v1, v2 = _config1_views(device, batch)
     hip_step, _ = build(device, "simclr", arch="resnet18", reduce_bottom_conv=True)
     lr = hip_step.trainer.optim.param_groups[0]["lr"]                  # 2.0 seeded to 1e-12 + 0.2 by get_scheduler, as in the reference
     hip0 = hip_step({"aug_1": v1, "aug_2": v2})
@@ -480,19 +481,43 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
     for _ in range(gpu_steps):
         hip_step({"aug_1": v1, "aug_2": v2})
     torch.cuda.synchronize()
-    eager_dt = (time.perf_counter() - t0) / gpu_steps
-    # the same trainer's step through TwoViewTrainer.step: replayed as ONE HIP graph at this size (ssv_amd.graph.StepGraph, SSV_STEP_GRAPH=auto)
-    t = hip_step.trainer
-    for _ in range(3):
-        t.step({"aug_1": v1, "aug_2": v2})
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(gpu_steps):
-        t.step({"aug_1": v1, "aug_2": v2})
-    torch.cuda.synchronize()
-    gpu_dt = (time.perf_counter() - t0) / gpu_steps
-    graph_state = t._step_graph.describe()
-    del hip_step
+    res = {"lr": lr, "hip0": hip0, "eager_dt": (time.perf_counter() - t0) / gpu_steps, "graph_dt": None, "step_graph": None}
+    if graph:
+        # the same trainer's step through TwoViewTrainer.step: replayed as ONE HIP graph at this size (ssv_amd.graph.StepGraph, SSV_STEP_GRAPH=auto)
+        t = hip_step.trainer
+        for _ in range(3):
+            t.step({"aug_1": v1, "aug_2": v2})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(gpu_steps):
+            t.step({"aug_1": v1, "aug_2": v2})
+        torch.cuda.synchronize()
+        res["graph_dt"] = (time.perf_counter() - t0) / gpu_steps
+        res["step_graph"] = t._step_graph.describe()
+    return res
+
+
+def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
+    """BASELINE config 1 / BASELINE.md section 2: the reference's own CPU-runnable case - SimCLR resnet18 (reduce_bottom_conv) on 32 x 32 images at
+    batch 64 with configs/simclr.yaml's hyper-parameters (configs/simclr.yaml:38-39) - as `cpu_steps` timed steps of the CPU oracle on this
+    box's host cores, next to the same step on the HIP path (same views, fresh trainers on both sides; step-0 loss compared).  The HIP side runs in a CHILD
+    process (``bench.py --config1-child``): a fault there (HIP-graph replay is the youngest code of the path) costs this block, never the headline line."""
+    import subprocess
+    import oracle
+    hip, child_error = None, None
+    try:
+        proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--config1-child", str(batch), str(gpu_steps)], capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if proc.returncode == 0 and lines:
+            hip = json.loads(lines[-1])
+        else:
+            child_error = f"child exit code {proc.returncode}: {proc.stderr.strip().splitlines()[-1] if proc.stderr.strip() else 'no output'}"
+    except Exception as exc:
+        child_error = f"{type(exc).__name__}: {exc}"
+    if hip is None:                                                    # the eager step in this process; the graph figure is then absent, with the reason
+        hip = config1_hip(device, batch, gpu_steps, graph=False)
+    lr, hip0, eager_dt = hip["lr"], hip["hip0"], hip["eager_dt"]
+    v1, v2 = _config1_views(device, batch)
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     m = oracle.SimCLROracle("resnet18", True, 128, lr=lr, weight_decay=1e-4)
     c1, c2 = v1.cpu().contiguous(), v2.cpu().contiguous()
@@ -501,15 +526,20 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
     for _ in range(cpu_steps):
         m.train_step(c1, c2)
     cpu_dt = (time.perf_counter() - t0) / cpu_steps
+    eager = {"value": round(batch / eager_dt, 1), "ms_per_step": round(eager_dt * 1e3, 3),
+             "sample": f"{gpu_steps} timed steps (5 warm-up) of train_step() launched kernel by kernel"}
+    if hip["graph_dt"] is not None:
+        gpu_dt = hip["graph_dt"]
+        gpu = {"value": round(batch / gpu_dt, 1), "unit": "images/sec", "ms_per_step": round(gpu_dt * 1e3, 3),
+               "sample": f"{gpu_steps} timed steps of the HIP trainer's step() on the same views, loss read every step: the step replayed as one HIP graph "
+                         "(ssv_amd.graph.StepGraph; ~490 launches whose host enqueue time equals the GPU's work at this size); measured in a child process",
+               "step_graph": hip["step_graph"], "eager": eager}
+    else:
+        gpu = dict(eager, unit="images/sec", step_graph={"error": child_error})
     return {"workload": f"SimCLR resnet18 (reduce_bottom_conv) 32x32, batch {batch}, configs/simclr.yaml hyper-parameters (lr seeded to {lr:.3g}), synthetic uint8 source -> GPU two-view augmentation",
             "cpu": {"value": round(batch / cpu_dt, 1), "unit": "images/sec", "ms_per_step": round(cpu_dt * 1e3, 2), "cores": torch.get_num_threads(), "kind": "port",
                     "sample": f"{cpu_steps} timed steps (1 warm-up) of the oracle, torch fp32 CPU"},
-            "gpu": {"value": round(batch / gpu_dt, 1), "unit": "images/sec", "ms_per_step": round(gpu_dt * 1e3, 3),
-                    "sample": f"{gpu_steps} timed steps of the HIP trainer's step() on the same views, loss read every step: the step replayed as one HIP graph "
-                              "(ssv_amd.graph.StepGraph; ~490 launches whose host enqueue time equals the GPU's work at this size)",
-                    "step_graph": graph_state,
-                    "eager": {"value": round(batch / eager_dt, 1), "ms_per_step": round(eager_dt * 1e3, 3),
-                              "sample": f"{gpu_steps} timed steps (5 warm-up) of train_step() launched kernel by kernel"}},
+            "gpu": gpu,
             "loss_step0": {"hip": round(hip0, 7), "cpu": round(cpu0, 7), "rel_err": float(f"{abs(hip0 - cpu0) / abs(cpu0):.2e}")}}
 
 
@@ -660,7 +690,19 @@ def other_config_leg(device, algo, tf, source, sample_ids, rows, cfg, warmup=3, 
     return out
 
 
+def config1_child(argv):
+    """``bench.py --config1-child BATCH STEPS``: the HIP side of config_1's block, alone in this process; one JSON line on stdout."""
+    from ssv_amd import _lib
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py --config1-child needs an MI355X")
+    _lib.load()
+    device = torch.device("cuda", torch.cuda.current_device())
+    print(json.dumps(config1_hip(device, int(argv[0]), int(argv[1]))), flush=True)
+
+
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--config1-child":
+        return config1_child(sys.argv[2:4])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

@@ -21,7 +21,10 @@ Not graphed (the call falls back to the eager step): a process group (collective
 False - none of the shipped trainers any more: MoCo's queue pointer lives in device memory), a batch whose shapes have no graph yet and differ from the common one only once (the ragged last batch of an epoch runs eagerly).
 AdamW is graphable because its step count lives in device memory (``ssv_adamw_counted``); DINO's per-epoch scalars (temperatures, weight decay) are part of the key.
 """
+import atexit
+import gc
 import os
+import weakref
 
 import torch
 
@@ -35,11 +38,26 @@ AUTO_MAX_PIXELS = 64 * 64            # per image: CIFAR (32 x 32) and the like; 
 WARMUP_STEPS = 2                     # eager steps before a capture: the optimizer's first update (its first-step flag is a kernel argument), allocator warm-up
 
 
-class StepGraph:
-    """``sg = StepGraph(trainer); metrics = sg(batch)`` - the drop-in for ``trainer.train_step(batch)``."""
+_LIVE = weakref.WeakSet()          # every StepGraph that may hold graphs: closed at interpreter exit, while the HIP runtime is still up
 
-    def __init__(self, trainer, keys=None, mode=None, graph_floors=True):
-        self.trainer = trainer
+
+def _close_all():
+    """Graph objects must not be left to interpreter finalisation: a CUDAGraph destroyed after the HIP runtime's own teardown aborts the process (seen once as
+    'Aborted (core dumped)' AFTER a green pytest run - the exit code of the whole session was lost)."""
+    for sg in list(_LIVE):
+        sg.close()
+
+
+atexit.register(_close_all)
+
+
+class StepGraph:
+    """``sg = StepGraph(trainer); metrics = sg(batch)`` - the drop-in for ``trainer.train_step(batch)``.  ``weak=True`` (what TwoViewTrainer.step passes: the trainer
+    holds its StepGraph) holds the trainer weakly: no reference cycle, so dropping the trainer destroys its graphs at once - by reference count, at a defined point -
+    and not whenever the cycle collector runs."""
+
+    def __init__(self, trainer, keys=None, mode=None, graph_floors=True, weak=False):
+        self._trainer = weakref.ref(trainer) if weak else (lambda: trainer)
         self.keys = keys
         self.graph_floors = graph_floors   # small images: the captured step takes the Winograd forms from fewer tiles / channels (ops.graph_dispatch); False = the eager selection, bit for bit
         self.mode = MODE if mode is None else mode
@@ -49,6 +67,26 @@ class StepGraph:
         self.disabled = None         # reason, once capture has failed or the trainer is not graphable
         self.replays = 0
         self.captures = 0
+
+    @property
+    def trainer(self):
+        t = self._trainer()
+        if t is None:
+            raise RuntimeError("StepGraph: the trainer it was built for no longer exists")
+        return t
+
+    def close(self):
+        """Destroy every captured graph now (idle device, no capture in progress)."""
+        if self.graphs:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.graphs.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- eligibility ---------------------------------------------------------------------------------------------------------
     def _tensors(self, batch):
@@ -139,16 +177,22 @@ class StepGraph:
         prev = hnn.begin_capture(host)
         small = max(t.shape[-1] * t.shape[-2] for t in ins.values()) <= AUTO_MAX_PIXELS
         floors = ops.graph_dispatch() if (self.graph_floors and small) else None
+        trainer = self.trainer
+        gc_was_on = gc.isenabled()
+        gc.disable()                       # no destructor of an unrelated object (another trainer's graphs, events) may run in the middle of a stream capture
         try:
             if floors is not None:
                 floors.__enter__()
             with torch.cuda.graph(graph):
-                self.trainer.train_step(sbatch)
+                trainer.train_step(sbatch)
         finally:
+            if gc_was_on:
+                gc.enable()
             if floors is not None:
                 floors.__exit__(None, None, None)
             hnn.end_capture(prev)
             graph_ws, ops.workspace.buf = ops.workspace.buf, eager_ws
+        _LIVE.add(self)
         return graph, static, host, graph_ws
 
     def describe(self):

@@ -171,7 +171,7 @@ class TwoViewTrainer:
         sg = self.__dict__.get("_step_graph")
         if sg is None:
             from ..graph import StepGraph
-            sg = self._step_graph = StepGraph(self)
+            sg = self._step_graph = StepGraph(self, weak=True)
         return sg(batch)
 
     def _run_epoch(self, tag):

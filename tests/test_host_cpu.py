@@ -275,3 +275,25 @@ def test_step_graph_falls_back_to_the_eager_step_where_a_graph_cannot_be(monkeyp
     assert key[1] == (("lr", 0.2), ("momentum", 0.9), ("weight_decay", 1e-4)) and key[3] == (0.1, 0.04) and key[0][0][1] == (2, 3, 8, 8)
     t.optim.param_groups[0]["lr"] = 0.1
     assert graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs}) != key     # the schedule moved: another graph
+
+
+def test_step_graph_lifetime_rules():
+    """graph.StepGraph: held weakly by the trainer's own step() (no cycle: the graphs die with the trainer, by reference count), strongly when built by hand; every
+    live one is emptied by the interpreter-exit hook while the HIP runtime is still up."""
+    import gc
+    from ssv_amd import graph
+
+    class T:
+        graph_safe = True
+    t = T()
+    weak = graph.StepGraph(t, weak=True)
+    strong = graph.StepGraph(T())
+    assert weak.trainer is t and isinstance(strong.trainer, T)
+    del t
+    gc.collect()
+    with pytest.raises(RuntimeError, match="no longer exists"):
+        weak.trainer
+    strong.graphs["k"] = ("graph", {}, None, {})
+    graph._LIVE.add(strong)
+    graph._close_all()
+    assert strong.graphs == {}
