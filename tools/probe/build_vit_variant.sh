@@ -7,6 +7,7 @@
 #   w0 w1 w2 w4 w8 w15 w16 w31   tools/exp/r05_attn_whatif.patch  -DSSV_ATTN_WHATIF=<n>
 #   p3 p2 late3 late2            tools/exp/r05_attn_persistent_forward.patch  [-DSSV_ATTN_FWD_OCC=2] [-DSSV_ATTN_QNEXT_LATE]
 #   grid                         tools/exp/r05_attn_grid.patch
+#   stagger                      tools/exp/r05_attn_stagger.patch   (run with SSV_ATTN_STAGGER=<n>)
 #   bwd_new / bwd_old            tools/exp/r05_attn_bwd_loads.patch  [-DSSV_ATTN_BWD_LOADS_AT_TOP]
 set -e
 NAME=$1; PATCH=$2; shift 2
