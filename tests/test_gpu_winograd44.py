@@ -105,6 +105,30 @@ def _wgrad64(a, dy):
     return out
 
 
+@pytest.mark.parametrize("n,h,c", [(37, 28, 128), (24, 14, 256), (9, 56, 64), (130, 7, 512), (3, 12, 128)])
+def test_weight_gradient_through_f44_on_ragged_tile_counts(dev, n, h, c):
+    """The blocked accumulation of the F(4x4) weight gradient (row chunks of 512 tiles folded in fp64, a flush every 128 rows inside the kernel) on tile counts that are
+    no multiple of either: 37 x 49 = 1,813 (three chunks + 277 = two flushes + 21), 24 x 16 = 384 (below one chunk), 9 x 196 = 1,764 on the 64-channel layer, 130 x 4 = 520
+    (one chunk + 8), 3 x 9 = 27 (below one flush; 12 x 12 maps) - same bar as at the bench batch."""
+    from ssv_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(n, h, h, c, device=dev, generator=g)
+    w = (torch.randn(c, c, 3, 3, device=dev, generator=g) * (2.0 / (9 * c)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, h, h, c, device=dev, generator=g)
+    aff = (torch.rand(c, device=dev, generator=g) + 0.5, torch.randn(c, device=dev, generator=g) * 0.1)
+    ref = _wgrad64(torch.relu(x * aff[0] + aff[1]), dy)
+    _, _, v4 = ops.wino44_conv2d_fwd(x, w, in_affine=aff, want_stats=False, keep_v=True)
+    assert v4.shape[0] == 36
+    dw = torch.full_like(w, 7.0)                               # accumulate=False must overwrite
+    ops.wino_conv2d_wgrad(v4, dy, w, dw, accumulate=False)
+    err = float((dw.double() - ref).norm() / ref.norm())
+    assert err <= 2e-6, err
+    acc = dw.clone()
+    ops.wino_conv2d_wgrad(v4, dy, w, acc, accumulate=True)     # ... and accumulate=True adds exactly one more copy
+    err2 = float((acc.double() - 2 * ref).norm() / (2 * ref.norm()))
+    assert err2 <= 2e-6, err2
+
+
 @pytest.mark.parametrize("h,c", [(28, 128), (14, 256), (7, 512)])
 def test_weight_gradient_through_f44_at_batch_512_within_2e6_of_fp64(dev, h, c):
     """The bar the F(4x4) weight gradient ships under (round-4 review): relative l2 error of dW against fp64 <= 2e-6 on the three ResNet-50 Winograd shapes AT THE
