@@ -38,6 +38,39 @@ def test_default_splits_fill_the_device_at_the_config3_shape():
     assert lib.ssv_ntxent_split_workspace_bytes(512, 128, 1) == 0
 
 
+@pytest.mark.parametrize("nglob,b,seg0,d", [(96, 24, 48, 128), (50, 50, 0, 64), (200, 40, 120, 128), (33, 11, 22, 96)])
+@pytest.mark.parametrize("splits", [2, 3, 7, 64])
+def test_ntxent_column_splits_on_ragged_shapes(dev, nglob, b, seg0, d, splits):
+    """The column-split row kernels on shapes that are no multiple of anything - row blocks of 48 / 100 / 80 / 22 rows (partial 32-row tiles), 2 Nglob = 192 / 100 / 400 / 66
+    columns (partial last column tile, a split count that leaves trailing splits empty: dropped; more splits than column tiles: refused), a rank's block in the middle of the batch - against the unsplit
+    kernels (the same sums regrouped: rounding level) and, through them, the oracle on the full batch."""
+    from ssv_amd import _lib, ops
+    zi, zj = seeded_randn(300 + nglob, nglob, d), seeded_randn(301 + nglob, nglob, d)
+    zh_i, zh_j = oracle.l2_normalize(zi).detach().requires_grad_(), oracle.l2_normalize(zj).detach().requires_grad_()
+    oracle.ntxent_loss(zh_i, zh_j, False, 0.5).backward()
+    zall = torch.cat([zh_i.detach(), zh_j.detach()]).to(dev).contiguous()
+    inv_t, gscale = 2.0, 2.0 / (2 * nglob)
+    lse1, pos1 = ops.ntxent_fwd(zall, nglob, b, seg0, inv_t, splits=1)
+    if splits > -(-2 * nglob // 32):                           # more splits than 32-column tiles: refused, not silently clamped
+        with pytest.raises(_lib.SsvError, match="more splits"):
+            ops.ntxent_fwd(zall, nglob, b, seg0, inv_t, splits=splits)
+        return
+    lse_s, pos_s = ops.ntxent_fwd(zall, nglob, b, seg0, inv_t, splits=splits)
+    close(lse_s, lse1, rtol=2e-6, what="lse split vs unsplit")
+    close(pos_s, pos1, rtol=2e-6, what="positive logit split vs unsplit")
+    # every row's log-sum-exp (the backward needs all of them): one call per block of b rows, unsplit
+    lse_all = torch.empty(2 * nglob, device=dev)
+    for r0 in range(0, nglob, b):
+        bb = min(b, nglob - r0)
+        l, _ = ops.ntxent_fwd(zall, nglob, bb, r0, inv_t, splits=1)
+        lse_all[r0:r0 + bb], lse_all[nglob + r0:nglob + r0 + bb] = l[:bb], l[bb:]
+    dz1 = ops.ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_t, gscale, splits=1)
+    dzs = ops.ntxent_bwd(zall, lse_all, nglob, b, seg0, inv_t, gscale, splits=splits)
+    close(dzs, dz1, rtol=1e-4, what="dZ split vs unsplit")
+    close(dzs[:b], zh_i.grad[seg0:seg0 + b], rtol=5e-4, what="dzi vs oracle")
+    close(dzs[b:], zh_j.grad[seg0:seg0 + b], rtol=5e-4, what="dzj vs oracle")
+
+
 def test_ntxent_eight_rank_blocks_at_config3_shape_match_the_full_batch_oracle(dev):
     """world 8, Nglob 4096, Bloc 512, D 128: ssv_ntxent_fwd[_split] / _loss / _bwd[_split] per row block vs oracle.ntxent_loss on the full batch."""
     from ssv_amd import _lib, ops
