@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSV_HIP_LIB") or os.path.join(_HERE, "csrc", "libssv_hip.so")   # override: diagnostic builds only
 
-ABI_VERSION = 110        # ssv_version() of the library this binding was written against (include/ssv_hip.h)
+ABI_VERSION = 111        # ssv_version() of the library this binding was written against (include/ssv_hip.h)
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc", "attn", "norm")
 
 
@@ -103,6 +103,7 @@ SIGNATURES = {
     "ssv_wino44_filter_grad": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int, _vp]),
     "ssv_wino44_dy_transform_both": (C.c_int, [_i32, _i32, _i32, _i32, _vp, C.POINTER(BnDyin), _vp, _vp, _vp]),
     "ssv_gemm_batched": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ssv_gemm_batched_split": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ssv_gemm_batched_wgrad_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "ssv_gemm_batched_wgrad": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_gemm_batched_wgrad_blocked_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32, _i32]),

@@ -1198,6 +1198,22 @@ def _wino44_filter(w, wshape, transposed=False):
     return u
 
 
+# OPT-IN (default 0 = off: every product of the shipped step runs on v_mfma_f32_32x32x2_f32): the transformed-domain products of the Winograd forward and data
+# gradient on the BF16 matrix pipe by operand splitting - each fp32 operand as three bf16 pieces, 6 (or 9) of the nine piece products accumulated in fp32
+# (csrc/gemm_split.hip: error against fp64 at or below the fp32 kernel's; DESIGN 9 "what comes next").  SSV_SPLIT_BF16=6|9.
+SPLIT_BF16_TERMS = int(os.environ.get("SSV_SPLIT_BF16", "0"))
+SPLIT_BF16_MIN_CHANNELS = 128      # output channels: the split kernel's tile is 128 wide
+
+
+def _gemm_batched(nb, t, c, k, a, u, m):
+    """m[b] = a[b] . u[b]^T for the nb transformed-domain positions (a [nb][t][c], u [nb][k][c], m [nb][t][k])."""
+    if SPLIT_BF16_TERMS in (6, 9) and k >= SPLIT_BF16_MIN_CHANNELS and c % 32 == 0:
+        _note("gemm_split_bf16")
+        call("ssv_gemm_batched_split", nb, t, c, k, ptr(a), ptr(u), ptr(m), SPLIT_BF16_TERMS, stream())
+    else:
+        call("ssv_gemm_batched", nb, t, c, k, ptr(a), ptr(u), ptr(m), stream())
+
+
 def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     """wino_conv2d_fwd through F(4x4, 3x3): 36 transformed-domain GEMMs over a quarter of the tiles.  ``keep_v``: the weight gradient's operand comes back as
     the third result - the transformed input V [36][T][C] itself (WINOGRAD44_WGRAD: the weight gradient runs F(4x4) too), or the F(2x2) transformed input
@@ -1218,7 +1234,7 @@ def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     if keep_v and WINOGRAD44_WGRAD:
         v2 = v
     m = torch.empty((36, t, k), dtype=torch.float32, device=x.device)
-    call("ssv_gemm_batched", 36, t, c, k, ptr(v), ptr(u), ptr(m), stream())
+    _gemm_batched(36, t, c, k, v, u, m)
     y = _empty((n, h, w_, k), x)
     part = None
     if want_stats:
@@ -1252,7 +1268,7 @@ def wino44_conv2d_dgrad(dy, w, gate=None):
         v = torch.empty((36, t, k), dtype=torch.float32, device=dy.device)
         call("ssv_wino44_input_transform", n, h, w_, k, ptr(dy), None, None, ptr(v), None, stream())
     m = torch.empty((36, t, c), dtype=torch.float32, device=dy.device)
-    call("ssv_gemm_batched", 36, t, k, c, ptr(v), ptr(u), ptr(m), stream())
+    _gemm_batched(36, t, k, c, v, u, m)
     dx = _empty((n, h, w_, c), dy)
     if gate is not None:
         groups = int(lib.ssv_wino44_groups(n, h, w_, 0))
@@ -1281,7 +1297,7 @@ def wino_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
     v = torch.empty((16, t, c), dtype=torch.float32, device=x.device)
     call("ssv_wino_input_transform", n, h, w_, c, ptr(x), ptr(sc), ptr(sh), ptr(v), stream())
     m = torch.empty((16, t, k), dtype=torch.float32, device=x.device)
-    call("ssv_gemm_batched", 16, t, c, k, ptr(v), ptr(u), ptr(m), stream())
+    _gemm_batched(16, t, c, k, v, u, m)
     y = _empty((n, h, w_, k), x)
     part = None
     if want_stats:
@@ -1308,7 +1324,7 @@ def wino_conv2d_dgrad(dy, w, gate=None):
     v = torch.empty((16, t, k), dtype=torch.float32, device=dy.device)
     call("ssv_wino_input_transform", n, h, w_, k, ptr(dy), None, None, ptr(v), stream())
     m = torch.empty((16, t, c), dtype=torch.float32, device=dy.device)
-    call("ssv_gemm_batched", 16, t, k, c, ptr(v), ptr(u), ptr(m), stream())
+    _gemm_batched(16, t, k, c, v, u, m)
     dx = _empty((n, h, w_, c), dy)
     if gate is not None:
         groups = int(lib.ssv_wino_groups(n, h, w_))

@@ -6,7 +6,7 @@ bytes / busy cycles get divided by another class's time.  First match wins; test
 # family (the transformed-domain GEMMs ARE conv_fwd_k launches), gated output (<2>, <3>: a data gradient's epilogue) -> conv_dgrad, dY / filter-gradient
 # transforms -> weight gradient.  The stem's rows-in-LDS kernels (round 4) are the stem's forward / weight gradient.
 CLASSES = (
-    ("conv_fwd", "conv_fwd_k"), ("conv_fwd", "stem_fwd_rows_k"),
+    ("conv_fwd", "conv_fwd_k"), ("conv_fwd", "stem_fwd_rows_k"), ("conv_fwd", "gemm_batched_split_k"),
     ("conv_dgrad", "conv_dgrad_k"), ("conv_dgrad", "wino_output_k<2"), ("conv_dgrad", "wino_output_k<3"), ("conv_dgrad", "wino44_output_k<2"), ("conv_dgrad", "wino44_output_k<3"),
     ("conv_wgrad", "conv_wgrad_k"), ("conv_wgrad", "stem_wgrad_rows_k"), ("conv_wgrad", "wgrad_reduce"),
     ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_wgrad", "wino44_dy_k"), ("conv_wgrad", "wino44_dy_both_k"), ("conv_wgrad", "wino44_dfilter_k"),
