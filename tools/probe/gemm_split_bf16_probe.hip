@@ -18,6 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 
+#ifndef WHATIF
+#define WHATIF 0     // timing what-ifs (results wrong): 1 no residual arithmetic (all planes = the first conversion), 2 = 1 + only plane 0 written to LDS, 4 no restaging / barriers after the first tile
+#endif
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDH = 40;                 // bf16 elements per LDS row (32 + 8 pad: 80 bytes, odd multiple of 16 -> conflict-free ds_read_b128 over 16 rows)
 constexpr int LDF = 36;                 // floats per LDS row of the fp32 kernel
@@ -64,11 +67,12 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(int M, int N, int K, cons
     for (int q = 0; q < NP; ++q) {
       const bf2 h0 = __builtin_convertvector(x0, bf2), h1 = __builtin_convertvector(x1, bf2);
       pl[q][0] = __builtin_bit_cast(unsigned, h0); pl[q][1] = __builtin_bit_cast(unsigned, h1);
-      if (q + 1 < NP) {
+      if (q + 1 < NP && !(WHATIF & 3)) {
         x0 -= f2{__uint_as_float(pl[q][0] << 16), __uint_as_float(pl[q][0] & 0xFFFF0000u)};
         x1 -= f2{__uint_as_float(pl[q][1] << 16), __uint_as_float(pl[q][1] & 0xFFFF0000u)};
       }
-      *(uint2*)(&s[q][off]) = make_uint2(pl[q][0], pl[q][1]);
+      if (!(WHATIF & 2) || q == 0) *(uint2*)(&s[q][off]) = make_uint2(pl[q][0], pl[q][1]);
+      if ((WHATIF & 3) && q == 0 && NP > 1) { if (WHATIF & 2) break; }
     }
   };
   auto lstore = [&]() {
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(int M, int N, int K, cons
   __syncthreads();
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = k0 + BK < K;
-    if (more) gload(k0 + BK);
+    if (more && !(WHATIF & 4)) gload(k0 + BK);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {                                     // two k-slabs of 16
       bf16x8 fa[NP][2], fb[NP][2];
@@ -108,6 +112,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(int M, int N, int K, cons
 #undef MM
         }
     }
+    if (WHATIF & 4) continue;
     __syncthreads();
     if (more) lstore();
     __syncthreads();
