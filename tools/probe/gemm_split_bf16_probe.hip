@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <vector>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -115,6 +116,118 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(int M, int N, int K, cons
     if (WHATIF & 4) continue;
     __syncthreads();
     if (more) lstore();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h, col = n0 + wn + 32 * j + r;
+        C[(size_t)row * N + col] = acc[i][j][e];
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pipelined split kernel
+// ONE workgroup per CU (one wave per SIMD, up to 512 registers), LDS double-buffered (2 x 61 KB), ONE barrier per k-tile.  Two register stages: while the MFMAs of tile k
+// run from LDS buffer k & 1, the rows of tile k + 1 (loaded a whole iteration earlier) are split and written to buffer (k + 1) & 1 in eight pieces placed between the MFMA
+// groups, and the loads of tile k + 2 are in flight.
+template <int TERMS>
+__global__ void __launch_bounds__(256, 1) gemm_split_pipe_k(int M, int N, int K, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C) {
+  constexpr int NP = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];          // [2 buffers][A | B][3 planes][128 * LDH]
+  auto plane = [&](int buf, int ab, int q) { return lds + (size_t)((buf * 2 + ab) * NP + q) * (BM * LDH); };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const float* pa[4];
+  const float* pb[4];
+  int off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 3, k4 = (idx & 7) * 4;
+    pa[i] = A + (size_t)(m0 + row) * K + k4;
+    pb[i] = B + (size_t)(n0 + row) * K + k4;
+    off[i] = row * LDH + k4;
+  }
+  f32x4 st[2][8];                                                      // two stages x (4 A + 4 B) float4
+  auto gload = [&](f32x4* s, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] = *(const f32x4*)(pa[i] + k0); s[4 + i] = *(const f32x4*)(pb[i] + k0); }
+  };
+  auto split_store = [&](const f32x4& v, int buf, int ab, int o) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 x0 = {v[0], v[1]}, x1 = {v[2], v[3]};
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x0, bf2)), p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x1, bf2));
+      if (q + 1 < NP) {
+        x0 -= f2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+        x1 -= f2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xFFFF0000u)};
+      }
+      *(uint2*)(plane(buf, ab, q) + o) = make_uint2(p0, p1);
+    }
+  };
+  // one k-tile: MFMAs from buffer `buf`, the stage `nx` (tile k + 1) split into buffer buf ^ 1 in 8 pieces between the MFMA groups
+  auto tile = [&](int buf, const f32x4* nx, auto next_tag) {
+    constexpr bool has_next = decltype(next_tag)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[NP][2], fb[NP][2];
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[q][t] = *(const bf16x8*)(plane(buf, 0, q) + (wm + 32 * t + r) * LDH + 16 * s + 8 * h);
+          fb[q][t] = *(const bf16x8*)(plane(buf, 1, q) + (wn + 32 * t + r) * LDH + 16 * s + 8 * h);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#define MM(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, fa[P][i]), __builtin_bit_cast(bf16x8n, fb[Q][j]), acc[i][j], 0, 0, 0)
+          if (TERMS == 9) { MM(2, 2); MM(2, 1); MM(1, 2); }
+          MM(2, 0); MM(0, 2); MM(1, 1); MM(1, 0); MM(0, 1); MM(0, 0);
+#undef MM
+          const int piece = (s * 2 + i) * 2 + j;                       // 0 .. 7: one staged float4 per MFMA group
+          if (has_next) {
+            split_store(nx[piece], buf ^ 1, piece >> 2, off[piece & 3]);
+#ifndef NO_SCHED_GROUPS
+            // issue order asked of the scheduler: one MFMA, four vector instructions, ... - the split's ~24 instructions ride in the MFMAs' shadows (one wave per SIMD:
+            // nothing else can fill them), then the three LDS writes
+#pragma unroll
+            for (int g = 0; g < (TERMS == 9 ? 9 : 6); ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 9 ? 3 : 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+#endif
+          }
+        }
+    }
+  };
+  const int nk = K / BK;
+  gload(st[0], 0);
+  if (nk > 1) gload(st[1], BK);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) split_store(st[0][p], 0, p >> 2, off[p & 3]);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) gload(st[0], (kt + 2) * BK);                      // stage 0 is free: its tile is in LDS buffer 0
+    if (kt + 1 < nk) tile(0, st[1], std::true_type{}); else tile(0, st[1], std::false_type{});
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) gload(st[1], (kt + 3) * BK);
+    if (kt + 2 < nk) tile(1, st[0], std::true_type{}); else tile(1, st[0], std::false_type{});
     __syncthreads();
   }
 #pragma unroll
@@ -253,6 +366,13 @@ int main(int argc, char** argv) {
   report("fp32 MFMA (32x32x2 f32)", time_ms([&]() { hipLaunchKernelGGL(gemm_f32_k, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
   report("bf16 split, 9 terms", time_ms([&]() { hipLaunchKernelGGL(gemm_split_k<9>, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
   report("bf16 split, 6 terms", time_ms([&]() { hipLaunchKernelGGL(gemm_split_k<6>, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
+  {
+    const size_t lds_bytes = (size_t)2 * 2 * 3 * BM * LDH * 2;
+    hipFuncSetAttribute((const void*)gemm_split_pipe_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void*)gemm_split_pipe_k<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    report("bf16 split, 6 terms, pipelined", time_ms([&]() { hipLaunchKernelGGL(gemm_split_pipe_k<6>, grid, block, lds_bytes, 0, M, N, K, A, B, C); }, 10));
+    report("bf16 split, 9 terms, pipelined", time_ms([&]() { hipLaunchKernelGGL(gemm_split_pipe_k<9>, grid, block, lds_bytes, 0, M, N, K, A, B, C); }, 10));
+  }
   report("bf16 split, 3 terms", time_ms([&]() { hipLaunchKernelGGL(gemm_split_k<3>, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
   report("plain bf16 (1 term)", time_ms([&]() { hipLaunchKernelGGL(gemm_split_k<1>, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
   return 0;
