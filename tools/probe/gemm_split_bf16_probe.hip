@@ -129,6 +129,110 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(int M, int N, int K, cons
       }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- B (the weights) split ONCE, ahead of the GEMM
+__global__ void presplit_k(size_t n, const float* __restrict__ x, unsigned short* __restrict__ p0, unsigned short* __restrict__ p1, unsigned short* __restrict__ p2) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const unsigned short a = bf16_rne(v); const float r1 = v - bf16_to_f32(a);
+  const unsigned short b = bf16_rne(r1); const float r2 = r1 - bf16_to_f32(b);
+  p0[i] = a; p1[i] = b; p2[i] = bf16_rne(r2);
+}
+
+// the two-workgroups-per-CU kernel with B read as three bf16 planes [3][N][K] (16-byte pieces straight to LDS): half of the split's vector work is gone
+template <int TERMS>
+__global__ void __launch_bounds__(256, 2) gemm_split_preb_k(int M, int N, int K, const float* __restrict__ A, const unsigned short* __restrict__ Bp, float* __restrict__ C) {
+  constexpr int NP = 3;
+  __shared__ __attribute__((aligned(16))) unsigned short sa[NP][BM * LDH], sb[NP][BN * LDH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x4 ra[4];
+  bf16x8 rb[NP][2];                                                   // per plane: 128 x 32 bf16 = 512 pieces of 8; thread t takes pieces t, t + 256: row = idx >> 2, k8 = (idx & 3) * 8
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, k4 = (idx & 7) * 4;
+      ra[i] = *(const f32x4*)(A + (size_t)(m0 + row) * K + k0 + k4);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 2, k8 = (idx & 3) * 8;
+        rb[q][i] = *(const bf16x8*)(Bp + ((size_t)q * N + n0 + row) * K + k0 + k8);
+      }
+  };
+  auto split_store = [&](const f32x4& v, int off) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 x0 = {v[0], v[1]}, x1 = {v[2], v[3]};
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x0, bf2)), p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x1, bf2));
+      if (q + 1 < NP) {
+        x0 -= f2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+        x1 -= f2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xFFFF0000u)};
+      }
+      *(uint2*)(&sa[q][off]) = make_uint2(p0, p1);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int idx = tid + 256 * i; split_store(ra[i], (idx >> 3) * LDH + (idx & 7) * 4); }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int idx = tid + 256 * i; *(bf16x8*)(&sb[q][(idx >> 2) * LDH + (idx & 3) * 8]) = rb[q][i]; }
+  };
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) gload(k0 + BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[NP][2], fb[NP][2];
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[q][t] = *(const bf16x8*)(&sa[q][(wm + 32 * t + r) * LDH + 16 * s + 8 * h]);
+          fb[q][t] = *(const bf16x8*)(&sb[q][(wn + 32 * t + r) * LDH + 16 * s + 8 * h]);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#define MM(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, fa[P][i]), __builtin_bit_cast(bf16x8n, fb[Q][j]), acc[i][j], 0, 0, 0)
+          if (TERMS == 9) { MM(2, 2); MM(2, 1); MM(1, 2); }
+          MM(2, 0); MM(0, 2); MM(1, 1); MM(1, 0); MM(0, 1); MM(0, 0);
+#undef MM
+        }
+    }
+    __syncthreads();
+    if (more) lstore();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h, col = n0 + wn + 32 * j + r;
+        C[(size_t)row * N + col] = acc[i][j][e];
+      }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- pipelined split kernel
 // ONE workgroup per CU (one wave per SIMD, up to 512 registers), LDS double-buffered (2 x 61 KB), ONE barrier per k-tile.  Two register stages: while the MFMAs of tile k
 // run from LDS buffer k & 1, the rows of tile k + 1 (loaded a whole iteration earlier) are split and written to buffer (k + 1) & 1 in eight pieces placed between the MFMA
@@ -372,6 +476,15 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute((const void*)gemm_split_pipe_k<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     report("bf16 split, 6 terms, pipelined", time_ms([&]() { hipLaunchKernelGGL(gemm_split_pipe_k<6>, grid, block, lds_bytes, 0, M, N, K, A, B, C); }, 10));
     report("bf16 split, 9 terms, pipelined", time_ms([&]() { hipLaunchKernelGGL(gemm_split_pipe_k<9>, grid, block, lds_bytes, 0, M, N, K, A, B, C); }, 10));
+  }
+  {
+    unsigned short* Bp; hipMalloc(&Bp, (size_t)3 * N * K * 2);
+    const size_t nb = (size_t)N * K;
+    const float tp = time_ms([&]() { hipLaunchKernelGGL(presplit_k, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, nb, B, Bp, Bp + nb, Bp + 2 * nb); }, 5);
+    printf("  (splitting B once: %.3f ms)\n", tp);
+    report("bf16 split, 6 terms, B pre-split", time_ms([&]() { hipLaunchKernelGGL(gemm_split_preb_k<6>, grid, block, 0, 0, M, N, K, A, Bp, C); }, 10));
+    report("bf16 split, 9 terms, B pre-split", time_ms([&]() { hipLaunchKernelGGL(gemm_split_preb_k<9>, grid, block, 0, 0, M, N, K, A, Bp, C); }, 10));
+    hipFree(Bp);
   }
   report("bf16 split, 3 terms", time_ms([&]() { hipLaunchKernelGGL(gemm_split_k<3>, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
   report("plain bf16 (1 term)", time_ms([&]() { hipLaunchKernelGGL(gemm_split_k<1>, grid, block, 0, 0, M, N, K, A, B, C); }, 10));
