@@ -24,6 +24,7 @@ AdamW is graphable because its step count lives in device memory (``ssv_adamw_co
 import atexit
 import gc
 import os
+import time
 import weakref
 
 import torch
@@ -35,6 +36,7 @@ from . import ops
 # SSV_STEP_GRAPH: "1" always (where possible), "0" never, "auto" (default) for small images only - where the step is launch-bound
 MODE = os.environ.get("SSV_STEP_GRAPH", "auto")
 AUTO_MAX_PIXELS = 64 * 64            # per image: CIFAR (32 x 32) and the like; at 224 x 224 the step is GPU-bound and the static input copies cost more than the launches
+DESTROY_GRACE_S = float(os.environ.get("SSV_GRAPH_DESTROY_GRACE", "0.05"))   # between the device going idle and a graph's destruction (see StepGraph._drop)
 WARMUP_STEPS = 2                     # eager steps before a capture: the optimizer's first update (its first-step flag is a kernel argument), allocator warm-up
 
 
@@ -61,7 +63,7 @@ class StepGraph:
         self.keys = keys
         self.graph_floors = graph_floors   # small images: the captured step takes the Winograd forms from fewer tiles / channels (ops.graph_dispatch); False = the eager selection, bit for bit
         self.mode = MODE if mode is None else mode
-        self.graphs = {}             # key -> (graph, static inputs, pinned loss, workspace buffers kept alive)
+        self.graphs = {}             # key -> (graph, static inputs, pinned loss, (workspace buffers, event objects of the capture) kept alive)
         self.eager_steps = 0
         self.seen = {}               # input-shape signature -> times met without a graph
         self.disabled = None         # reason, once capture has failed or the trainer is not graphable
@@ -75,12 +77,28 @@ class StepGraph:
             raise RuntimeError("StepGraph: the trainer it was built for no longer exists")
         return t
 
+    def _drop(self, keys):
+        """Destroy the graphs under `keys` in a DEFINED order: device idle, then the graph itself (CUDAGraph.reset = hipGraphExecDestroy + hipGraphDestroy), and only then
+        the event objects that were recorded inside its capture, its static inputs and its workspace (a record's tuple would otherwise release its LAST item first)."""
+        recs = [self.graphs.pop(k) for k in keys if k in self.graphs]
+        if recs and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            # hipDeviceSynchronize returns when the last command's signal is set; the runtime's completion callbacks (its asynchronous handler thread) may still be
+            # walking the launch's command objects.  Destroying the graph under them corrupted the host heap (native backtrace of the fault: libhsa-runtime64's handler
+            # thread -> libamdhip64 callbacks; tools/exp/r05_graph_event_stress.py reproduces it within ~50 capture / destroy cycles of a two-stream step, never with
+            # the graphs kept alive).  Give the handler time to finish before the graph goes - a re-capture happens once per epoch, the wait is noise.
+            time.sleep(DESTROY_GRACE_S)
+            torch.cuda.synchronize()
+        for rec in recs:
+            try:
+                rec[0].reset()
+            except Exception:
+                pass
+        del recs
+
     def close(self):
         """Destroy every captured graph now (idle device, no capture in progress)."""
-        if self.graphs:
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-            self.graphs.clear()
+        self._drop(list(self.graphs))
 
     def __del__(self):
         try:
@@ -140,7 +158,7 @@ class StepGraph:
             if self.captures >= 8 and self.replays < 4 * self.captures:
                 # a scalar of the key moves nearly every step (a per-step learning-rate schedule): capturing costs more than launching - stay eager
                 self.disabled = f"{self.captures} captures for {self.replays} replays: a scalar baked into the graph changes too often"
-                self.graphs.clear()
+                self.close()
                 return self.trainer.train_step(batch)
             try:
                 self.captures += 1
@@ -149,8 +167,7 @@ class StepGraph:
                 self.disabled = f"capture failed: {type(exc).__name__}: {exc}"
                 torch.cuda.synchronize()
                 return self.trainer.train_step(batch)
-            for old in [k for k in self.graphs if k[0] == key[0] and k != key]:
-                del self.graphs[old]         # the schedule moved on: one graph per input shape
+            self._drop([k for k in self.graphs if k[0] == key[0] and k != key])         # the schedule moved on: one graph per input shape
             self.graphs[key] = rec
         graph, static, host, _ = rec
         for k, t in ins.items():
@@ -190,10 +207,10 @@ class StepGraph:
                 gc.enable()
             if floors is not None:
                 floors.__exit__(None, None, None)
-            hnn.end_capture(prev)
+            events = hnn.end_capture(prev)
             graph_ws, ops.workspace.buf = ops.workspace.buf, eager_ws
         _LIVE.add(self)
-        return graph, static, host, graph_ws
+        return graph, static, host, (graph_ws, events)
 
     def describe(self):
         return {"mode": self.mode, "graphs": len(self.graphs), "captures": self.captures, "replays": self.replays, "eager_steps": self.eager_steps, "disabled": self.disabled}

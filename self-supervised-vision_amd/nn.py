@@ -64,7 +64,18 @@ def join_view_streams(device):
         cur = torch.cuda.current_stream(device)
         for st in _STREAMS[device]:
             if st != cur:
-                cur.wait_stream(st)
+                _wait_stream(cur, st)
+
+
+def _wait_stream(waiter, st):
+    """``waiter.wait_stream(st)`` with an event object of our own: under stream capture it must outlive the capture (kept with the graph, _CAPTURE_KEEP)."""
+    if _CAPTURE_KEEP is None:
+        waiter.wait_stream(st)
+        return
+    ev = torch.cuda.Event()
+    ev.record(st)
+    waiter.wait_event(ev)
+    _CAPTURE_KEEP.append(ev)
 
 
 class parallel_views:
@@ -82,6 +93,8 @@ class parallel_views:
             self.main = torch.cuda.current_stream(self.device)
             self.start = torch.cuda.Event()
             self.start.record(self.main)
+            if _CAPTURE_KEEP is not None:
+                _CAPTURE_KEEP.append(self.start)
             self.used = set()
         return self
 
@@ -91,7 +104,7 @@ class parallel_views:
     def __exit__(self, *exc):
         if self.enabled:
             for slot in self.used:
-                self.main.wait_stream(_STREAMS[self.device][slot])
+                _wait_stream(self.main, _STREAMS[self.device][slot])
         return False
 
 
@@ -194,17 +207,26 @@ _EARLY_LOSS = os.environ.get("SSV_LATE_LOSS_READ", "0") != "1"      # diagnostic
 _CAPTURE_HOST = None     # while graph.StepGraph captures a step: the pinned float the step's loss is copied to by a node of the graph
 
 
+_CAPTURE_ORDER = None    # while a step is captured: id(BatchNorm module) -> the event view 0 recorded behind its update IN THIS CAPTURE (see _bn_order_record)
+_CAPTURE_KEEP = None     # while a step is captured: every event object recorded in the capture; graph.StepGraph keeps the list for as long as the graph lives
+
+
 def begin_capture(host):
     """The step that follows is recorded into a HIP graph, not executed: ``early_item`` must neither synchronise nor allocate - it copies the scalar into
-    ``host`` (pinned, owned by the graph's record) and ``get()`` returns a placeholder; the replaying caller reads ``host`` after the graph has run."""
-    global _CAPTURE_HOST
-    prev, _CAPTURE_HOST = _CAPTURE_HOST, host
+    ``host`` (pinned, owned by the graph's record) and ``get()`` returns a placeholder; the replaying caller reads ``host`` after the graph has run.
+    The BatchNorm ordering events of the captured step are capture-local (``_CAPTURE_ORDER``): no event object that outlives the capture is ever recorded in it."""
+    global _CAPTURE_HOST, _CAPTURE_ORDER, _CAPTURE_KEEP
+    prev, _CAPTURE_HOST = (_CAPTURE_HOST, _CAPTURE_ORDER, _CAPTURE_KEEP), host
+    _CAPTURE_ORDER = {}
+    _CAPTURE_KEEP = []
     return prev
 
 
 def end_capture(prev):
-    global _CAPTURE_HOST
-    _CAPTURE_HOST = prev
+    global _CAPTURE_HOST, _CAPTURE_ORDER, _CAPTURE_KEEP
+    kept = _CAPTURE_KEEP
+    _CAPTURE_HOST, _CAPTURE_ORDER, _CAPTURE_KEEP = prev
+    return kept                                   # the capture's event objects: the caller keeps them until the graph is gone
 
 
 class early_item:
@@ -542,12 +564,22 @@ def grouped_conv(tape, x, weight, groups, stride, pad):
 
 
 def _bn_order_wait(bn, x):
-    if _STREAMS and _SLOT == 1 and bn._order_event is not None:     # running-stat update order across the two view streams: slot 0 first
-        torch.cuda.current_stream(x.device).wait_event(bn._order_event)
+    if _STREAMS and _SLOT == 1:                                     # running-stat update order across the two view streams: slot 0 first
+        ev = bn._order_event if _CAPTURE_ORDER is None else _CAPTURE_ORDER.get(id(bn))
+        if ev is not None:
+            torch.cuda.current_stream(x.device).wait_event(ev)
 
 
 def _bn_order_record(bn, x):
     if _STREAMS and _SLOT == 0 and _lib.stream() != 0:              # on a view stream (the default stream's raw handle is 0): no Stream object per BatchNorm call
+        if _CAPTURE_ORDER is not None:
+            # Under stream capture a FRESH event per record, kept with the graph (_CAPTURE_KEEP): the module's persistent event is never recorded inside a capture
+            # (an event recorded there belongs to that graph; it is neither re-recorded nor waited on eagerly afterwards).
+            ev = torch.cuda.Event()
+            ev.record()
+            _CAPTURE_ORDER[id(bn)] = ev
+            _CAPTURE_KEEP.append(ev)
+            return
         if bn._order_event is None:
             object.__setattr__(bn, "_order_event", torch.cuda.Event())
         bn._order_event.record()                                   # on the current stream
