@@ -36,7 +36,7 @@ from . import ops
 # SSV_STEP_GRAPH: "1" always (where possible), "0" never, "auto" (default) for small images only - where the step is launch-bound
 MODE = os.environ.get("SSV_STEP_GRAPH", "auto")
 AUTO_MAX_PIXELS = 64 * 64            # per image: CIFAR (32 x 32) and the like; at 224 x 224 the step is GPU-bound and the static input copies cost more than the launches
-DESTROY_GRACE_S = float(os.environ.get("SSV_GRAPH_DESTROY_GRACE", "0.05"))   # between the device going idle and a graph's destruction (see StepGraph._drop)
+DESTROY_GRACE_S = float(os.environ.get("SSV_GRAPH_DESTROY_GRACE", "0.1"))   # between the device going idle and a graph's destruction (see StepGraph._drop)
 WARMUP_STEPS = 2                     # eager steps before a capture: the optimizer's first update (its first-step flag is a kernel argument), allocator warm-up
 
 
