@@ -241,7 +241,8 @@ int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const fl
  * operand as three bf16 pieces, `terms` = 6 or 9 of the nine piece products accumulated in fp32 by v_mfma_f32_32x32x16_bf16; error against fp64 at or below
  * ssv_gemm_batched's (it replaces the same F.conv2d arithmetic, networks/resnet.py:56-58, in the transformed domain). */
 int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
-                           float* y /*[batch][rows][K]*/, int32_t terms, void* stream);
+                           float* y /*[batch][rows][K]*/, const float* bias /*[K] or NULL (batch 1)*/, const float* addend /*[batch][rows][K] or NULL*/,
+                           int32_t terms, void* stream);
 size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K);
 int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x /*[batch][rows][C]*/, const float* dy /*[batch][rows][K]*/,
                            float* dw /*[batch][K][C]*/, void* ws, size_t ws_bytes, void* stream);

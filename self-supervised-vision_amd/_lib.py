@@ -103,7 +103,7 @@ SIGNATURES = {
     "ssv_wino44_filter_grad": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int, _vp]),
     "ssv_wino44_dy_transform_both": (C.c_int, [_i32, _i32, _i32, _i32, _vp, C.POINTER(BnDyin), _vp, _vp, _vp]),
     "ssv_gemm_batched": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "ssv_gemm_batched_split": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "ssv_gemm_batched_split": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ssv_gemm_batched_wgrad_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "ssv_gemm_batched_wgrad": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_gemm_batched_wgrad_blocked_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32, _i32]),

@@ -1,5 +1,5 @@
 // fp32 batched GEMM on the BF16 matrix pipe by operand splitting (round 5; OPT-IN: ops.SPLIT_BF16_TERMS / SSV_SPLIT_BF16, default off - the shipped step runs every
-// product on v_mfma_f32_32x32x2_f32).  For the transformed-domain products of the Winograd layers (csrc/winograd*.hip): y[b][rows][K] = a[b][rows][C] . w[b][K][C]^T.
+// product on v_mfma_f32_32x32x2_f32).  For the transformed-domain products of the Winograd layers (csrc/winograd*.hip): y[b][rows][K] = a[b][rows][C] . w[b][K][C]^T (+ bias[K] + addend[b][rows][K]: the plain 1x1 / Linear products' epilogue).
 //
 //   a = a1 + a2 + a3,  a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)   (round to nearest even; the residuals are exact fp32 subtractions; 3 x 8 significant
 //   bits cover the 24 of an fp32), the same for w;  a . w = sum of ai . wj with every ai . wj exact (8 x 8 bits) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
@@ -26,7 +26,8 @@ constexpr int SLD = 40;                                        // bf16 elements 
 
 template <int TERMS>
 __global__ void __launch_bounds__(256, 2)
-gemm_batched_split_k(int rows, int C, int K, int tiles_n, const float* __restrict__ a, const float* __restrict__ w, float* __restrict__ y) {
+gemm_batched_split_k(int rows, int C, int K, int tiles_n, const float* __restrict__ a, const float* __restrict__ w, float* __restrict__ y,
+                     const float* __restrict__ bias, const float* __restrict__ addend) {
   static_assert(TERMS == 6 || TERMS == 9, "6 or 9 terms");
   __shared__ __attribute__((aligned(16))) unsigned short sa[3][SBM * SLD], sb[3][SBN * SLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -35,6 +36,7 @@ gemm_batched_split_k(int rows, int C, int K, int tiles_n, const float* __restric
   a += (size_t)blockIdx.y * rows * C;
   w += (size_t)blockIdx.y * K * C;
   y += (size_t)blockIdx.y * rows * K;
+  if (addend) addend += (size_t)blockIdx.y * rows * K;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -120,26 +122,33 @@ gemm_batched_split_k(int rows, int C, int K, int tiles_n, const float* __restric
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = n0 + wn + 32 * j + 8 * q + 4 * h;
-        if (col < K) *(f32x4*)(y + (size_t)row * K + col) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (col < K) {
+          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          if (bias) v += *(const f32x4*)(bias + col);                   // y = a . w^T + bias[channel] + addend[row][channel], as ssv_conv2d_fwd's epilogue
+          if (addend) v += *(const f32x4*)(addend + (size_t)row * K + col);
+          *(f32x4*)(y + (size_t)row * K + col) = v;
+        }
       }
   }
 }
 
 }  // namespace
 
-extern "C" int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a, const float* w, float* y, int32_t terms, void* stream) {
+extern "C" int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a, const float* w, float* y,
+                                      const float* bias, const float* addend, int32_t terms, void* stream) {
   SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "ssv_gemm_batched_split: bad shape");
   SSV_REQUIRE(C % 32 == 0 && K % 4 == 0, "ssv_gemm_batched_split: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", C, K);
   SSV_REQUIRE(terms == 6 || terms == 9, "ssv_gemm_batched_split: terms must be 6 or 9 (got %d)", terms);
-  SSV_REQUIRE(a && w && y && (((uintptr_t)a | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "ssv_gemm_batched_split: null or unaligned pointer");
+  SSV_REQUIRE(a && w && y && (((uintptr_t)a | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)addend) & 15) == 0, "ssv_gemm_batched_split: null or unaligned pointer");
+  SSV_REQUIRE(!bias || batch == 1, "ssv_gemm_batched_split: a bias goes with one product (batch 1)");
   const int64_t tiles_m = cdiv64(rows, SBM);
   const int tiles_n = cdiv(K, SBN);
   SSV_REQUIRE(tiles_m * tiles_n < (1ll << 31), "ssv_gemm_batched_split: grid too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_CONV_FWD, s);
   const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch);
-  if (terms == 6) hipLaunchKernelGGL(gemm_batched_split_k<6>, grid, dim3(256), 0, s, (int)rows, C, K, tiles_n, a, w, y);
-  else hipLaunchKernelGGL(gemm_batched_split_k<9>, grid, dim3(256), 0, s, (int)rows, C, K, tiles_n, a, w, y);
+  if (terms == 6) hipLaunchKernelGGL(gemm_batched_split_k<6>, grid, dim3(256), 0, s, (int)rows, C, K, tiles_n, a, w, y, bias, addend);
+  else hipLaunchKernelGGL(gemm_batched_split_k<9>, grid, dim3(256), 0, s, (int)rows, C, K, tiles_n, a, w, y, bias, addend);
   SSV_CHECK_LAUNCH("ssv_gemm_batched_split");
   return SSV_OK;
 }

@@ -68,6 +68,19 @@ def _sub(t, n0, n1):
     return None if t is None else t[n0:n1]
 
 
+def _split_plain(rows, c, k, a, w2d, y, bias, addend):
+    """The plain 1x1 / Linear product y = a . w^T (+ bias + addend) on the bf16 pipe by operand splitting, when the opt-in switch is on and the shape fits
+    (SPLIT_BF16_TERMS, defined with the Winograd products below).  Returns False when the caller must run the fp32-MFMA kernel."""
+    if SPLIT_BF16_TERMS not in (6, 9) or k < SPLIT_BF16_MIN_CHANNELS or c % 32 or k % 4 or rows >= (1 << 31):
+        return False
+    for t in (bias, addend):
+        if t is not None and t.data_ptr() % 16:
+            return False
+    _note("gemm_split_bf16")
+    call("ssv_gemm_batched_split", 1, rows, c, k, ptr(a), ptr(w2d), ptr(y), ptr(bias), ptr(addend), SPLIT_BF16_TERMS, stream())
+    return True
+
+
 def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None, groups=1):
     """``groups`` > 1: w is the DENSE block-diagonal bank of a grouped convolution (group_expand); every column tile then contracts over the
     channels of its own groups only."""
@@ -75,6 +88,9 @@ def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None, groups=1):
     w, wshape = _ohwi(w)
     d = conv_desc(x.shape, wshape, stride, pad)
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
+    if (groups == 1 and wshape[2] == 1 and wshape[3] == 1 and stride == 1 and pad == 0 and x.is_contiguous() and (addend is None or addend.is_contiguous())
+            and _split_plain(d.N * d.H * d.W, d.C, d.K, x, w, y, bias, addend)):
+        return y
     for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K)):
         dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad)
         if groups > 1:
@@ -355,6 +371,9 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
                 parts.append(part)
             elif groups > 1:          # the transposed bank is block-diagonal too (input and output channels of a group change places)
                 call("ssv_conv2d_fwd_grouped", C.byref(d), int(groups), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
+            elif (r == 1 and dyc.is_contiguous() and dxc.is_contiguous() and (adc is None or adc.is_contiguous())
+                  and _split_plain(d.N * d.H * d.W, k, c, dyc, wt, dxc, None, adc)):
+                pass                  # dx = dy . W (the transposed filter [C][K] as the k-contiguous operand) on the bf16 pipe (opt-in)
             else:
                 call("ssv_conv2d_fwd", C.byref(d), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
         else:
@@ -1209,7 +1228,7 @@ def _gemm_batched(nb, t, c, k, a, u, m):
     """m[b] = a[b] . u[b]^T for the nb transformed-domain positions (a [nb][t][c], u [nb][k][c], m [nb][t][k])."""
     if SPLIT_BF16_TERMS in (6, 9) and k >= SPLIT_BF16_MIN_CHANNELS and c % 32 == 0:
         _note("gemm_split_bf16")
-        call("ssv_gemm_batched_split", nb, t, c, k, ptr(a), ptr(u), ptr(m), SPLIT_BF16_TERMS, stream())
+        call("ssv_gemm_batched_split", nb, t, c, k, ptr(a), ptr(u), ptr(m), None, None, SPLIT_BF16_TERMS, stream())
     else:
         call("ssv_gemm_batched", nb, t, c, k, ptr(a), ptr(u), ptr(m), stream())
 

@@ -297,7 +297,7 @@ def test_batched_gemm_on_the_bf16_pipe_by_operand_splitting(dev, nb, t, c, k, te
     y32 = torch.full((nb, t, k), float("nan"), device=dev)
     ysp = torch.full((nb, t, k), float("nan"), device=dev)
     _lib.call("ssv_gemm_batched", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(y32), _lib.stream())
-    _lib.call("ssv_gemm_batched_split", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(ysp), terms, _lib.stream())
+    _lib.call("ssv_gemm_batched_split", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(ysp), None, None, terms, _lib.stream())
     torch.cuda.synchronize()
     assert torch.isfinite(ysp).all()
     e32 = float((y32.double() - ref).norm() / ref.norm())
@@ -307,7 +307,14 @@ def test_batched_gemm_on_the_bf16_pipe_by_operand_splitting(dev, nb, t, c, k, te
     assert esp <= 1.10 * e32 + 1e-9, (esp, e32)
     assert worstsp <= 1.5 * worst32 + 1e-9, (worstsp, worst32)
     with pytest.raises(_lib.SsvError, match="terms"):
-        _lib.call("ssv_gemm_batched_split", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(ysp), 3, _lib.stream())
+        _lib.call("ssv_gemm_batched_split", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(ysp), None, None, 3, _lib.stream())
+    # the plain 1x1 / Linear epilogue: + bias[channel] + addend[row][channel] (one product), the addend in place
+    bias = torch.randn(k, device=dev, generator=g)
+    acc = torch.randn(t, k, device=dev, generator=g)
+    want = ref[0] + bias.double() + acc.double()
+    _lib.call("ssv_gemm_batched_split", 1, t, c, k, _lib.ptr(a[0]), _lib.ptr(w[0]), _lib.ptr(acc), _lib.ptr(bias), _lib.ptr(acc), terms, _lib.stream())
+    torch.cuda.synchronize()
+    assert float((acc.double() - want).norm() / want.norm()) <= 1.10 * e32 + 1e-7
 
 
 @pytest.mark.parametrize("n,h,c", [(64, 28, 128), (64, 14, 256), (128, 7, 512)])
