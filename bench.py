@@ -35,7 +35,65 @@ PMC_FILES = {"simclr": "r05_simclr_b%d_pmc_hbm_traffic.json", "dino": "r05_dino_
 CONV_LAYER_FILE = "r05_conv_layers_b%d.csv"
 PMC_MFMA_FILES = {"simclr": "r05_simclr_b%d_pmc_mfma.json", "dino": "r05_dino_b%d_pmc_mfma.json"}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity headline)
+BF16X3_TERMS = 6                     # bf16 piece products per fp32 product in the shipped arithmetic (csrc/split_bf16.h)
+BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS            # 416.7 TFLOP/s of fp32 products: the roof of the pipe the dominant kernels run on
 HBM_PEAK_GBS = 8000.0
+
+
+def arithmetic_block(device):
+    """What `dtype: f32` means in this line: fp32 operands and results; each fp32 product evaluated as six exact bf16 piece products accumulated in fp32 on the
+    bf16 matrix pipe (csrc/split_bf16.h).  The error ratios are measured HERE, on this device: a forward-, data-gradient- and weight-gradient-shaped product of a
+    ResNet-50 bottleneck (28 x 28 x 512 -> 128, batch 32) in both arithmetics against an fp64 evaluation - tests/test_gpu_split.py holds every one of the 53 layers
+    x 3 products to <= 1.05."""
+    from ssv_amd import _lib, ops
+    n, h, c, k = 32, 28, 512, 128
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.relu(torch.randn(n, h, h, c, device=device, generator=g) + 0.3)
+    w = (torch.randn(k, c, 1, 1, device=device, generator=g) * (2.0 / c) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, h, h, k, device=device, generator=g)
+    xd, wd, dyd = x.reshape(-1, c).double(), w.reshape(k, c).double(), dy.reshape(-1, k).double()
+    ref = (xd @ wd.t(), dyd @ wd, dyd.t() @ xd)
+    err = {}
+    for name in ("f32", "bf16x3"):
+        with ops.arithmetic(name):
+            y = ops.conv2d_fwd(x, w, 1, 0)
+            dx = ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, 0)
+            dw = torch.zeros_like(w)
+            ops.conv2d_wgrad(x, dy, w, dw, 1, 0, accumulate=False)
+            torch.cuda.synchronize()
+            got = (y.reshape(-1, k), dx.reshape(-1, c), dw.reshape(k, c))
+            err[name] = [float((a.double() - r).norm() / r.norm()) for a, r in zip(got, ref)]
+    ratios = [b / a for a, b in zip(err["f32"], err["bf16x3"])]
+    return {"name": ops.ARITHMETIC, "operands": "fp32 (HBM, LDS staging input)", "results": "fp32",
+            "product": "a*b = sum of %d of the 9 products of three bf16 pieces per operand (a = a0+a1+a2 exact, round to nearest even); every piece product is exact" % BF16X3_TERMS,
+            "terms": BF16X3_TERMS, "accumulate": "fp32 (v_mfma_f32_16x16x32_bf16; a0b0 and the five small terms in separate accumulators, added in the epilogue)",
+            "instruction": "v_mfma_f32_16x16x32_bf16" if ops.ARITHMETIC == "bf16x3" else "v_mfma_f32_32x32x2_f32",
+            "error_vs_fp64": {"shape": "28x28x512 -> 128 1x1, batch 32: forward, data gradient, weight gradient (relative l2)",
+                              "fp32_mfma": [float("%.3e" % e) for e in err["f32"]], "bf16x3": [float("%.3e" % e) for e in err["bf16x3"]],
+                              "worst_ratio_bf16x3_over_fp32_mfma": round(max(ratios), 3), "bar": 1.05,
+                              "all_53_layers_x_3_products": "tests/test_gpu_split.py::test_all_53_layer_shapes_x_3_products_no_worse_than_fp32_mfma"},
+            "not_on_this_arithmetic": "the 3-channel image stem (forward, weight gradient), the strided data-gradient kernel (three 3x3 / stride-2 layers), attention and "
+                                      "NT-Xent Gram products run on v_mfma_f32_32x32x2_f32 (ssv_conv_arithmetic() reports per launch)",
+            "switch": "SSV_ARITHMETIC=f32 runs every product on v_mfma_f32_32x32x2_f32 (the arithmetic of rounds 1-5): the fp32_mfma_instruction_path leg of this line"}
+
+
+def fp32_instruction_leg(step, b, world, warmup=2, steps=6):
+    """The same step with every product on v_mfma_f32_32x32x2_f32 (ops.arithmetic('f32')), timed in this process after the headline's timed region: either reading of
+    `dtype: f32` finds its number in this line."""
+    from ssv_amd import ops
+    with ops.arithmetic("f32"):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": round(b * world * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "arithmetic": "every product on v_mfma_f32_32x32x2_f32 (SSV_ARITHMETIC=f32), same process, same inputs, after the timed region",
+            "roof_tflops": FP32_MFMA_PEAK_TFLOPS}
 
 
 def conv_macs_resnet50(h, w, proj_dim=128):
@@ -869,18 +927,23 @@ def main():
                 tot = [r for r in layer_rows if r["layer"].startswith("TOTAL")]
                 family_gb, family_src = round(2 * sum(float(r["fwd_GB"]) for r in tot), 1), used["layers"]
         attn_ms = prof.get("attn", (0.0, 0))[0] / args.prof_steps
+        from ssv_amd import ops as _ops
+        bf = _ops.ARITHMETIC == "bf16x3"
+        peak = BF16X3_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": ("implicit-GEMM family running the Linear layers" if args.algo == "dino" else "conv implicit-GEMM family") +
-                                           " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)",
-                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                                           (" (fwd+dgrad+wgrad; fp32 products as 6 bf16 piece products on v_mfma_f32_16x16x32_bf16)" if bf else " (fwd+dgrad+wgrad, fp32 v_mfma_f32_32x32x2_f32)"),
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "peak_is": ("dense bf16 MFMA peak 2,500 TFLOP/s / 6 piece products per fp32 product = 416.7 TFLOP/s of fp32 products" if bf else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                "frac_vs_fp32_mfma_roof": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 # `frac` / `frac_algorithmic` price the reference's ALGORITHMIC FLOPs (direct convolution); the Winograd layers execute
                 # 2.25x fewer multiplies, so the matrix pipe's own utilisation is `executed_frac` = FLOPs the MFMA counters saw / the same family time
-                "frac_algorithmic": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "executed_frac": None if executed_gflop is None else round(executed_gflop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4),
+                "frac_algorithmic": round(ach / peak, 4),
+                "executed_frac": None if executed_gflop is None else round(executed_gflop / conv_ms / peak, 4),
                 "executed_gflop_per_step": executed_gflop,
                 # the clock the chip held while the family's kernels ran in the counter pass (GRBM_GUI_ACTIVE / 8 XCDs / kernel time: DVFS under the fp32 MFMA
                 # load, MI355X_MICROARCH.md); `peak` above is the guide's figure at 2.4 GHz, so executed_frac ~= matrix-pipe busy fraction x clock / 2.4
                 "effective_clock_ghz": family_clock,
-                "executed_frac_of_peak_at_that_clock": None if (executed_gflop is None or not family_clock) else round(executed_gflop / conv_ms / (FP32_MFMA_PEAK_TFLOPS * family_clock / 2.4), 4),
+                "executed_frac_of_peak_at_that_clock": None if (executed_gflop is None or not family_clock) else round(executed_gflop / conv_ms / (peak * family_clock / 2.4), 4),
                 "counters_src_sha16": my_src, "counters_lib_sha16": my_lib, "counters_stale": bool(stale), "counters_rejected": stale or None,
                 "counters_note": "src_sha16 = the sources the LOADED library was compiled from (ssv_source_sha16; hipcc output is not bit-reproducible, so the file hash "
                                  "lib_sha16 only identifies one build artefact); traffic / mfma_counters / executed_frac / algorithmic_gb_per_step are replayed from "
@@ -898,11 +961,23 @@ def main():
                 "algorithmic_gflop_per_step": round(conv_flop_step / 1e9, 1), "kernel_ms_per_step": round(conv_ms, 3),
                 "launches_per_step": int(conv_launch), "avg_launch_ms": round(conv_ms / max(conv_launch, 1), 4),
                 "timing": "HIP events per launch over %d extra single-stream steps after the timed region" % args.prof_steps,
-                "whole_step_mfma_frac": round(images_per_s / world * (conv_flop_step + attn_flop_step) / b / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "whole_step_mfma_frac": round(images_per_s / world * (conv_flop_step + attn_flop_step) / b / 1e12 / peak, 4),
+                "whole_step_frac_vs_fp32_mfma_roof": round(images_per_s / world * (conv_flop_step + attn_flop_step) / b / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "mfma_counters": mfma,
                 "attention": None if not attn_flop_step else {"algorithmic_gflop_per_step": round(attn_flop_step / 1e9, 1), "kernel_ms_per_step": round(attn_ms, 3),
                                                               "achieved_tflops": round(attn_flop_step / max(attn_ms, 1e-9) / 1e9, 2)},
                 "classes": classes}
+
+    # ---- the same step on the fp32 MFMA instruction, and what the shipped arithmetic is (rank 0, one GPU: after the timed region) ----
+    fp32_leg, arith = None, None
+    if rank == 0 and world == 1 and not args.emulate_world:
+        from ssv_amd import ops as _ops
+        try:
+            arith = arithmetic_block(device)
+            if _ops.ARITHMETIC == "bf16x3":
+                fp32_leg = fp32_instruction_leg(step, b, world)
+        except Exception as exc:
+            fp32_leg = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- BASELINE config 3's per-rank step on this one GPU (default SimCLR line only; after the timed region and the instrumented steps) ----
     emu_block = None
@@ -940,6 +1015,8 @@ def main():
                    # every SSV_* variable in the environment: the product's diagnostic switches - {} = the shipped kernel selection
                    "diagnostic_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("SSV_")},
                    "library": os.path.relpath(_lib.LIB_PATH, ROOT)},
+        "arithmetic": arith,
+        "fp32_mfma_instruction_path": fp32_leg,
         "roofline": roof,
         "distributed": dist_info,
     }

@@ -51,7 +51,25 @@ typedef struct ssv_conv_desc {
   int32_t K, R, S;         /* filter [K,R,S,C]            */
   int32_t stride, pad;     /* same in both spatial dims   */
   int32_t Ho, Wo;          /* output [N,Ho,Wo,K]          */
+  /* ABI 120: HOW the launch multiplies.  SSV_ARITH_F32_MFMA (0): v_mfma_f32_32x32x2_f32 on the fp32 operands.  SSV_ARITH_BF16X3 (6): every fp32 operand as
+   * three bf16 pieces, six of the nine piece products (each exact) accumulated in fp32 by v_mfma_f32_16x16x32_bf16 - fp32 inputs, fp32 outputs, error against
+   * fp64 at or below the fp32-MFMA kernel's (csrc/split_bf16.h states the arithmetic and its edge cases; tests/test_gpu_split.py measures it on every layer
+   * shape of the networks).  It is a REQUEST: launches whose shape has no such kernel (C % 32 != 0 forward products - the image stem -, C % 4 != 0 weight
+   * gradients, the strided data-gradient kernel) run on fp32 MFMA; ssv_conv_arithmetic() tells which one a launch takes. */
+  int32_t arithmetic;
+  int32_t reserved;        /* 0 */
+  /* SSV_ARITH_BF16X3, launches with a WEIGHT operand (forward, data gradient): that operand pre-split by ssv_split_planes - [3][K][R*S*C] bf16, the `w` the
+   * launch is given, piece by piece - made once per weight and step instead of once per tile.  NULL: the launch runs on fp32 MFMA.  Weight gradients (both
+   * operands are activations, split while they are staged) ignore it. */
+  const void* w_planes;
 } ssv_conv_desc;
+enum { SSV_ARITH_F32_MFMA = 0, SSV_ARITH_BF16X3 = 6 };
+/* product: 0 forward-kernel launches (ssv_conv2d_fwd* / ssv_linear_*), 1 ssv_conv2d_dgrad*, 2 ssv_conv2d_wgrad*.  Returns the arithmetic the launch described by
+ * d will run on (SSV_ARITH_*), or SSV_ERR_INVALID */
+int ssv_conv_arithmetic(const ssv_conv_desc* d, int32_t product);
+/* planes[q][i], q < 3: the three bf16 pieces of x[i] (round to nearest even, residuals exact): x[i] == p0 + p1 + p2 for |x[i]| in [2^-109, 3.38e38].  n % 8 == 0,
+ * 16-byte aligned pointers; planes holds 3 n bf16 (6 n bytes). */
+int ssv_split_planes(int64_t n, const float* x, void* planes, void* stream);
 
 /* y = conv(x, w) (+ bias[k]) (+ addend)            bias/addend may be NULL */
 int ssv_conv2d_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -237,12 +255,16 @@ int ssv_wino44_dy_transform_both(int32_t N, int32_t H, int32_t W, int32_t K, con
 /* batched GEMMs on the implicit-GEMM kernels, ONE launch: y[b] = a[b] . w[b]^T   /   dw[b] = dy[b]^T . x[b]   (b < batch) */
 int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
                      float* y /*[batch][rows][K]*/, void* stream);
-/* The same product on the BF16 matrix pipe by operand splitting (csrc/gemm_split.hip; OPT-IN, ops.SPLIT_BF16_TERMS - the shipped step does not call it): each fp32
- * operand as three bf16 pieces, `terms` = 6 or 9 of the nine piece products accumulated in fp32 by v_mfma_f32_32x32x16_bf16; error against fp64 at or below
- * ssv_gemm_batched's (it replaces the same F.conv2d arithmetic, networks/resnet.py:56-58, in the transformed domain). */
-int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const float* w /*[batch][K][C]*/,
+/* The same products in SSV_ARITH_BF16X3 (ssv_conv_desc.arithmetic; csrc/split_bf16.h): w_planes = ssv_split_planes(batch * K * C, w) - [3][batch][K][C] bf16, ONE call over all the batch's filters;
+ * bias [K] (batch 1 only) and addend [batch][rows][K] ride in the epilogue as ssv_conv2d_fwd's do.  C % 32 == 0, K % 4 == 0.  (It replaces the same F.conv2d /
+ * nn.Linear arithmetic, networks/resnet.py:56-58, networks/vit.py:17-19, in the transformed domain or directly.) */
+int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a /*[batch][rows][C]*/, const void* w_planes /*[3][batch][K][C] bf16*/,
                            float* y /*[batch][rows][K]*/, const float* bias /*[K] or NULL (batch 1)*/, const float* addend /*[batch][rows][K] or NULL*/,
-                           int32_t terms, void* stream);
+                           void* stream);
+/* dw[b] = dy[b]^T . x[b] in SSV_ARITH_BF16X3: both operands split while they are staged.  max_chunk_rows / flush_rows as ssv_gemm_batched_wgrad_blocked (0 / 0: the
+ * plain split with the fp32 fold); workspace: ssv_gemm_batched_wgrad_blocked_workspace_bytes(batch, rows, C, K, max_chunk_rows). */
+int ssv_gemm_batched_wgrad_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
+                                 int32_t max_chunk_rows, int32_t flush_rows, void* ws, size_t ws_bytes, void* stream);
 size_t ssv_gemm_batched_wgrad_workspace_bytes(int32_t batch, int64_t rows, int32_t C, int32_t K);
 int ssv_gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x /*[batch][rows][C]*/, const float* dy /*[batch][rows][K]*/,
                            float* dw /*[batch][K][C]*/, void* ws, size_t ws_bytes, void* stream);
@@ -399,6 +421,9 @@ int ssv_barlow_cgrad(int32_t D, const float* craw, float inv_b, float lambda, fl
  * added to g first: the two views' backward passes run on two HIP streams and accumulate into separate slabs. */
 int ssv_sgd_nesterov(int64_t n, float* p, const float* g, const float* g2, float* buf, float lr, float weight_decay,
                      float momentum, int first_step, void* stream);
+/* the same update with (lr, weight_decay, momentum, first_step != 0) read from hyper[0..3] in DEVICE memory: the launch of a step replayed as a HIP graph, whose
+ * schedules (utils/train_utils.py:30-37, models/simclr.py:77-84) then move device floats instead of kernel arguments */
+int ssv_sgd_nesterov_dev(int64_t n, float* p, const float* g, const float* g2, float* buf, const float* hyper /*[4]*/, void* stream);
 /* BYOL.momentum_update models/byol.py:120-123: t = tau*t + (1-tau)*o over n floats */
 int ssv_ema(int64_t n, float* target, const float* online, float tau, void* stream);
 int ssv_fill(int64_t n, float* p, float value, void* stream);
@@ -520,6 +545,10 @@ int ssv_adamw(int64_t n, float* p, const float* g, const float* g2, float* m, fl
  * argument changes from step to step, so the step can be replayed as a HIP graph. */
 int ssv_adamw_counted(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int64_t* step_dev, float* bc_dev, float clip, void* stream);
+/* ssv_adamw_counted with the learning rate and the weight decay read from bc_dev[2], bc_dev[3] (device memory the host rewrites when a schedule moves them): no
+ * argument of the launch changes over a whole run - one captured HIP graph of the step serves every epoch (ssv_amd/graph.py). */
+int ssv_adamw_counted_dev(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float beta1, float beta2,
+                          float eps, int64_t* step_dev, float* bc_dev /*[4]*/, float clip, void* stream);
 
 /* MultiCrop (utils/augmentations.py:156-173): RandomResizedCrop(scale, ratio 3/4..4/3, BICUBIC) boxes drawn from the Philox
  * stream (seed, step, sample, view_base + crop), view_base >= 16; then crop + bicubic resize (align_corners = False, A = -0.75,

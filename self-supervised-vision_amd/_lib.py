@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSV_HIP_LIB") or os.path.join(_HERE, "csrc", "libssv_hip.so")   # override: diagnostic builds only
 
-ABI_VERSION = 111        # ssv_version() of the library this binding was written against (include/ssv_hip.h)
+ABI_VERSION = 120        # ssv_version() of the library this binding was written against (include/ssv_hip.h)
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "pool", "loss", "optim", "aug", "misc", "attn", "norm")
 
 
@@ -19,8 +19,11 @@ class SsvError(RuntimeError):
     pass
 
 
+ARITH_F32_MFMA, ARITH_BF16X3 = 0, 6      # ssv_conv_desc.arithmetic (include/ssv_hip.h)
+
+
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo", "arithmetic", "reserved")] + [("w_planes", C.c_void_p)]
 
 
 class BnGate(C.Structure):
@@ -103,7 +106,10 @@ SIGNATURES = {
     "ssv_wino44_filter_grad": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int, _vp]),
     "ssv_wino44_dy_transform_both": (C.c_int, [_i32, _i32, _i32, _i32, _vp, C.POINTER(BnDyin), _vp, _vp, _vp]),
     "ssv_gemm_batched": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "ssv_gemm_batched_split": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ssv_gemm_batched_split": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssv_gemm_batched_wgrad_split": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "ssv_split_planes": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "ssv_conv_arithmetic": (C.c_int, [_cd, _i32]),
     "ssv_gemm_batched_wgrad_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "ssv_gemm_batched_wgrad": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssv_gemm_batched_wgrad_blocked_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32, _i32]),
@@ -136,6 +142,7 @@ SIGNATURES = {
     "ssv_scale": (C.c_int, [_i64, _vp, _vp, _vp]),
     "ssv_barlow_cgrad": (C.c_int, [_i32, _vp, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "ssv_sgd_nesterov": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, C.c_int, _vp]),
+    "ssv_sgd_nesterov_dev": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssv_ema": (C.c_int, [_i64, _vp, _vp, _f32, _vp]),
     "ssv_fill": (C.c_int, [_i64, _vp, _f32, _vp]),
     "ssv_add": (C.c_int, [_i64, _vp, _vp, _vp]),
@@ -166,6 +173,7 @@ SIGNATURES = {
     "ssv_dino_center_update": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _f32, _vp, _vp]),
     "ssv_adamw": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "ssv_adamw_counted": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
+    "ssv_adamw_counted_dev": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
     "ssv_multicrop_params": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, _vp, _i64, _vp, _vp]),
     "ssv_multicrop": (C.c_int, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ssv_negdot_pair_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),

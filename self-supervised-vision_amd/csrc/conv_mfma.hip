@@ -26,6 +26,7 @@
 //                                fragments are ds_read_b32, 32 consecutive banks per half-wave.
 // Both operands of one MFMA always take the same k = 8*ks + 4*(l>>5) + t, so any mix is consistent.
 #include "common.h"
+#include "split_bf16.h"
 #include <string.h>
 #include <type_traits>
 
@@ -116,6 +117,10 @@ struct ConvKP {
   // Output columns [n0, n1) only depend on the input channels of the groups they fall into, so a tile's contraction runs over that channel range
   // instead of all of C (fwd: channels, dgrad: output channels), and a weight-gradient tile whose rows and columns share no group is skipped.
   int Cg, Kg;
+  // SSV_ARITH_BF16X3 (the SP kernel variants, csrc/split_bf16.h): the weight operand pre-split into three bf16 planes [3][K][RSC] (batched launches:
+  // [3][batch][K][RSC], ONE ssv_split_planes call over all the batch's filters); NULL in launches whose operands are both activations.  wp_stride: elements per plane
+  const unsigned short* w_planes;
+  long long wp_stride;
 };
 
 // [lo, hi) of the contraction channels (multiples of `bk`, hi capped at `ctot`) that the output columns [n0, n1) of a block-diagonal product can see:
@@ -148,7 +153,7 @@ __device__ __forceinline__ float gelu_grad_f(float v) { return ssv_gelu_grad(v);
 // Needs tensors below 2 GiB (offsets stay non-negative ints; OOB_OFF + any in-range offset is still out of range).
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr int OOB_OFF = (int)0x80000000u;
-__device__ __forceinline__ rsrc_t make_rsrc(const float* base, unsigned bytes) {
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ f32x4 bload4(rsrc_t rs, int voff_bytes, int soff_bytes) {
@@ -432,6 +437,74 @@ __device__ __forceinline__ void k_loop2(int nkt, const float* As, const float* B
   }
 }
 
+// The k-loop of the SSV_ARITH_BF16X3 variants (csrc/split_bf16.h): the same register-prefetch loop as k_loop - ONE LDS stage, two barriers per k-tile, the next
+// tile's global loads in flight under this tile's MFMAs - over LDS images of three bf16 planes per operand.  A k-tile is 32 of the contraction = one
+// v_mfma_f32_16x16x32_bf16 per (16 x 16 tile, piece product): 6 x TM16 x TN16 per wave.  KROWA / KROWB: that operand's image is k-major (both in the weight
+// gradient, the weights in the strided data gradient; transposed reads).
+// The structure was chosen by measurement (tools/probe/gemm_split_tuned_probe.hip, profiles/r06_probe_split_tuned.txt): two LDS stages with one barrier per tile lose
+// at every occupancy the LDS allows (106-160 against 175-185 TFLOP/s at 4096^3), the 16 x 16 x 32 instruction beats 32 x 32 x 16 by 6-15 % on every shape (the chip
+// holds a higher clock under it), and the split's vector work hides under the other resident workgroups' MFMAs (a build without the residual arithmetic: +0-1 %).
+template <int TM16, int TN16, bool KROWA, bool KROWB, int RBA, int RBB, int FLUSH = 0, class LoadTile, class StoreTile, class Xform = NoXform>
+__device__ __forceinline__ void k_loop_split(int nkt, const unsigned char* As, int a_plane, const unsigned char* Bs, int b_plane, int wr0, int wc0, int lane,
+                                             f32x4 (&acc)[TM16][TN16], LoadTile&& load_tile, StoreTile&& store_tile, Xform&& xform_tile = NoXform()) {
+  if (nkt <= 0) return;
+  f32x4 hi[FLUSH > 0 ? TM16 : 1][FLUSH > 0 ? TN16 : 1];
+  if constexpr (FLUSH > 0) {
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN16; ++j) hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 lo[TM16][TN16];                          // the five small piece products of every tile (splitbf::mma6), folded into acc at the end
+#pragma unroll
+  for (int i = 0; i < TM16; ++i)
+#pragma unroll
+    for (int j = 0; j < TN16; ++j) lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load_tile();
+  xform_tile();
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    load_tile();                               // past the last tile: out-of-range offsets read zeros (or in-buffer rows never stored)
+    bf16x8 fb[TN16][3];
+#pragma unroll
+    for (int j = 0; j < TN16; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if constexpr (KROWB) fb[j][q] = splitbf::krow_frag<RBB>(Bs + q * b_plane, wc0 + 16 * j, lane);
+        else fb[j][q] = splitbf::rowk_frag(Bs + q * b_plane, wc0 + 16 * j, lane);
+      }
+#pragma unroll
+    for (int i = 0; i < TM16; ++i) {
+      bf16x8 fa[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if constexpr (KROWA) fa[q] = splitbf::krow_frag<RBA>(As + q * a_plane, wr0 + 16 * i, lane);
+        else fa[q] = splitbf::rowk_frag(As + q * a_plane, wr0 + 16 * i, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < TN16; ++j) splitbf::mma6(acc[i][j], lo[i][j], fb[j], fa);
+    }
+    if constexpr (FLUSH > 0) {
+      if ((kt + 1) % FLUSH == 0) {               // uniform
+#pragma unroll
+        for (int i = 0; i < TM16; ++i)
+#pragma unroll
+          for (int j = 0; j < TN16; ++j) { hi[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) { xform_tile(); store_tile(0); __syncthreads(); }
+  }
+#pragma unroll
+  for (int i = 0; i < TM16; ++i)
+#pragma unroll
+    for (int j = 0; j < TN16; ++j) {
+      if constexpr (FLUSH > 0) acc[i][j] = hi[i][j] + acc[i][j];
+      acc[i][j] += lo[i][j];
+    }
+}
+
 // Vectorised epilogue: a wave's accumulators hold one COLUMN per lane (32 consecutive columns per 32x32 tile), so a direct
 // store is 4 bytes per lane and 16*TM*TN instructions.  Staging 32-row slabs of the wave's tile through its own LDS
 // region turns that into 16-byte-per-lane stores of whole 256-byte row segments (4x fewer store instructions, and the
@@ -474,8 +547,30 @@ __device__ __forceinline__ void bstore4(rsrc_t rs, int voff_bytes, f32x4 v) {
 // of that row in the addend tensor, or -1 for "this row has no addend" (the compact gradient of a stride-2 shortcut: only rows with even
 // (h, w) carry one).  SameOff = the addend has the output's layout.
 struct SameOff {};
-template <int TM, int TN, int EPI = 0, bool STATS = false, int GATE = 0, class RowOff, class AddOff = SameOff>
-__device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int lane, int col0, int ncols,
+// one 32-row slab (slab tm) of a wave's accumulators -> its LDS staging area [32][TN * 32 + 4]: the fp32-MFMA tiles hold a column per lane (scalar writes), the
+// 16 x 16 tiles of the bf16 piece products (splitbf::mma6: column operand first) four consecutive columns of one row per lane (16-byte writes)
+template <int TM, int TN>
+__device__ __forceinline__ void stage_slab(const f32x16 (&acc)[TM][TN], float* __restrict__ ep, int tm, int lane) {
+  constexpr int LDE = TN * 32 + 4;
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
+}
+template <int TM, int TN>
+__device__ __forceinline__ void stage_slab(const f32x4 (&acc)[2 * TM][2 * TN], float* __restrict__ ep, int tm, int lane) {
+  constexpr int LDE = TN * 32 + 4;
+  const int fr = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 2 * TN; ++jj) *reinterpret_cast<f32x4*>(&ep[(16 * ii + fr) * LDE + 16 * jj + 4 * kg]) = acc[2 * tm + ii][jj];
+}
+template <bool SP, class A, class B> __device__ __forceinline__ auto& sel_acc(A& a, B& b) { if constexpr (SP) return b; else return a; }
+
+template <int TM, int TN, int EPI = 0, bool STATS = false, int GATE = 0, class Acc, class RowOff, class AddOff = SameOff>
+__device__ __forceinline__ void epilogue_vec(const Acc& acc, float* __restrict__ ep, int lane, int col0, int ncols,
                                              const float* __restrict__ bias, const float* addend, float* out, long long out_elems, RowOff&& row_off,
                                              float* out_act = nullptr, const float* gate = nullptr,
                                              float* pmean = nullptr, float* pm2 = nullptr, int group_rows = 0,
@@ -486,7 +581,6 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
   // the two-target gate (GATE 3) is compiled for 2 per CU and uses the room for 4 rows in flight (r03 x1: 1.43 -> 1.34 ms on the 56x56 unit input)
   constexpr int HB0 = GATE == 1 ? 2 : 4;
   constexpr int HB = NP < HB0 ? NP : HB0;
-  const int l31 = lane & 31, h = lane >> 5;
   const int r_in = lane / C4, c4 = lane % C4;
   const int gcol = col0 + c4 * 4;
   const bool cok = gcol < ncols && r_in < RPI;          // TN = 3 (C4 = 24 lanes per row): the last 16 lanes of a wave have no row in a pass
@@ -522,10 +616,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
     const rsrc_t r_act = make_rsrc((EPI == 1 || EPI == 4) ? out_act : out, bytes);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) ep[((j & 3) + 8 * (j >> 2) + 4 * h) * LDE + tn * 32 + l31] = acc[tm][tn][j];
+      stage_slab<TM, TN>(acc, ep, tm, lane);
       if constexpr (STATS) { if (tm == 0) st_p = *reinterpret_cast<const f32x4*>(&ep[c4 * 4]); }     // pivot: first row of the group
       // Rows go through in steps of HB: a step issues its loads (addend, gate operands: in flight together), then computes and stores.  (Issuing the NEXT
       // step's loads before this step's stores - so that waiting for them does not also wait for the stores on gfx9's single in-order counter - was
@@ -667,12 +758,16 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[TM][TN], float*
 // (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false, bool S2 = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false, bool S2 = false, bool SP = false>
 // Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
 // 28x28 layers); the two-target gate (GATE 3) needs 218.  (kernel_resources.py lists every variant; r03_experiments_step_time.txt the A/Bs.)
-__global__ void __launch_bounds__(256, (OPM == 2 || GATE == 3 || S2 || C4 == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC)) SSV_CONV_ATTR
+// SP (SSV_ARITH_BF16X3, csrc/split_bf16.h; the float4 path only): the same launch on the bf16 matrix pipe - the A operand is split into three bf16 planes while it is
+// staged (after its formed-on-load transform), the weights arrive pre-split (p.w_planes), the main loop is k_loop_split and the accumulators are 16 x 16 tiles; every
+// epilogue is the fp32 variant's.  LDS: 192 bytes per staged row = 48 KB on the 128 x 128 tile (the fp32 image: 36.9 KB); narrow outputs (K < 128) take a 128 x 64
+// tile (36 KB, half the accumulators) where the fp32 variants take 256 x 64.  Two accumulator sets (splitbf::mma6): 2 workgroups per CU on the wide tile.
+__global__ void __launch_bounds__(256, SP ? ((BN == 128 || OPM == 2) ? 2 : 3) : ((OPM == 2 || GATE == 3 || S2 || C4 == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC))) SSV_CONV_ATTR
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -684,10 +779,13 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);     // the vectorised epilogue's staging area (one 32-row slab per wave)
   static_assert(!S2 || (VEC && C4 == 0 && !XF && OPM == 0), "the two-stage loop serves the plain float4 path");
   static_assert(C4 != 3 || (VEC && BM == 256 && BK == 32 && TM == 2 && !XF && OPM == 0 && !S2 && EP_FLOATS <= HALO_FLOATS), "the halo loader serves the 256-row tile of the plain float4 path");
-  constexpr int SMEM = C4 == 3 ? HALO_FLOATS : (S2 ? 2 * STAGE : ((VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE));
+  static_assert(!SP || (VEC && C4 == 0 && !S2 && BK == 32), "the bf16-piece variants are the float4 path with K-step 32");
+  constexpr int SP_FLOATS = (BM + BN) * 48;             // three planes of 64-byte rows per operand
+  constexpr int SMEM = SP ? (SP_FLOATS > EP_FLOATS ? SP_FLOATS : EP_FLOATS)
+                          : (C4 == 3 ? HALO_FLOATS : (S2 ? 2 * STAGE : ((VEC && (EPI || STATS || GATE != 0 || OPM != 0) && EP_FLOATS > STAGE) ? EP_FLOATS : STAGE)));
   static_assert(!S2 || 2 * STAGE >= EP_FLOATS, "epilogue staging must fit the two stages");
   __shared__ __attribute__((aligned(16))) float smem[SMEM + SSV_EXP_LDS_PAD];
-  __shared__ __attribute__((aligned(16))) float xfs[XF ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm
+  __shared__ __attribute__((aligned(16))) float xfs[(XF && !SP) ? 2 * XF_MAXC : 4];    // [scale | shift] of the fused input BatchNorm (SP: read per k-tile, the LDS is the planes')
   float* As = smem;
   float* Bs = smem + BM * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -697,9 +795,16 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
   const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   x += (size_t)blockIdx.y * p.bs_a; w += (size_t)blockIdx.y * p.bs_b; y += (size_t)blockIdx.y * p.bs_o;      // batched GEMMs (uniform; 0 otherwise)
+  if (addend) addend += (size_t)blockIdx.y * p.bs_o;
 
-  f32x16 acc[TM][TN];
-  zero_acc<TM, TN>(acc);
+  f32x16 acc[SP ? 1 : TM][SP ? 1 : TN];
+  f32x4 acc16[SP ? 2 * TM : 1][SP ? 2 * TN : 1];       // SP: 16 x 16 tiles of the bf16 piece products
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else zero_acc<SP ? 1 : TM, SP ? 1 : TN>(acc);
 #if SSV_EXP_WGPRIO
   wg_static_priority();
 #endif
@@ -989,8 +1094,23 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         ktiles = p.R * p.S * ((c_hi - lc0) / BK);
       }
     }
-    f32x4 ra[AP], rb[BP];
-    f32x4 ra2[OPM ? AP : 1], co[OPM ? 4 : 1];
+    f32x4 ra[AP], rb[SP ? 1 : BP];
+    f32x4 ra2[OPM ? AP : 1], co[(OPM || (XF && SP)) ? 4 : 1];
+    // SP: the weight tile arrives as three bf16 planes, 16-byte pieces (8 k of one filter row) straight to LDS: BN * 4 pieces per plane and k-tile
+    constexpr int BPP = SP ? (BN * 4 + 255) / 256 : 1;
+    u32x4 rbp[SP ? 3 : 1][BPP];
+    int boffp[BPP], bldsp[BPP];
+    const long long wplane = p.wp_stride;                               // elements per plane (all batch elements)
+    const rsrc_t rwp = make_rsrc(SP ? (const void*)(p.w_planes + (size_t)blockIdx.y * p.bs_b) : (const void*)w, SP ? (unsigned)((2 * wplane + (long long)p.K * p.RSC) * 2) : 16u);
+    if constexpr (SP) {
+#pragma unroll
+      for (int i = 0; i < BPP; ++i) {
+        const int idx = tid + 256 * i, br = idx >> 2, k8 = idx & 3;
+        boffp[i] = (idx < BN * 4 && n0 + br < p.K) ? ((n0 + br) * p.RSC + k8 * 8) * 2 : OOB_OFF;
+        bldsp[i] = splitbf::rowk_off(br, k8);
+      }
+    }
+    const rsrc_t rxs0 = make_rsrc((XF && SP) ? p.xf_scale : x, (XF && SP) ? (unsigned)p.C * 4u : 16u), rxs1 = make_rsrc((XF && SP) ? p.xf_shift : x, (XF && SP) ? (unsigned)p.C * 4u : 16u);
     const rsrc_t rx2 = make_rsrc(DYF ? p.dyin_x : (SUM ? p.sum_res : x), (unsigned)p.N * p.H * p.W * p.C * 4u);
     const rsrc_t rco = make_rsrc(DYF ? p.dyin_coef : x, DYF ? (unsigned)p.C * 16u : 16u);
     const rsrc_t rs0 = make_rsrc(SUM ? p.sum_scale : x, (unsigned)p.C * 4u), rs1 = make_rsrc(SUM ? p.sum_shift : x, (unsigned)p.C * 4u);
@@ -1000,7 +1120,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     const rsrc_t rsm = make_rsrc(SUM && p.sum_mask ? reinterpret_cast<float*>(p.sum_mask) : y, (unsigned)p.N * p.H * p.W * (p.C / 4));
     int st_off = 0;                // SUM: uniform byte offset of the tile being transformed (the loader has moved on by then)
     int xf_ok = 0, xf_c = 0;       // XF: which of the staged rows hold real pixels (bit i), first channel of this thread's float4
-    if constexpr (XF) {
+    if constexpr (XF && !SP) {
       for (int c = tid; c < p.C; c += 256) { xfs[c] = p.xf_scale[c]; xfs[XF_MAXC + c] = p.xf_shift[c]; }
       __syncthreads();
     }
@@ -1008,6 +1128,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
       const int toff_x = ((lr * p.W + ls) * p.C + lc0) * 4;    // uniform
       const int toff_w = ((lr * p.S + ls) * p.C + lc0) * 4;
       if constexpr (XF) { xf_ok = 0; xf_c = lc0 + chunk; }
+      if constexpr (XF && SP) { co[0] = bload4(rxs0, chunk * 4, lc0 * 4); co[1] = bload4(rxs1, chunk * 4, lc0 * 4); }
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const bool ok = inb | (((unsigned)(hi0[i] + lr) < (unsigned)p.H) & ((unsigned)(wi0[i] + ls) < (unsigned)p.W));
@@ -1025,8 +1146,16 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         if (raff) { co[2] = bload4(rs2, chunk * 4, lc0 * 4); co[3] = bload4(rs3, chunk * 4, lc0 * 4); }
         else { co[2] = f32x4{1.f, 1.f, 1.f, 1.f}; co[3] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
+      if constexpr (SP) {
 #pragma unroll
-      for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < BPP; ++i)
+            rbp[q][i] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rwp, boffp[i] == OOB_OFF ? OOB_OFF : boffp[i] + q * (int)(wplane * 2), toff_w >> 1, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff[i], toff_w);
+      }
       // k order = (channel chunk, r, s) with the TAPS innermost: consecutive k-tiles re-read the same pixels' 128-byte channel
       // slice shifted by one tap, so the re-reads hit in L2 (with the channel chunk innermost every tap came back from HBM / the
       // infinity cache: 8-10x the input bytes on the 3x3 layers).  Straight-line advance (selects, no branches) keeps the k-loop
@@ -1044,7 +1173,9 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         // the staged values are the producer's raw conv output: apply its BatchNorm + ReLU here (same fmaf / fmaxf as bn_apply_k,
         // so the operand is bit-identical to the materialised activation); padding taps stay exactly zero.  A row past M keeps
         // relu(shift) - harmless, its output row is never stored nor counted.
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(&xfs[xf_c]), sh = *reinterpret_cast<const f32x4*>(&xfs[XF_MAXC + xf_c]);
+        f32x4 sc, sh;
+        if constexpr (SP) { sc = co[0]; sh = co[1]; }
+        else { sc = *reinterpret_cast<const f32x4*>(&xfs[xf_c]); sh = *reinterpret_cast<const f32x4*>(&xfs[XF_MAXC + xf_c]); }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
           // ReLU and "a padding tap stays zero" in ONE instruction per element: clamp to [0, cap] with cap = +inf for a real pixel and
@@ -1083,14 +1214,28 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         }
       }
     };
+    constexpr int A_PLANE = BM * splitbf::ROWB, B_PLANE = BN * splitbf::ROWB;
+    unsigned char* const Asb = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* const Bsb = Asb + 3 * A_PLANE;
     auto store_tile = [&](int buf) {
+      if constexpr (SP) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) splitbf::rowk_store(Asb, A_PLANE, rsub + RPP * i, tid % CH, ra[i]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < BPP; ++i)
+            if (BN * 4 % 256 == 0 || tid + 256 * i < BN * 4) *reinterpret_cast<u32x4*>(Bsb + q * B_PLANE + bldsp[i]) = rbp[q][i];
+        return;
+      }
       const int so = S2 ? buf * STAGE : 0;
 #pragma unroll
       for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[so + (rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
       for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[so + (rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    if constexpr (S2) k_loop2<TM, TN, LDT, BK, AP + BP, STAGE>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+    if constexpr (SP) k_loop_split<2 * TM, 2 * TN, false, false, 128, 128>(ktiles, Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile, xform_tile);
+    else if constexpr (S2) k_loop2<TM, TN, LDT, BK, AP + BP, STAGE>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
     else k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
   } else {
     // ---- generic gather (any C; used by the 3-channel stem): scalar staging, k -> (r,s,c) per element ----
@@ -1164,7 +1309,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         constexpr int GR = TM * 32;
         const int g = rbase / GR;
         const int valid = min(GR, p.M - rbase);
-        epilogue_vec<TM, TN, 0, true>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
+        epilogue_vec<TM, TN, 0, true>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                           nullptr, nullptr, p.aux_out + (size_t)g * p.K, p.aux_out2 + (size_t)g * p.K, valid > 0 ? valid : 0);
       } else if constexpr (GATE != 0) {
@@ -1182,15 +1327,15 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
             if ((ho | wo) & 1u) return -1;
             return ((long long)((int)n * p.add_H2 + (int)(ho >> 1)) * p.add_W2 + (int)(wo >> 1)) * p.K;
           };
-          epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
+          epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
                                                    nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64), add_off,
                                                    (long long)p.N * p.add_H2 * p.add_W2 * p.K);
         } else {
-          epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
+          epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
                                                    nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
         }
       } else {
-        epilogue_vec<TM, TN, EPI>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
+        epilogue_vec<TM, TN, EPI>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                   [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                   (EPI == 1 || EPI == 4) ? p.aux_out : nullptr, (EPI == 2 || EPI == 5) ? p.aux_in : nullptr);
       }
@@ -1198,6 +1343,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
     }
   }
   static_assert(GATE == 0 || (VEC && EP_FLOATS <= SMEM), "the gated epilogue is the vectorised one");
+  if constexpr (SP) return;            // K % 4 == 0 is a launch precondition of the bf16-piece variants
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -1224,12 +1370,15 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 // dgrad: rows are the input pixels of ONE stride-parity class (blockIdx.y); only taps with
 // (ph + pad - r) % stride == 0 contribute to that class, with ho = hq + (ph + pad - r)/stride.
 // =============================================================================================
-template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false, int GATE = 0>
-__global__ void __launch_bounds__(256, SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
+// SP (SSV_ARITH_BF16X3; the 128 x 128 tile with K-step 32): dY rows are split while they are staged (ROWK planes), the weights arrive pre-split (p.w_planes) and keep their
+// k-major image ([32 output channels][input channels] per plane), read by transposed reads.
+template <int BM, int BN, int WGM, int WGN, int BK, bool EPI = false, int GATE = 0, bool SP = false>
+__global__ void __launch_bounds__(256, SP ? 2 : SSV_CONV_WGPC) SSV_CONV_ATTR      // 3 workgroups per CU: they hide each other's barriers, loads and epilogues
 conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w, const float* addend, float* dx) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int LDT = BK + 4;
-  constexpr int A_FLOATS = BM * LDT, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
+  static_assert(!SP || (BK == 32 && BN == 128), "the bf16-piece data gradient: K-step 32, 128 input channels per tile");
+  constexpr int A_FLOATS = BM * LDT, B_FLOATS = BK * BN, STAGE = SP ? 48 * (BM + BN) : A_FLOATS + B_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[STAGE + SSV_EXP_LDS_PAD];
   __shared__ unsigned rowpix[BM];
   __shared__ int taps[64 * 3];      // (dho, dwo, tapoff) per valid tap
@@ -1287,8 +1436,14 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   __syncthreads();
   const int ntaps = ntaps_s;
 
-  f32x16 acc[TM][TN];
-  zero_acc<TM, TN>(acc);
+  f32x16 acc[SP ? 1 : TM][SP ? 1 : TN];
+  f32x4 acc16[SP ? 2 * TM : 1][SP ? 2 * TN : 1];
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else zero_acc<SP ? 1 : TM, SP ? 1 : TN>(acc);
 
   constexpr int CH = BK / 4, RPP = 256 / CH;
   constexpr int AP = BM / RPP;           // A passes: RPP rows x CH float4 per pass
@@ -1325,7 +1480,20 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
   }
   int dho = 0, dwo = 0, tapoff = 0;
   if (ntaps > 0) { dho = taps[0]; dwo = taps[1]; tapoff = taps[2]; }
-  f32x4 ra[AP], rb[BP];
+  f32x4 ra[AP], rb[SP ? 1 : BP];
+  // SP: the [32 k][BN c] weight tile of every plane in 16-byte pieces (8 input channels of one output channel's tap): 32 * BN / 8 pieces per plane
+  constexpr int BPP = SP ? 32 * (BN / 8) / 256 : 1;
+  u32x4 rbp[SP ? 3 : 1][BPP];
+  int boffp[BPP], bldsp[BPP];
+  const rsrc_t rwp = make_rsrc(SP ? (const void*)p.w_planes : (const void*)w, SP ? (unsigned)(3 * p.wp_stride * 2) : 16u);
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < BPP; ++i) {
+      const int idx = tid + 256 * i, kr = idx / (BN / 8), c8 = idx % (BN / 8);
+      boffp[i] = n0 + c8 * 8 < p.C ? (kr * p.RSC + n0 + c8 * 8) * 2 : OOB_OFF;
+      bldsp[i] = splitbf::krow_off<BN * 2>(kr, c8);
+    }
+  }
   auto load_tile = [&]() {
     const int toff_a = ((dho * p.Wo + dwo) * p.K + lk0) * 4;   // uniform (may be negative: folded into the lane offset)
     const int toff_b = (lk0 * p.RSC + tapoff) * 4;
@@ -1334,8 +1502,16 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
       const bool ok = inb | (((unsigned)(hq_[i] + dho) < (unsigned)p.Ho) & ((unsigned)(wq_[i] + dwo) < (unsigned)p.Wo));
       ra[i] = bload4(rdy, ok ? aoff[i] + toff_a : OOB_OFF, 0);
     }
+    if constexpr (SP) {
 #pragma unroll
-    for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff + BRP * i * p.RSC * 4, toff_b);
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < BPP; ++i)
+          rbp[q][i] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rwp, boffp[i] == OOB_OFF ? OOB_OFF : boffp[i] + q * (int)(p.wp_stride * 2), toff_b >> 1, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = bload4(rw, boff + BRP * i * p.RSC * 4, toff_b);
+    }
     // straight-line advance to the next (k-tile, tap) with the TAPS innermost: consecutive tiles re-read the same dY pixels'
     // channel slice one tap over and hit in L2 (see the forward kernel)
     ti += 1;
@@ -1344,13 +1520,26 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
     lk0 += w1 ? BK : 0;
     dho = taps[3 * ti]; dwo = taps[3 * ti + 1]; tapoff = taps[3 * ti + 2];
   };
+  constexpr int A_PLANE = BM * splitbf::ROWB, B_PLANE = 32 * BN * 2;
+  unsigned char* const Asb = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* const Bsb = Asb + 3 * A_PLANE;
   auto store_tile = [&](int buf) {
+    if constexpr (SP) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) splitbf::rowk_store(Asb, A_PLANE, rsub + RPP * i, tid % CH, ra[i]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < BPP; ++i) *reinterpret_cast<u32x4*>(Bsb + q * B_PLANE + bldsp[i]) = rbp[q][i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(rsub + RPP * i) * LDT + chunk]) = ra[i];
 #pragma unroll
     for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rb[i];
   };
-  k_loop<TM, TN, true, false, LDT, BN, BK, AP + BP>(ntaps * (kspan / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
+  if constexpr (SP) k_loop_split<2 * TM, 2 * TN, false, true, 128, BN * 2>(ntaps * (kspan / BK), Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile);
+  else k_loop<TM, TN, true, false, LDT, BN, BK, AP + BP>(ntaps * (kspan / BK), As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
 
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);
   static_assert(!EPI || EP_FLOATS <= STAGE, "the fused-activation dgrad needs the vectorised epilogue");
@@ -1359,16 +1548,17 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
     if constexpr (GATE != 0) {
       // partial index: (parity class, row tile, 64-row group of the wave) - the grid has the same number of row tiles for every class
       const long long grp = ((long long)blockIdx.y * (gridDim.x / NT) + mt) * (BM / 64) + (wr0 / 64);
-      epilogue_vec<TM, TN, 0, false, GATE>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx, (long long)p.N * p.H * p.W * p.C,
+      epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx, (long long)p.N * p.H * p.W * p.C,
                                                [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
                                                nullptr, nullptr, nullptr, nullptr, 0, &p.gate, grp);
     } else {
-      epilogue_vec<TM, TN, EPI ? 2 : 0>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx, (long long)p.N * p.H * p.W * p.C,
+      epilogue_vec<TM, TN, EPI ? 2 : 0>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.C, nullptr, addend, dx, (long long)p.N * p.H * p.W * p.C,
                                         [&](int r) -> long long { const unsigned pix = rowpix[wr0 + r]; return pix != 0xffffffffu ? (long long)pix * p.C : -1; },
                                         nullptr, EPI ? p.aux_in : nullptr);
     }
     return;
   }
+  if constexpr (SP) return;
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -1404,11 +1594,14 @@ conv_dgrad_k(ConvKP p, const float* __restrict__ dy, const float* __restrict__ w
 // BIAS (LIN gather): the workgroups of column tile 0 also sum the dY rows they stage - the bias gradient's column sums, one partial row per split
 //       (p.aux_out [nsplit][K]), reduced with the weight gradient's slabs in the same fixed order: the stand-alone column-sum pass over dY disappears.
 // FLUSH: two-level accumulation, see k_loop (the blocked batched weight gradient only).
-template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false, bool BIAS = false, int FLUSH = 0>
-__global__ void __launch_bounds__(256)
+// SP (SSV_ARITH_BF16X3, csrc/split_bf16.h; float4 gathers only): BOTH operands are activations, so both are split into three bf16 planes while they are staged; the LDS
+//     images stay k-major ([32 pixels][channels], as the rows lie in HBM) and the fragments come out of them by transposed reads (ds_read_b64_tr_b16).
+template <int BM, int BN, int WGM, int WGN, int BK, bool VECB, int GATHER, bool XF = false, bool DYF = false, bool BIAS = false, int FLUSH = 0, bool SP = false>
+__global__ void __launch_bounds__(256, (SP && BM == 128 && BN == 128) ? 2 : 1)
 conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int chunk_rows, int tiles) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  constexpr int STAGE = BK * (BM + BN);
+  static_assert(!SP || (VECB && GATHER != 3 && BK == 32), "the bf16-piece variants: float4 gathers, K-step 32");
+  constexpr int STAGE = SP ? 48 * (BM + BN) : BK * (BM + BN);   // SP: three planes of [32][channels] bf16 per operand
   constexpr int EP_FLOATS = 4 * 32 * (TN * 32 + 4);            // the vectorised epilogue's staging area (one 32-row slab per wave)
   static_assert(!XF || VECB, "the fused-input variant is the float4 path");
   static_assert(!DYF || (VECB && GATHER == 1), "the BatchNorm-backward operand: 1x1 / stride 1 layers");
@@ -1435,8 +1628,14 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
     }
   }
 
-  f32x16 acc[TM][TN];
-  zero_acc<TM, TN>(acc);
+  f32x16 acc[SP ? 1 : TM][SP ? 1 : TN];
+  f32x4 acc16[SP ? 2 * TM : 1][SP ? 2 * TN : 1];
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else zero_acc<SP ? 1 : TM, SP ? 1 : TN>(acc);
 
   // A = dY rows (float4 along output channels)
   constexpr int ACV = BM / 4, ARP = 256 / ACV, AP = BK / ARP;
@@ -1614,9 +1813,15 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
       }
     }
   };
+  constexpr int A_PLANE = 32 * BM * 2, B_PLANE = 32 * BN * 2;            // SP: bytes of one plane of the dY / X image
+  unsigned char* const Asb = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* const Bsb = Asb + 3 * A_PLANE;
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
+    for (int i = 0; i < AP; ++i) {
+      if constexpr (SP) splitbf::krow_store<BM * 2>(Asb, A_PLANE, arow + ARP * i, acol, ra[i]);
+      else *reinterpret_cast<f32x4*>(&As[(arow + ARP * i) * BM + acol]) = ra[i];
+    }
     if constexpr (BIAS) {
       if (jt == 0) {
 #pragma unroll
@@ -1628,11 +1833,13 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
       if constexpr (GATHER == 3) {
         const int f = tid + 256 * i;
         if (f < BK * BCV) *reinterpret_cast<f32x4*>(&Bs[(f / BCV) * BN + (f % BCV) * 4]) = rbv[i];
-      } else if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
+      } else if constexpr (SP) splitbf::krow_store<BN * 2>(Bsb, B_PLANE, brow + BRP * i, bcol, rbv[i]);
+      else if constexpr (VECB) *reinterpret_cast<f32x4*>(&Bs[(brow + BRP * i) * BN + bcol]) = rbv[i];
       else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
-  k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0), FLUSH>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
+  if constexpr (SP) k_loop_split<2 * TM, 2 * TN, true, true, BM * 2, BN * 2, FLUSH>((me - ms + BK - 1) / BK, Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile, xform_tile);
+  else k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0), FLUSH>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
 
   if constexpr (BIAS) {
     static_assert(STAGE >= (256 / (BM / 4)) * BM, "the bias partials are folded through the stage buffer");
@@ -1652,10 +1859,11 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
   float* out = partial + (size_t)split * p.K * NCOL;
   if ((NCOL & 3) == 0) {       // whole 16-byte row segments through the wave's LDS slab (4x fewer store instructions), as in the forward kernel
     const int rbase = i0 + wr0;
-    epilogue_vec<TM, TN>(acc, smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, NCOL, nullptr, nullptr, out, (long long)p.K * NCOL,
+    epilogue_vec<TM, TN>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, j0 + wc0, NCOL, nullptr, nullptr, out, (long long)p.K * NCOL,
                          [&](int r) -> long long { const int row = rbase + r; return row < p.K ? (long long)row * NCOL : -1; });
     return;
   }
+  if constexpr (SP) return;            // NCOL % 4 == 0 follows from C % 4 == 0, a launch precondition of the bf16-piece variants
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -1729,6 +1937,8 @@ ConvKP make_kp(const ssv_conv_desc* d) {
   p.bs_a = p.bs_b = p.bs_o = 0;
   p.add_H2 = p.add_W2 = 0;
   p.Cg = p.Kg = 0;
+  p.w_planes = (const unsigned short*)d->w_planes;
+  p.wp_stride = (long long)d->K * p.RSC;
   return p;
 }
 
@@ -1768,6 +1978,19 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d, int groups = 0) {
 namespace {
 
 
+// Does a forward-kernel launch described by d run its bf16-piece variant (SSV_ARITH_BF16X3)?  The float4 path with whole 32-channel k-tiles, 16-byte output rows, a
+// pre-split weight operand (a block-diagonal bank included: its tiles contract over their own groups' channels in either arithmetic).
+inline bool sp_fwd_ok(const ssv_conv_desc* d, int groups = 0) {
+  return d->arithmetic == SSV_ARITH_BF16X3 && d->w_planes != nullptr && (((uintptr_t)d->w_planes) & 15) == 0 && d->C % 32 == 0 && d->K % 4 == 0;
+}
+// the strided data-gradient kernel: its 128 x 128 tile (C >= 128), whole 32-channel k-tiles of the output channels, the weights pre-split
+inline bool sp_dgrad_ok(const ssv_conv_desc* d) {
+  return d->arithmetic == SSV_ARITH_BF16X3 && d->w_planes != nullptr && (((uintptr_t)d->w_planes) & 15) == 0 && d->K % 32 == 0 && d->C >= 128 && d->C % 8 == 0;
+}
+inline bool sp_wgrad_ok(const ssv_conv_desc* d, int groups = 0) {
+  return d->arithmetic == SSV_ARITH_BF16X3 && d->C % 4 == 0 && d->K % 4 == 0;
+}
+
 // forward family: optional statistics epilogue (pmean / pm2) and optional fused input BatchNorm + ReLU (in_scale / in_shift)
 int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y,
                float* pmean, float* pm2, const float* in_scale, const float* in_shift, hipStream_t s, const ssv_bn_gate* gate = nullptr,
@@ -1777,10 +2000,11 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
   if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
+  const bool sp = sp_fwd_ok(d, groups);
   const bool wide = d->K >= 128 && groups <= 1;               // block-diagonal banks: the 64-column tile sees the fewest foreign groups
   // (1x1 layers with few k-tiles - 64 -> 256 at 56x56 runs at 2.7 TB/s and 69 TFLOP/s, the SUM of its MFMA and HBM times - were tried on a 128 x 64 tile
   //  at 4 / 5 workgroups per CU, on a 64 x 256 tile writing whole 1 KB rows and as a persistent kernel that loads its next tile under the epilogue: no change, r03 x3)
-  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : (sp ? cdiv(p.M, 128) : cdiv(p.M, 256)) * cdiv(d->K, 64));
   // 3x3 / stride 1 / padding 1 on the 256 x 64 tile: the halo loader (conv_fwd_k, C4 == 3) when the tile's rows fit its LDS records.  DIAGNOSTIC BUILDS ONLY
   // (-DSSV_EXP_HALO, round 4): three different main loops for this layer - the generic one, one halo stage of 32 channels, two halo stages of 16 - all land on
   // 104-109 TFLOP/s, because the kernel already keeps the matrix pipe 0.80-0.82 busy and the chip clocks it at 2.0-2.1 GHz under that load
@@ -1799,20 +2023,30 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
       return SSV_OK;
     }
 #endif
-#define FWDG(BM_, BN_, WM_, WN_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWDG_TILE(G_) do { if (wide) FWDG(128, 128, 2, 2, G_); else FWDG(256, 64, 4, 1, G_); } while (0)
+#define FWDG_(BM_, BN_, WM_, WN_, G_, SP_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 0, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWDG(BM_, BN_, WM_, WN_, G_) FWDG_(BM_, BN_, WM_, WN_, G_, false)
+#define FWDG_TILE(G_) do { if (sp) { if (wide) FWDG_(128, 128, 2, 2, G_, true); else FWDG_(128, 64, 2, 2, G_, true); } \
+                           else    { if (wide) FWDG(128, 128, 2, 2, G_); else FWDG(256, 64, 4, 1, G_); } } while (0)
     if (add_H2 > 0) {                                          // compact stride-2 addend: wide tile, byte-mask gates (checked by the caller)
-#define FWDGS(G_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 0, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWDGS_(G_, SP_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 0, true, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWDGS(G_) do { if (sp) FWDGS_(G_, true); else FWDGS_(G_, false); } while (0)
       if (gate->x2) FWDGS(3); else FWDGS(2);
 #undef FWDGS
+#undef FWDGS_
     } else if (gate->x2) FWDG_TILE(3); else if (gate->mask) FWDG_TILE(2); else FWDG_TILE(1);
 #undef FWDG_TILE
 #undef FWDG
+#undef FWDG_
     return SSV_OK;
   }
-#define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWD_(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_, SP_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_, 0, 0, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
+#define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) FWD_(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_, false)
+// the float4 path with K-step 32: either arithmetic
+#define FWD_TILE_A(ST_, XF_) do { \
+    if (sp) { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, true); else FWD_(128, 64, 2, 2, 32, ST_, 0, XF_, true); } \
+    else    { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, false); else FWD_(256, 64, 4, 1, 32, ST_, 0, XF_, false); } } while (0)
 #define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
 #ifdef SSV_EXP_HALO
   if (halo) {
@@ -1822,9 +2056,9 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   if (stats && d->C == 4) {                                    // the padded image stem with the statistics epilogue
     FWD_TILE(32, true, true, false);
   } else if (stats || xf) {                                    // C % 32 == 0 checked by the callers
-    if (stats && xf) FWD_TILE(32, true, false, true);
-    else if (stats)  FWD_TILE(32, true, false, false);
-    else             FWD_TILE(32, false, false, true);
+    if (stats && xf) FWD_TILE_A(true, true);
+    else if (stats)  FWD_TILE_A(true, false);
+    else             FWD_TILE_A(false, true);
   } else if (d->C == 4) {                                      // image stems (3 channels padded to 4): tap-vector gather
     FWD_TILE(32, false, true, false);
   } else if (d->C % 32 == 0) {
@@ -1834,7 +2068,7 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
       return SSV_OK;
     }
 #endif
-    FWD_TILE(32, false, false, false);
+    FWD_TILE_A(false, false);
   } else if (d->C % 16 == 0) {
     FWD_TILE(16, false, false, false);
   } else {
@@ -1842,7 +2076,9 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
     hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, GBK, false>), dim3(g2), dim3(256), 0, s, p, x, w, bias, addend, y);
   }
 #undef FWD_TILE
+#undef FWD_TILE_A
 #undef FWD
+#undef FWD_
   return SSV_OK;
 }
 
@@ -1902,7 +2138,7 @@ int check_gate(const ssv_bn_gate* g, const char* who) {
 extern "C" int64_t ssv_conv2d_fwd_gate_groups(const ssv_conv_desc* d) {
   if (!d || d->K <= 0) return 0;
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-  const int bm = d->K >= 128 ? 128 : 256;
+  const int bm = (d->K >= 128 || sp_fwd_ok(d)) ? 128 : 256;           // rows of the launch's tile (the bf16-piece variants: 128 at every width)
   return cdiv64(M, bm) * (bm / 64);
 }
 
@@ -1957,18 +2193,24 @@ int fwd_dyin_impl(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyi
   p.add_H2 = add_H2; p.add_W2 = add_W2;
   if (gate) p.gate = *gate;
   const bool wide = d->K >= 128;
-  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : cdiv(p.M, 256) * cdiv(d->K, 64));
+  const bool sp = sp_fwd_ok(d);
+  const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : (sp ? cdiv(p.M, 128) : cdiv(p.M, 256)) * cdiv(d->K, 64));
   const int gm = gate ? (gate->x2 ? 3 : (gate->mask ? 2 : 1)) : 0;
-#define FWDD(BM_, BN_, WM_, WN_, G_) \
-  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
-#define FWDD_TILE(G_) do { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } while (0)
+#define FWDD_(BM_, BN_, WM_, WN_, G_, SP_) \
+  hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+#define FWDD(BM_, BN_, WM_, WN_, G_) FWDD_(BM_, BN_, WM_, WN_, G_, false)
+#define FWDD_TILE(G_) do { if (sp) { if (wide) FWDD_(128, 128, 2, 2, G_, true); else FWDD_(128, 64, 2, 2, G_, true); } \
+                           else    { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } } while (0)
   if (add_H2 > 0) {                                          // compact stride-2 addend: wide tile and byte-mask gate checked by the caller
-#define FWDDS(G_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 1, true>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+#define FWDDS_(G_, SP_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 1, true, false, SP_>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
+#define FWDDS(G_) do { if (sp) FWDDS_(G_, true); else FWDDS_(G_, false); } while (0)
     if (gm == 3) FWDDS(3); else FWDDS(2);
 #undef FWDDS
+#undef FWDDS_
   } else if (gm == 3) FWDD_TILE(3); else if (gm == 2) FWDD_TILE(2); else if (gm == 1) FWDD_TILE(1); else FWDD_TILE(0);
 #undef FWDD_TILE
 #undef FWDD
+#undef FWDD_
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_dyin");
   return SSV_OK;
 }
@@ -2008,9 +2250,12 @@ extern "C" int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x
   // (a 128 x 64 tile with K-step 64 - 256-byte row pieces - is 6 % faster for the 256 -> 64 conv1 of the 56x56 stage, r03 x1, but its statistics
   // epilogue sums each 64-row group in another order: the forward would no longer be bit-identical to bn_apply + conv2d_fwd_stats.  Not taken.)
   const bool wide = d->K >= 128;
-  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)(cdiv(p.M, 256) * cdiv(d->K, 64));
-  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
-  else      hipLaunchKernelGGL((conv_fwd_k<256, 64, 4, 1, 32, true, false, true, false, false, 0, 2>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y);
+  const bool sp = sp_fwd_ok(d);
+  const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)((sp ? cdiv(p.M, 128) : cdiv(p.M, 256)) * cdiv(d->K, 64));
+#define FWDS(BM_, BN_, WM_, WN_, SP_) hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, true, false, false, 0, 2, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y)
+  if (sp) { if (wide) FWDS(128, 128, 2, 2, true); else FWDS(128, 64, 2, 2, true); }
+  else    { if (wide) FWDS(128, 128, 2, 2, false); else FWDS(256, 64, 4, 1, false); }
+#undef FWDS
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_sumin_stats");
   return SSV_OK;
 }
@@ -2062,8 +2307,10 @@ extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const
     else   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 3, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, act);
   } else
 #endif
-  if (h) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 1>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, h);
-  else   hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 3>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, act);
+#define FWDE(E_, SP_, OUT_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, E_, false, 0, false, 0, 0, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, OUT_)
+  if (sp_fwd_ok(d)) { if (h) FWDE(1, true, h); else FWDE(3, true, act); }
+  else              { if (h) FWDE(1, false, h); else FWDE(3, false, act); }
+#undef FWDE
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
   return SSV_OK;
 }
@@ -2106,7 +2353,8 @@ extern "C" int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, 
     hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   else
 #endif
-  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  if (sp_fwd_ok(d)) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  else hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   SSV_CHECK_LAUNCH("ssv_linear_fwd_gelugrad");
   return SSV_OK;
 }
@@ -2123,7 +2371,8 @@ extern "C" int ssv_linear_gelu_fwd_dact(const ssv_conv_desc* d, const float* x, 
   ConvKP p = make_kp(d);
   p.aux_out = act;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
+  if (sp_fwd_ok(d)) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4, false, 0, false, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
+  else hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd_dact");
   return SSV_OK;
 }
@@ -2140,7 +2389,8 @@ extern "C" int ssv_linear_fwd_mulgrad(const ssv_conv_desc* d, const float* dy, c
   ConvKP p = make_kp(d);
   p.aux_in = dact;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-  hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  if (sp_fwd_ok(d)) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5, false, 0, false, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  else hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   SSV_CHECK_LAUNCH("ssv_linear_fwd_mulgrad");
   return SSV_OK;
 }
@@ -2178,7 +2428,8 @@ int dgrad_impl(const ssv_conv_desc* d, int groups, const float* dy, const float*
   const int64_t Mc = (int64_t)d->N * Hq * Wq;
   if (d->C >= 128 && groups <= 1) {
     const dim3 g((unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128)), st * st);
-    if (bk32) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32>), g, dim3(256), 0, s, p, dy, w, addend, dx);
+    if (bk32 && sp_dgrad_ok(d)) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32, false, 0, true>), g, dim3(256), 0, s, p, dy, w, addend, dx);
+    else if (bk32) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32>), g, dim3(256), 0, s, p, dy, w, addend, dx);
     else      hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 16>), g, dim3(256), 0, s, p, dy, w, addend, dx);
   } else {
     const dim3 g((unsigned)(cdiv64(Mc, 256) * cdiv(d->C, 64)), st * st);
@@ -2213,14 +2464,17 @@ extern "C" int ssv_conv2d_dgrad_gated(const ssv_conv_desc* d, const float* dy, c
   const int st = d->stride;
   const int64_t Mc = (int64_t)d->N * cdiv(d->H, st) * cdiv(d->W, st);
 #define DG(BM_, BN_, WM_, WN_, G_) hipLaunchKernelGGL((conv_dgrad_k<BM_, BN_, WM_, WN_, 32, false, G_>), g, dim3(256), 0, s, p, dy, w, addend, dx)
+#define DGS(G_) hipLaunchKernelGGL((conv_dgrad_k<128, 128, 2, 2, 32, false, G_, true>), g, dim3(256), 0, s, p, dy, w, addend, dx)
   if (d->C >= 128) {
     const dim3 g((unsigned)(cdiv64(Mc, 128) * cdiv(d->C, 128)), st * st);
-    if (gate->mask) DG(128, 128, 2, 2, 2); else DG(128, 128, 2, 2, 1);
+    if (sp_dgrad_ok(d)) { if (gate->mask) DGS(2); else DGS(1); }
+    else if (gate->mask) DG(128, 128, 2, 2, 2); else DG(128, 128, 2, 2, 1);
   } else {
     const dim3 g((unsigned)(cdiv64(Mc, 256) * cdiv(d->C, 64)), st * st);
     if (gate->mask) DG(256, 64, 4, 1, 2); else DG(256, 64, 4, 1, 1);
   }
 #undef DG
+#undef DGS
   SSV_CHECK_LAUNCH("ssv_conv2d_dgrad_gated");
   return SSV_OK;
 }
@@ -2313,15 +2567,20 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   // gather mode of the X operand (see conv_wgrad_k): LIN, S1 (needs one carry per K-step: BK/Wo + 1 <= Ho, Ho == H, Wo == W) or generic
   const bool s1ok = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && 32 / d->Wo + 1 <= d->Ho;
   const int gather = (d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1) ? 1 : (s1ok ? 2 : 0);
-#define WG_LAUNCH(BM_, BN_, WM_, WN_, B_, V_, G_, X_) \
-  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, B_, V_, G_, X_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
-#define WG_DYIN(BM_, BN_, WM_, WN_, X_) \
-  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, X_, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+  const bool sp = sp_wgrad_ok(d, groups);
+#define WG_LAUNCH_(BM_, BN_, WM_, WN_, B_, V_, G_, X_, SP_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, B_, V_, G_, X_, false, false, 0, SP_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define WG_LAUNCH(BM_, BN_, WM_, WN_, B_, V_, G_, X_) WG_LAUNCH_(BM_, BN_, WM_, WN_, B_, V_, G_, X_, false)
+#define WG_LAUNCH_A(BM_, BN_, WM_, WN_, G_, X_) do { if (sp) WG_LAUNCH_(BM_, BN_, WM_, WN_, 32, true, G_, X_, true); else WG_LAUNCH_(BM_, BN_, WM_, WN_, 32, true, G_, X_, false); } while (0)
+#define WG_DYIN_(BM_, BN_, WM_, WN_, X_, SP_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, X_, true, false, 0, SP_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define WG_DYIN(BM_, BN_, WM_, WN_, X_) do { if (sp) WG_DYIN_(BM_, BN_, WM_, WN_, X_, true); else WG_DYIN_(BM_, BN_, WM_, WN_, X_, false); } while (0)
 #define WG_GATHER(BM_, BN_, WM_, WN_, X_) \
-  do { if (gather == 1) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 1, X_); else if (gather == 2) WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 2, X_); \
-       else WG_LAUNCH(BM_, BN_, WM_, WN_, 32, true, 0, X_); } while (0)
-#define WG_BIAS(BM_, BN_, WM_, WN_) \
-  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false, false, true>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+  do { if (gather == 1) WG_LAUNCH_A(BM_, BN_, WM_, WN_, 1, X_); else if (gather == 2) WG_LAUNCH_A(BM_, BN_, WM_, WN_, 2, X_); \
+       else WG_LAUNCH_A(BM_, BN_, WM_, WN_, 0, X_); } while (0)
+#define WG_BIAS_(BM_, BN_, WM_, WN_, SP_) \
+  hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false, false, true, 0, SP_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, tiles)
+#define WG_BIAS(BM_, BN_, WM_, WN_) do { if (sp) WG_BIAS_(BM_, BN_, WM_, WN_, true); else WG_BIAS_(BM_, BN_, WM_, WN_, false); } while (0)
   if (dbias) {                                     // preconditions checked by ssv_conv2d_wgrad_bias: LIN gather, float4 columns
     if (wp.bm == 128) { if (wp.bn == 64) WG_BIAS(128, 64, 2, 2); else WG_BIAS(128, 128, 2, 2); }
     else              { if (wp.bn == 64) WG_BIAS(64, 64, 2, 2);  else WG_BIAS(64, 128, 1, 4); }
@@ -2346,8 +2605,12 @@ int wgrad_impl(const ssv_conv_desc* d, const float* x, const float* in_scale, co
   }
 #undef WG_GATHER
 #undef WG_DYIN
+#undef WG_DYIN_
 #undef WG_BIAS
+#undef WG_BIAS_
 #undef WG_LAUNCH
+#undef WG_LAUNCH_A
+#undef WG_LAUNCH_
   SSV_CHECK_LAUNCH("ssv_conv2d_wgrad(partial)");
   const int64_t n = (int64_t)d->K * p.RSC;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, accumulate);
@@ -2707,6 +2970,32 @@ extern "C" int ssv_gemm_batched(int32_t batch, int64_t rows, int32_t C, int32_t 
   return SSV_OK;
 }
 
+// The same products in SSV_ARITH_BF16X3 (csrc/split_bf16.h): the forward kernel's bf16-piece variant on pre-split weights [batch][3][K][C]; bias / addend as in
+// ssv_conv2d_fwd's epilogue (the plain 1x1 / Linear products of the ViT, the heads and the stage-exit gradients use batch 1 of it).
+extern "C" int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* a, const void* w_planes, float* y,
+                                      const float* bias, const float* addend, void* stream) {
+  SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "ssv_gemm_batched_split: bad shape");
+  SSV_REQUIRE(C % 32 == 0 && K % 4 == 0, "ssv_gemm_batched_split: needs C %% 32 == 0 and K %% 4 == 0 (got C=%d K=%d)", C, K);
+  SSV_REQUIRE(a && w_planes && y && (((uintptr_t)a | (uintptr_t)w_planes | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)addend) & 15) == 0, "ssv_gemm_batched_split: null or unaligned pointer");
+  SSV_REQUIRE(!bias || batch == 1, "ssv_gemm_batched_split: a bias goes with one product (batch 1)");
+  ssv_conv_desc d = {(int32_t)rows, 1, 1, C, K, 1, 1, 1, 0, 1, 1};
+  if (int rc = check_desc(&d, "ssv_gemm_batched_split")) return rc;
+  d.arithmetic = SSV_ARITH_BF16X3; d.w_planes = w_planes;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_CONV_FWD, s);
+  ConvKP p = make_kp(&d);
+  p.bs_a = rows * C; p.bs_b = (long long)K * C; p.bs_o = rows * K;
+  p.wp_stride = (long long)batch * K * C;
+  SSV_REQUIRE(p.wp_stride * 6 < (1ll << 31), "ssv_gemm_batched_split: weight planes of 2 GiB or more");
+  const bool wide = K >= 128;
+  const dim3 grid((unsigned)(cdiv(p.M, 128) * cdiv(K, wide ? 128 : 64)), (unsigned)batch);
+  const float* w = nullptr;
+  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, 0, 0, false, false, true>), grid, dim3(256), 0, s, p, a, w, bias, addend, y);
+  else      hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, 32, true, false, false, false, false, 0, 0, false, false, true>), grid, dim3(256), 0, s, p, a, w, bias, addend, y);
+  SSV_CHECK_LAUNCH("ssv_gemm_batched_split");
+  return SSV_OK;
+}
+
 namespace {
 // the same fixed-order fold with the slabs accumulated in fp64: the cross-chunk half of the BLOCKED weight gradient (ssv_gemm_batched_wgrad_blocked)
 __global__ void __launch_bounds__(256)
@@ -2761,7 +3050,7 @@ extern "C" size_t ssv_gemm_batched_wgrad_blocked_workspace_bytes(int32_t batch, 
 // max_chunk > 0 (ssv_gemm_batched_wgrad_blocked): BLOCKED accumulation - no fp32 accumulator chain runs over more than max_chunk rows, and the slabs are
 // folded in fp64 (still fixed order): the error of a long transformed-domain sum (Winograd F(4x4): 25,088 tiles at 28x28 / batch 512) stops growing with its length.
 static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw, int max_chunk, int flush_rows,
-                              void* ws, size_t ws_bytes, void* stream, const char* who) {
+                              void* ws, size_t ws_bytes, void* stream, const char* who, bool sp = false) {
   SSV_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows < (1ll << 31) && C > 0 && K > 0, "%s: bad shape", who);
   SSV_REQUIRE(C % 4 == 0 && K % 4 == 0, "%s: needs C %% 4 == 0 and K %% 4 == 0 (got C=%d K=%d)", who, C, K);
   SSV_REQUIRE(x && dy && dw && ws && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)ws) & 15) == 0, "%s: null or unaligned pointer", who);
@@ -2777,7 +3066,8 @@ static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K,
   float* part = (float*)ws;
   SSV_REQUIRE((int64_t)wp.tiles * wp.nsplit < (1ll << 31), "%s: too many workgroups", who);
   const dim3 grid((unsigned)(wp.tiles * wp.nsplit), (unsigned)batch);
-#define BWG(BM_, BN_, WM_, WN_, FL_) hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false, false, false, FL_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles)
+#define BWG_(BM_, BN_, WM_, WN_, FL_, SP_) hipLaunchKernelGGL((conv_wgrad_k<BM_, BN_, WM_, WN_, 32, true, 1, false, false, false, FL_, SP_>), grid, dim3(256), 0, s, p, x, dy, part, wp.chunk, wp.tiles)
+#define BWG(BM_, BN_, WM_, WN_, FL_) do { if (sp) BWG_(BM_, BN_, WM_, WN_, FL_, true); else BWG_(BM_, BN_, WM_, WN_, FL_, false); } while (0)
   if (flush_rows > 0) {                       // two-level accumulation: blocks of 4 k-tiles = 128 rows
     if (wp.bm == 128) { if (wp.bn == 64) BWG(128, 64, 2, 2, 4); else BWG(128, 128, 2, 2, 4); }
     else              { if (wp.bn == 64) BWG(64, 64, 2, 2, 4); else BWG(64, 128, 1, 4, 4); }
@@ -2786,6 +3076,7 @@ static int gemm_batched_wgrad(int32_t batch, int64_t rows, int32_t C, int32_t K,
     else              { if (wp.bn == 64) BWG(64, 64, 2, 2, 0); else BWG(64, 128, 1, 4, 0); }
   }
 #undef BWG
+#undef BWG_
   SSV_CHECK_LAUNCH("ssv_gemm_batched_wgrad(partial)");
   const int64_t n = (int64_t)K * C;
   if (max_chunk > 0 || flush_rows > 0) hipLaunchKernelGGL(wgrad_reduce64_k, dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0, s, (const float*)part, wp.nsplit, n, dw, 0);
@@ -2805,6 +3096,22 @@ extern "C" int ssv_gemm_batched_wgrad_blocked(int32_t batch, int64_t rows, int32
   SSV_REQUIRE(flush_rows == 0 || flush_rows == 128, "ssv_gemm_batched_wgrad_blocked: flush_rows must be 0 or 128 (got %d)", flush_rows);
   SSV_REQUIRE(max_chunk_rows > 0 || flush_rows > 0, "ssv_gemm_batched_wgrad_blocked: nothing blocked - use ssv_gemm_batched_wgrad");
   return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, max_chunk_rows, flush_rows, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad_blocked");
+}
+
+extern "C" int ssv_gemm_batched_wgrad_split(int32_t batch, int64_t rows, int32_t C, int32_t K, const float* x, const float* dy, float* dw,
+                                            int32_t max_chunk_rows, int32_t flush_rows, void* ws, size_t ws_bytes, void* stream) {
+  SSV_REQUIRE(max_chunk_rows == 0 || max_chunk_rows >= 32, "ssv_gemm_batched_wgrad_split: max_chunk_rows must be 0 (the plain split) or >= 32 (got %d)", max_chunk_rows);
+  SSV_REQUIRE(flush_rows == 0 || flush_rows == 128, "ssv_gemm_batched_wgrad_split: flush_rows must be 0 or 128 (got %d)", flush_rows);
+  return gemm_batched_wgrad(batch, rows, C, K, x, dy, dw, max_chunk_rows, flush_rows, ws, ws_bytes, stream, "ssv_gemm_batched_wgrad_split", true);
+}
+
+// which arithmetic a launch described by d takes (include/ssv_hip.h)
+extern "C" int ssv_conv_arithmetic(const ssv_conv_desc* d, int32_t product) {
+  SSV_REQUIRE(d != nullptr && product >= 0 && product <= 2, "ssv_conv_arithmetic: bad arguments");
+  if (int rc = check_desc(d, "ssv_conv_arithmetic")) return rc;
+  if (product == 0) return sp_fwd_ok(d) ? SSV_ARITH_BF16X3 : SSV_ARITH_F32_MFMA;
+  if (product == 2) return (sp_wgrad_ok(d) && !(d->C == 3)) ? SSV_ARITH_BF16X3 : SSV_ARITH_F32_MFMA;
+  return sp_dgrad_ok(d) ? SSV_ARITH_BF16X3 : SSV_ARITH_F32_MFMA;      // the strided data-gradient kernel (stride-1 data gradients are forward-kernel launches on the transposed filter)
 }
 
 #ifdef SSV_STAMP

@@ -137,6 +137,7 @@ __global__ void adamw_k(int64_t n, float* __restrict__ p, const float* __restric
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (bc_dev) { bc1 = bc_dev[0]; rsqrt_bc2 = bc_dev[1]; }      // ssv_adamw_counted: the bias corrections of a step count that lives in device memory
+  if (lr < 0.f) { lr = bc_dev[2]; wd = bc_dev[3]; }            // ssv_adamw_counted_dev: learning rate and weight decay live there too
   float gi = g[i];
   if (g2) gi += g2[i];
   if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
@@ -238,5 +239,19 @@ extern "C" int ssv_adamw_counted(int64_t n, float* p, const float* g, const floa
   hipLaunchKernelGGL(adamw_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, n, p, g, g2, m, v, lr, beta1, beta2, eps, weight_decay,
                      1.f, 1.f, (const float*)bc_dev, clip);
   SSV_CHECK_LAUNCH("adamw_k(counted)");
+  return SSV_OK;
+}
+
+// ... and with the learning rate and the weight decay in device memory as well (bc_dev[2], bc_dev[3], written by the host when a schedule moves them): one captured
+// graph of the step then serves every epoch.
+extern "C" int ssv_adamw_counted_dev(int64_t n, float* p, const float* g, const float* g2, float* m, float* v, float beta1, float beta2,
+                                     float eps, int64_t* step_dev, float* bc_dev, float clip, void* stream) {
+  SSV_REQUIRE(n > 0 && p && g && m && v && step_dev && bc_dev, "ssv_adamw_counted_dev: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_OPTIM, s);
+  hipLaunchKernelGGL(adamw_tick_k, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev);
+  hipLaunchKernelGGL(adamw_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, n, p, g, g2, m, v, -1.f, beta1, beta2, eps, 0.f,
+                     1.f, 1.f, (const float*)bc_dev, clip);
+  SSV_CHECK_LAUNCH("adamw_k(counted, device hyper-parameters)");
   return SSV_OK;
 }

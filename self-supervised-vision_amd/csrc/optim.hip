@@ -5,10 +5,13 @@ namespace {
 
 // optim.SGD(momentum, nesterov=True, weight_decay): g' = g + wd*p; buf = g' (first step) or
 // momentum*buf + g'; p -= lr*(g' + momentum*buf).
+// hyper != NULL (ssv_sgd_nesterov_dev): lr, weight decay, momentum and the first-step flag are read from DEVICE memory - nothing in the launch changes when a
+// schedule moves them, so one captured HIP graph of the step serves the whole run (ssv_amd/graph.py); the arithmetic is the same expression on the same floats.
 template <bool TWO>
 __global__ void __launch_bounds__(256)
 sgd_nesterov_k(int64_t n, float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g2, float* __restrict__ buf,
-               float lr, float wd, float mom, int first) {
+               float lr, float wd, float mom, int first, const float* __restrict__ hyper) {
+  if (hyper) { lr = hyper[0]; wd = hyper[1]; mom = hyper[2]; first = hyper[3] != 0.f; }
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -76,9 +79,20 @@ extern "C" int ssv_sgd_nesterov(int64_t n, float* p, const float* g, const float
   SSV_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)buf) & 15) == 0, "ssv_sgd_nesterov: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SSV_PROF_OPTIM, s);
-  if (g2) hipLaunchKernelGGL((sgd_nesterov_k<true>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, lr, weight_decay, momentum, first_step);
-  else    hipLaunchKernelGGL((sgd_nesterov_k<false>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, lr, weight_decay, momentum, first_step);
+  if (g2) hipLaunchKernelGGL((sgd_nesterov_k<true>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, lr, weight_decay, momentum, first_step, (const float*)nullptr);
+  else    hipLaunchKernelGGL((sgd_nesterov_k<false>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, lr, weight_decay, momentum, first_step, (const float*)nullptr);
   SSV_CHECK_LAUNCH("ssv_sgd_nesterov");
+  return SSV_OK;
+}
+
+extern "C" int ssv_sgd_nesterov_dev(int64_t n, float* p, const float* g, const float* g2, float* buf, const float* hyper, void* stream) {
+  SSV_REQUIRE(n > 0 && p && g && buf && hyper, "ssv_sgd_nesterov_dev: bad arguments");
+  SSV_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)buf | (uintptr_t)hyper) & 15) == 0, "ssv_sgd_nesterov_dev: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SSV_PROF_OPTIM, s);
+  if (g2) hipLaunchKernelGGL((sgd_nesterov_k<true>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, 0.f, 0.f, 0.f, 0, hyper);
+  else    hipLaunchKernelGGL((sgd_nesterov_k<false>), dim3(grid_for(n)), dim3(256), 0, s, n, p, g, g2, buf, 0.f, 0.f, 0.f, 0, hyper);
+  SSV_CHECK_LAUNCH("ssv_sgd_nesterov_dev");
   return SSV_OK;
 }
 

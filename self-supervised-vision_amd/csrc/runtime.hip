@@ -13,7 +13,7 @@ void ssv_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ssv_version(void) { return 111; }   // 1.1x: round 5 added entry points (ntxent column splits, F(4x4) weight gradient, blocked batched wgrad; 111: ssv_gemm_batched_split)
+extern "C" int ssv_version(void) { return 120; }   // 1.2x: round 6, ssv_conv_desc carries the arithmetic (SSV_ARITH_BF16X3) and the pre-split weight planes; earlier: 1.1x round 5 entry points
 extern "C" const char* ssv_last_error(void) { return g_err; }
 #ifndef SSV_SRC_SHA16
 #define SSV_SRC_SHA16 "unknown"

@@ -8,9 +8,11 @@ batch into those buffers and replays.  Nothing of the step lives on the host:
 
   * the loss leaves through a device-to-host copy node into a pinned buffer (``nn.early_item`` under capture), read after the replay has finished;
   * BatchNorm running statistics / num_batches_tracked, the optimizer state and the gradient slabs are device memory that the kernels update in place;
-  * the learning rate and weight decay are kernel ARGUMENTS, baked into the graph: a graph is keyed by (input shapes, lr, weight decay, momentum) and a new one
-    is captured when the schedule moves them (once per epoch with the reference's schedulers); the optimizer's first-step flag is why capture waits for the
-    optimizer's first update;
+  * the learning rate, weight decay and momentum are DEVICE memory too (round 6: ssv_sgd_nesterov_dev / ssv_adamw_counted_dev read them from four floats the
+    optimizer owns; ``optim.push_hyper()`` rewrites those when a schedule has moved them, models/simclr.py:77-84), so ONE graph per input shape serves the whole run -
+    rounds 4-5 baked them in as kernel arguments and re-captured (and destroyed) a graph every epoch;
+  * scalars that still reach kernels as arguments (DINO's temperatures, MoCo's momentum: ``trainer.graph_key()``) key the graph: a bounded LRU of live graphs
+    (MAX_LIVE per StepGraph) covers their schedules;
   * scratch (ops.workspace) used by captured kernels is allocated inside the capture, in the graph's private pool, so no later eager allocation can move it.
 
 On small images the captured step also takes another kernel SELECTION than the eager one (ops.graph_dispatch): with no host cost per launch the Winograd forms pay
@@ -24,8 +26,8 @@ AdamW is graphable because its step count lives in device memory (``ssv_adamw_co
 import atexit
 import gc
 import os
-import time
 import weakref
+from collections import OrderedDict
 
 import torch
 
@@ -36,11 +38,43 @@ from . import ops
 # SSV_STEP_GRAPH: "1" always (where possible), "0" never, "auto" (default) for small images only - where the step is launch-bound
 MODE = os.environ.get("SSV_STEP_GRAPH", "auto")
 AUTO_MAX_PIXELS = 64 * 64            # per image: CIFAR (32 x 32) and the like; at 224 x 224 the step is GPU-bound and the static input copies cost more than the launches
-DESTROY_GRACE_S = float(os.environ.get("SSV_GRAPH_DESTROY_GRACE", "0.1"))   # between the device going idle and a graph's destruction (see StepGraph._drop)
-WARMUP_STEPS = 2                     # eager steps before a capture: the optimizer's first update (its first-step flag is a kernel argument), allocator warm-up
+WARMUP_STEPS = 2                     # eager steps before a capture: the optimizer's first update (its first-step flag), allocator warm-up
+MAX_LIVE = 4                         # captured graphs a StepGraph keeps (least recently replayed one retired first).  Each holds its private pool: the step's activations
+                                     # and workspace - resnet18 at 32 x 32: 0.35 GB at batch 64, 2.6 GB at batch 512 (tools/exp/r06_graph_lru_stress.py prints it)
+MAX_RETIRED = 16                     # retired graphs waiting for destruction, process-wide, before the oldest generation is destroyed
+
+# ---- when a graph is DESTROYED -----------------------------------------------------------------------------------------------------------------------------------
+# hipGraphExecDestroy racing the runtime's completion-handler thread for the graph's LAST launch corrupts the host heap (round 5: native backtrace in libhsa-runtime64's
+# handler thread; never with the graphs kept alive).  Rounds 4-5 destroyed a graph right after its last replay - every epoch - behind a sleep.  Now nothing destroys a
+# graph near its last launch: a graph that leaves service (LRU eviction, close(), its trainer's end) is RETIRED into a two-generation graveyard, and a generation is
+# destroyed only after the device has gone idle TWICE with other work in between (_reap: at a later capture, or at interpreter exit while the HIP runtime is still
+# up) - its last launch is then at least one whole capture older than the destruction.  No timing heuristic anywhere.
+_LIVE = weakref.WeakSet()          # every StepGraph that may hold graphs
+_RETIRED = [[], []]                # generation 0: retired since the last reap; generation 1: one reap old - the next reap destroys it
 
 
-_LIVE = weakref.WeakSet()          # every StepGraph that may hold graphs: closed at interpreter exit, while the HIP runtime is still up
+def _retire(recs):
+    _RETIRED[0].extend(recs)
+
+
+def _reap(final=False):
+    """Device idle, no capture in progress: destroy the generation that has already survived one reap, age the other.  ``final`` (interpreter exit): both."""
+    if not (_RETIRED[0] or _RETIRED[1]):
+        return
+    import torch as _t
+    if _t.cuda.is_available():
+        _t.cuda.synchronize()
+    for _ in range(2 if final else 1):
+        old, _RETIRED[1] = _RETIRED[1], _RETIRED[0]
+        _RETIRED[0] = []
+        for rec in old:
+            try:
+                rec[0].reset()             # CUDAGraph.reset = hipGraphExecDestroy + hipGraphDestroy; then the record's events, static inputs and workspace go
+            except Exception:
+                pass
+        del old
+        if final and _t.cuda.is_available():
+            _t.cuda.synchronize()
 
 
 def _close_all():
@@ -48,6 +82,7 @@ def _close_all():
     'Aborted (core dumped)' AFTER a green pytest run - the exit code of the whole session was lost)."""
     for sg in list(_LIVE):
         sg.close()
+    _reap(final=True)
 
 
 atexit.register(_close_all)
@@ -63,7 +98,7 @@ class StepGraph:
         self.keys = keys
         self.graph_floors = graph_floors   # small images: the captured step takes the Winograd forms from fewer tiles / channels (ops.graph_dispatch); False = the eager selection, bit for bit
         self.mode = MODE if mode is None else mode
-        self.graphs = {}             # key -> (graph, static inputs, pinned loss, (workspace buffers, event objects of the capture) kept alive)
+        self.graphs = OrderedDict()  # key -> (graph, static inputs, pinned loss, (workspace buffers, event objects of the capture) kept alive); least recently replayed first
         self.eager_steps = 0
         self.seen = {}               # input-shape signature -> times met without a graph
         self.disabled = None         # reason, once capture has failed or the trainer is not graphable
@@ -78,26 +113,14 @@ class StepGraph:
         return t
 
     def _drop(self, keys):
-        """Destroy the graphs under `keys` in a DEFINED order: device idle, then the graph itself (CUDAGraph.reset = hipGraphExecDestroy + hipGraphDestroy), and only then
-        the event objects that were recorded inside its capture, its static inputs and its workspace (a record's tuple would otherwise release its LAST item first)."""
+        """Take the graphs under `keys` out of service.  They are not destroyed here (see the note on destruction above): they retire, with everything recorded inside their
+        capture, and a later reap destroys them."""
         recs = [self.graphs.pop(k) for k in keys if k in self.graphs]
-        if recs and torch.cuda.is_available():
-            torch.cuda.synchronize()
-            # hipDeviceSynchronize returns when the last command's signal is set; the runtime's completion callbacks (its asynchronous handler thread) may still be
-            # walking the launch's command objects.  Destroying the graph under them corrupted the host heap (native backtrace of the fault: libhsa-runtime64's handler
-            # thread -> libamdhip64 callbacks; tools/exp/r05_graph_event_stress.py reproduces it within ~50 capture / destroy cycles of a two-stream step, never with
-            # the graphs kept alive).  Give the handler time to finish before the graph goes - a re-capture happens once per epoch, the wait is noise.
-            time.sleep(DESTROY_GRACE_S)
-            torch.cuda.synchronize()
-        for rec in recs:
-            try:
-                rec[0].reset()
-            except Exception:
-                pass
-        del recs
+        if recs:
+            _retire(recs)
 
     def close(self):
-        """Destroy every captured graph now (idle device, no capture in progress)."""
+        """Retire every captured graph (the StepGraph can capture again afterwards)."""
         self._drop(list(self.graphs))
 
     def __del__(self):
@@ -128,11 +151,11 @@ class StepGraph:
         return None
 
     def _key(self, ins):
-        """Everything a captured step bakes in: the input shapes and every scalar that reaches a kernel as an ARGUMENT - the optimizer's learning rate / weight
-        decay / momentum (or betas, epsilon, clamp), plus whatever the trainer names in ``graph_key()`` (DINO: temperatures, centre momentum)."""
+        """Everything a captured step bakes in: the input shapes and every scalar that reaches a kernel as an ARGUMENT - AdamW's betas / epsilon / clamp, plus whatever
+        the trainer names in ``graph_key()`` (DINO: temperatures, centre momentum)."""
         g = self.trainer.optim.param_groups[0]
         opt = tuple(sorted((k, float(v) if isinstance(v, (int, float)) else tuple(float(x) for x in v)) for k, v in g.items()
-                           if k in ("lr", "weight_decay", "momentum", "betas", "eps")))
+                           if k in ("betas", "eps")))            # lr / weight decay / momentum are device memory (optim.push_hyper): not part of the key
         extra = tuple(self.trainer.graph_key()) if hasattr(self.trainer, "graph_key") else ()
         return (tuple((k, tuple(t.shape), t.stride()) for k, t in sorted(ins.items())), opt, float(getattr(self.trainer.optim, "clip", 0.0)), extra)
 
@@ -160,19 +183,30 @@ class StepGraph:
                 self.disabled = f"{self.captures} captures for {self.replays} replays: a scalar baked into the graph changes too often"
                 self.close()
                 return self.trainer.train_step(batch)
+            if len(_RETIRED[0]) + len(_RETIRED[1]) >= MAX_RETIRED:
+                _reap()                      # idle device, no capture in progress: the generation retired before the previous reap goes
+            steps_before = self.trainer.optim._steps
             try:
                 self.captures += 1
                 rec = self._capture(batch, ins, key)
             except Exception as exc:         # never take the training run down: the eager step is always there
                 self.disabled = f"capture failed: {type(exc).__name__}: {exc}"
                 torch.cuda.synchronize()
+                # the recorded (never executed) step filled the weight caches with filters that live in the discarded graph's pool, and counted an optimizer step
+                ops.invalidate_weight_caches()
+                self.trainer.optim._steps = steps_before
                 return self.trainer.train_step(batch)
-            self._drop([k for k in self.graphs if k[0] == key[0] and k != key])         # the schedule moved on: one graph per input shape
+            self.trainer.optim._steps = steps_before          # recording a step executes nothing: the replays count
+            while len(self.graphs) >= MAX_LIVE:
+                self._drop([next(iter(self.graphs))])         # least recently replayed
             self.graphs[key] = rec
+        self.graphs.move_to_end(key)
         graph, static, host, _ = rec
         for k, t in ins.items():
             static[k].copy_(t, non_blocking=True)
+        self.trainer.optim.push_hyper()      # lr / weight decay / momentum as the schedules left them (a 16-byte copy when they moved)
         graph.replay()
+        self.trainer.optim._steps += 1
         # the replay changed the weights without running a line of Python: whatever an EAGER forward between replays (feature extraction, a ragged batch) cached of
         # them - transposed filters, Winograd-transformed filters - is stale now (found by test_graph_survives_eager_work_between_replays: the second extraction used
         # the first one's transformed filters)
@@ -209,8 +243,10 @@ class StepGraph:
                 floors.__exit__(None, None, None)
             events = hnn.end_capture(prev)
             graph_ws, ops.workspace.buf = ops.workspace.buf, eager_ws
+            ops.invalidate_weight_caches()     # whatever the recorded step cached of the weights (transposed / transformed / split filters) was never computed
         _LIVE.add(self)
         return graph, static, host, (graph_ws, events)
 
     def describe(self):
-        return {"mode": self.mode, "graphs": len(self.graphs), "captures": self.captures, "replays": self.replays, "eager_steps": self.eager_steps, "disabled": self.disabled}
+        return {"mode": self.mode, "graphs": len(self.graphs), "retired": len(_RETIRED[0]) + len(_RETIRED[1]), "captures": self.captures, "replays": self.replays,
+                "eager_steps": self.eager_steps, "disabled": self.disabled}

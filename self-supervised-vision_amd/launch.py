@@ -53,10 +53,12 @@ def run_and_forward_signals(cmd, env=None, grace=10.0):
     child - torch.distributed.run and, below it, the N ranks holding the GPUs and the rendezvous port - runs in its OWN session, and SIGTERM / SIGINT /
     SIGHUP to the parent are passed on to that whole process group (TERM, then KILL after ``grace`` seconds), so no rank outlives the command that
     started it.  Returns the child's exit code (128 + signal when it was stopped this way).  Still no exec, no HIP in this process."""
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    child = None
     got = []                                                     # [(signal number, time it arrived)]
 
     def signal_group(sig):
+        if child is None:                                        # a signal between installing the handlers and Popen's return: recorded, passed on below
+            return
         try:
             os.killpg(child.pid, sig)                            # the session leader's pid is the group id
         except ProcessLookupError:
@@ -66,8 +68,13 @@ def run_and_forward_signals(cmd, env=None, grace=10.0):
         got.append((signum, time.monotonic()))
         signal_group(signal.SIGTERM)
 
+    # handlers BEFORE the child exists: a signal in the window between Popen and signal.signal() would otherwise kill this parent by default action and orphan
+    # the child's session (the ranks holding the GPUs and the rendezvous port) - the very case this function exists to prevent
     previous = {s: signal.signal(s, forward) for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
     try:
+        child = subprocess.Popen(cmd, env=env, start_new_session=True)
+        if got:
+            signal_group(signal.SIGTERM)
         while True:
             try:
                 rc = child.wait(timeout=0.25)

@@ -222,6 +222,11 @@ def begin_capture(host):
     return prev
 
 
+def capturing():
+    """Is a training step being recorded into a HIP graph right now (graph.StepGraph._capture)?"""
+    return _CAPTURE_HOST is not None
+
+
 def end_capture(prev):
     global _CAPTURE_HOST, _CAPTURE_ORDER, _CAPTURE_KEEP
     kept = _CAPTURE_KEEP

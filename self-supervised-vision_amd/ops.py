@@ -18,13 +18,51 @@ def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
-def conv_desc(x_shape, w_shape, stride, pad):
-    n, h, w, c = x_shape
+# HOW the GEMM-shaped launches multiply (include/ssv_hip.h: ssv_conv_desc.arithmetic; csrc/split_bf16.h).  "bf16x3" (default since round 6): every fp32 operand as three
+# bf16 pieces, six exact piece products per fp32 product, fp32 accumulation on the bf16 matrix pipe - fp32 in, fp32 out, error against fp64 at or below the fp32-MFMA
+# kernels' on every layer shape (tests/test_gpu_split.py).  "f32": v_mfma_f32_32x32x2_f32 on the fp32 operands, the arithmetic of rounds 1-5.
+# SSV_ARITHMETIC=f32|bf16x3; bench.py reports both in one line.  Launches without a bf16-piece kernel (image stem, strided data gradient, grouped banks) run on
+# fp32 MFMA either way.
+ARITHMETIC = os.environ.get("SSV_ARITHMETIC", "bf16x3")
+if ARITHMETIC not in ("bf16x3", "f32"):
+    raise _lib.SsvError(f"SSV_ARITHMETIC must be bf16x3 or f32 (got {ARITHMETIC!r})")
+
+
+class arithmetic:
+    """``with ops.arithmetic("f32"): ...`` - the launches inside run on the named arithmetic (tests, bench.py's fp32-instruction leg)."""
+
+    def __init__(self, name):
+        if name not in ("bf16x3", "f32"):
+            raise _lib.SsvError(f"arithmetic must be bf16x3 or f32 (got {name!r})")
+        self.name = name
+
+    def __enter__(self):
+        global ARITHMETIC
+        self.prev, ARITHMETIC = ARITHMETIC, self.name
+        invalidate_weight_caches()
+        return self
+
+    def __exit__(self, *exc):
+        global ARITHMETIC
+        ARITHMETIC = self.prev
+        invalidate_weight_caches()
+        return False
+
+
+def conv_desc(x_shape, w_shape, stride, pad, w=None):
+    """``w``: the tensor the launch will be given as its weight operand (the filter, its transpose, a transformed filter) - in the bf16x3 arithmetic its pre-split
+    planes ride in the descriptor (made once per weight, stream and step: `_planes`).  Launches whose operands are both activations (weight gradients) pass none."""
+    n, h, w_, c = x_shape
     k, ci, r, s = w_shape
     if ci != c:
         raise _lib.SsvError(f"conv: input has {c} channels, filter expects {ci}")
-    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
-    return ConvDesc(n, h, w, c, k, r, s, stride, pad, ho, wo)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w_ + 2 * pad - s) // stride + 1
+    d = ConvDesc(n, h, w_, c, k, r, s, stride, pad, ho, wo)
+    if ARITHMETIC == "bf16x3":
+        d.arithmetic = _lib.ARITH_BF16X3
+        if w is not None and w.numel() % 8 == 0 and (c % 32 == 0 or k % 32 == 0):      # forward products contract over C, the strided data gradient over K
+            d.w_planes = ptr(_planes(w))
+    return d
 
 
 def _ohwi(w):
@@ -68,19 +106,6 @@ def _sub(t, n0, n1):
     return None if t is None else t[n0:n1]
 
 
-def _split_plain(rows, c, k, a, w2d, y, bias, addend):
-    """The plain 1x1 / Linear product y = a . w^T (+ bias + addend) on the bf16 pipe by operand splitting, when the opt-in switch is on and the shape fits
-    (SPLIT_BF16_TERMS, defined with the Winograd products below).  Returns False when the caller must run the fp32-MFMA kernel."""
-    if SPLIT_BF16_TERMS not in (6, 9) or k < SPLIT_BF16_MIN_CHANNELS or c % 32 or k % 4 or rows >= (1 << 31):
-        return False
-    for t in (bias, addend):
-        if t is not None and t.data_ptr() % 16:
-            return False
-    _note("gemm_split_bf16")
-    call("ssv_gemm_batched_split", 1, rows, c, k, ptr(a), ptr(w2d), ptr(y), ptr(bias), ptr(addend), SPLIT_BF16_TERMS, stream())
-    return True
-
-
 def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None, groups=1):
     """``groups`` > 1: w is the DENSE block-diagonal bank of a grouped convolution (group_expand); every column tile then contracts over the
     channels of its own groups only."""
@@ -88,11 +113,8 @@ def conv2d_fwd(x, w, stride=1, pad=0, bias=None, addend=None, groups=1):
     w, wshape = _ohwi(w)
     d = conv_desc(x.shape, wshape, stride, pad)
     y = _empty((d.N, d.Ho, d.Wo, d.K), x)
-    if (groups == 1 and wshape[2] == 1 and wshape[3] == 1 and stride == 1 and pad == 0 and x.is_contiguous() and (addend is None or addend.is_contiguous())
-            and _split_plain(d.N * d.H * d.W, d.C, d.K, x, w, y, bias, addend)):
-        return y
     for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K)):
-        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad)
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad, w=w)
         if groups > 1:
             call("ssv_conv2d_fwd_grouped", C.byref(dc), int(groups), ptr(x[n0:n1]), ptr(w), ptr(bias), ptr(_sub(addend, n0, n1)), ptr(y[n0:n1]), stream())
         else:
@@ -140,7 +162,7 @@ def conv2d_fwd_fused(x, w, stride=1, pad=0, in_affine=None, want_stats=True, kee
     sc, sh = in_affine if in_affine is not None else (None, None)
     g0 = 0
     for n0, n1 in _batch_chunks(d.N, (d.H * d.W * d.C, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo if want_stats else None):
-        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad)
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, stride, pad, w=w)
         gc = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(dc)))
         call("ssv_conv2d_fwd_bnrelu_in_stats", C.byref(dc), ptr(x[n0:n1]), ptr(sc), ptr(sh), ptr(w), ptr(y[n0:n1]),
              ptr(part[0][g0:g0 + gc]) if want_stats else None, ptr(part[1][g0:g0 + gc]) if want_stats else None, stream())
@@ -172,7 +194,7 @@ def conv2d_fwd_sumin(x, res, scale, shift, res_affine, w, want_mask=True):
     per = d.H * d.W * d.C
     g0 = 0
     for n0, n1 in _batch_chunks(d.N, (per, d.Ho * d.Wo * d.K), rows_per_sample=d.Ho * d.Wo):
-        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, 1, 0)
+        dc = conv_desc((n1 - n0,) + tuple(x.shape[1:]), wshape, 1, 0, w=w)
         gc = int(lib.ssv_conv2d_fwd_stats_groups(C.byref(dc)))
         call("ssv_conv2d_fwd_sumin_stats", C.byref(dc), ptr(x[n0:n1]), ptr(res[n0:n1]), ptr(scale), ptr(shift), ptr(rs), ptr(rh), ptr(w), ptr(y[n0:n1]),
              ptr(part[0][g0:g0 + gc]), ptr(part[1][g0:g0 + gc]), ptr(a[n0:n1]), None if mask is None else ptr(mask[n0 * per // 4:n1 * per // 4]), stream())
@@ -187,6 +209,7 @@ def can_fuse_conv_input(cin, cout, groups=1):
 
 _WT_CACHE = {}          # (weight address, stream) -> (storage kept alive, transposed filter): one transpose per weight, stream and step
 _WINO_U = {}            # (weight address, stream, shape, transposed?) -> (storage kept alive, Winograd-transformed filter), same lifetime
+_PLANES = {}            # (operand address, stream, elements) -> (storage kept alive, its three bf16 planes), same lifetime
 
 
 def invalidate_weight_caches():
@@ -194,6 +217,22 @@ def invalidate_weight_caches():
     networks, MemoryBank pushes, checkpoint loads): a cached transposed filter must never outlive the weights it was made from."""
     _WT_CACHE.clear()
     _WINO_U.clear()
+    _PLANES.clear()
+
+
+def _planes(w):
+    """The three bf16 planes of a weight operand (ssv_split_planes): [3][numel] bf16 as an int16 tensor, cached per HIP stream like the transposed filters."""
+    n = w.numel()
+    key = (w.data_ptr(), stream(), n, w._version)       # torch-level in-place edits of the operand move its version; the library's own updates call invalidate_weight_caches()
+    hit = _PLANES.get(key)
+    if hit is not None:
+        return hit[1]
+    if n % 8:
+        raise _lib.SsvError(f"_planes: operand of {n} elements (needs a multiple of 8)")
+    pl = torch.empty((3, n), dtype=torch.int16, device=w.device)
+    call("ssv_split_planes", n, ptr(w), ptr(pl), stream())
+    _PLANES[key] = (w.untyped_storage(), pl)
+    return pl
 
 
 def _transposed_filter(w, wshape):
@@ -343,7 +382,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
     for n0, n1 in chunks:
         dyc, dxc, adc = dy[n0:n1], dx[n0:n1], _sub(addend, n0, n1)
         if as_fwd:
-            d = conv_desc(dyc.shape, (c, k, r, s_), 1, r - 1 - pad)
+            d = conv_desc(dyc.shape, (c, k, r, s_), 1, r - 1 - pad, w=wt)
             if (d.Ho, d.Wo) != (x_shape[1], x_shape[2]):
                 raise _lib.SsvError("conv2d_dgrad: input shape does not match the stride-1 geometry")
             if compact is not None:         # one chunk (checked above); the compact stride-2 addend rides on the byte-mask gate epilogues
@@ -371,13 +410,10 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, gate=No
                 parts.append(part)
             elif groups > 1:          # the transposed bank is block-diagonal too (input and output channels of a group change places)
                 call("ssv_conv2d_fwd_grouped", C.byref(d), int(groups), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
-            elif (r == 1 and dyc.is_contiguous() and dxc.is_contiguous() and (adc is None or adc.is_contiguous())
-                  and _split_plain(d.N * d.H * d.W, k, c, dyc, wt, dxc, None, adc)):
-                pass                  # dx = dy . W (the transposed filter [C][K] as the k-contiguous operand) on the bf16 pipe (opt-in)
             else:
                 call("ssv_conv2d_fwd", C.byref(d), ptr(dyc), ptr(wt), None, ptr(adc), ptr(dxc), stream())
         else:
-            d = conv_desc(dxc.shape, wshape, stride, pad)
+            d = conv_desc(dxc.shape, wshape, stride, pad, w=w if groups == 1 else None)
             if gate is not None:
                 groups = int(lib.ssv_conv2d_dgrad_gate_groups(C.byref(d)))
                 st, part = _gate_struct(_gate_sub(gate, n0, n1), groups, c, dy)
@@ -965,7 +1001,7 @@ def linear_gelu_fwd(x, w, bias, keep_h=True):
     _lib._dev(x, w, bias)
     m, c = x.shape
     w, wshape = _ohwi(w)
-    d = conv_desc((m, 1, 1, c), wshape, 1, 0)
+    d = conv_desc((m, 1, 1, c), wshape, 1, 0, w=w)
     act = _empty((m, wshape[0]), x)
     h = torch.empty_like(act) if keep_h else None
     call("ssv_linear_gelu_fwd", C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(h), ptr(act), stream())
@@ -987,7 +1023,7 @@ def linear_gelu_fwd_dact(x, w, bias):
     _lib._dev(x, w, bias)
     m, c = x.shape
     w, wshape = _ohwi(w)
-    d = conv_desc((m, 1, 1, c), wshape, 1, 0)
+    d = conv_desc((m, 1, 1, c), wshape, 1, 0, w=w)
     act = _empty((m, wshape[0]), x)
     dact = torch.empty_like(act)
     call("ssv_linear_gelu_fwd_dact", C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(dact), ptr(act), stream())
@@ -1001,8 +1037,9 @@ def linear_dgrad_mul(dy, w, dact, addend=None, out=None):
     w, wshape = _ohwi(w)
     k, c = wshape[0], wshape[1]
     dh = out if out is not None else torch.empty_like(dact)
-    dt = conv_desc((m, 1, 1, k), (c, k, 1, 1), 1, 0)
-    call("ssv_linear_fwd_mulgrad", C.byref(dt), ptr(dy), ptr(_transposed_filter(w, wshape)), ptr(dact), ptr(addend), ptr(dh), stream())
+    wt = _transposed_filter(w, wshape)
+    dt = conv_desc((m, 1, 1, k), (c, k, 1, 1), 1, 0, w=wt)
+    call("ssv_linear_fwd_mulgrad", C.byref(dt), ptr(dy), ptr(wt), ptr(dact), ptr(addend), ptr(dh), stream())
     return dh
 
 
@@ -1016,8 +1053,9 @@ def linear_dgrad_gelu(dy, w, h, addend=None, out=None):
     k, c = wshape[0], wshape[1]
     if LINEAR_GELUGRAD_ON_FWD and k % 32 == 0 and c % 4 == 0 and c >= 128:
         # forward kernel on the transposed weights (cached per step like every stride-1 data gradient's): both operands k-contiguous rows
-        dt = conv_desc((m, 1, 1, k), (c, k, 1, 1), 1, 0)
-        call("ssv_linear_fwd_gelugrad", C.byref(dt), ptr(dy), ptr(_transposed_filter(w, wshape)), ptr(h), ptr(addend), ptr(dh), stream())
+        wt = _transposed_filter(w, wshape)
+        dt = conv_desc((m, 1, 1, k), (c, k, 1, 1), 1, 0, w=wt)
+        call("ssv_linear_fwd_gelugrad", C.byref(dt), ptr(dy), ptr(wt), ptr(h), ptr(addend), ptr(dh), stream())
         return dh
     call("ssv_conv2d_dgrad_gelu", C.byref(d), ptr(dy), ptr(w), ptr(h), ptr(addend), ptr(dh), stream())
     return dh
@@ -1131,6 +1169,7 @@ WINOGRAD44_WGRAD = os.environ.get("SSV_WINOGRAD44_WGRAD", "1") == "1"
 WINOGRAD44_WGRAD_CHUNK = int(os.environ.get("SSV_WINOGRAD44_WGRAD_CHUNK", "512"))
 # ... or / and inside the kernel: the MFMA accumulators flushed into a second register set every 128 tiles (0 = off)
 WINOGRAD44_WGRAD_FLUSH = int(os.environ.get("SSV_WINOGRAD44_WGRAD_FLUSH", "128"))
+WINOGRAD44_WGRAD_FLUSH_BF16X3 = 0
 # The backward of such a layer reads its output gradient ONCE: the weight gradient's dY transform also writes the data gradient's transformed input
 # (ssv_wino44_dy_transform_both; the data gradient that follows picks it up), and behind a fused input chain the output gradient is never written at all - the
 # BatchNorm backward hands over (g, x, coefficients) as a LazyGrad and the transform forms it on load (`wino44_lazy_dy_ok`).  SSV_WINOGRAD44_DY_BOTH=0: separate passes.
@@ -1217,20 +1256,28 @@ def _wino44_filter(w, wshape, transposed=False):
     return u
 
 
-# OPT-IN (default 0 = off: every product of the shipped step runs on v_mfma_f32_32x32x2_f32): the transformed-domain products of the Winograd forward and data
-# gradient on the BF16 matrix pipe by operand splitting - each fp32 operand as three bf16 pieces, 6 (or 9) of the nine piece products accumulated in fp32
-# (csrc/gemm_split.hip: error against fp64 at or below the fp32 kernel's; DESIGN 9 "what comes next").  SSV_SPLIT_BF16=6|9.
-SPLIT_BF16_TERMS = int(os.environ.get("SSV_SPLIT_BF16", "0"))
-SPLIT_BF16_MIN_CHANNELS = 128      # output channels: the split kernel's tile is 128 wide
-
-
 def _gemm_batched(nb, t, c, k, a, u, m):
-    """m[b] = a[b] . u[b]^T for the nb transformed-domain positions (a [nb][t][c], u [nb][k][c], m [nb][t][k])."""
-    if SPLIT_BF16_TERMS in (6, 9) and k >= SPLIT_BF16_MIN_CHANNELS and c % 32 == 0:
-        _note("gemm_split_bf16")
-        call("ssv_gemm_batched_split", nb, t, c, k, ptr(a), ptr(u), ptr(m), None, None, SPLIT_BF16_TERMS, stream())
+    """m[b] = a[b] . u[b]^T for the nb transformed-domain positions (a [nb][t][c], u [nb][k][c], m [nb][t][k]); in the bf16x3 arithmetic on the planes of u."""
+    if ARITHMETIC == "bf16x3" and c % 32 == 0 and k % 4 == 0:
+        _note("gemm_batched_bf16x3")
+        call("ssv_gemm_batched_split", nb, t, c, k, ptr(a), ptr(_planes(u)), ptr(m), None, None, stream())
     else:
         call("ssv_gemm_batched", nb, t, c, k, ptr(a), ptr(u), ptr(m), stream())
+
+
+def _gemm_batched_wgrad(nb, t, c, k, v, dm, du, chunk=0, flush=0):
+    """du[b] = dm[b]^T . v[b] over the t tiles; ``chunk`` / ``flush``: blocked accumulation (ssv_gemm_batched_wgrad_blocked)."""
+    lib = _lib.load()
+    if ARITHMETIC == "bf16x3" and c % 4 == 0 and k % 4 == 0:
+        _note("gemm_batched_wgrad_bf16x3")
+        ws = workspace.get(lib.ssv_gemm_batched_wgrad_blocked_workspace_bytes(nb, t, c, k, chunk), v.device)
+        call("ssv_gemm_batched_wgrad_split", nb, t, c, k, ptr(v), ptr(dm), ptr(du), chunk, flush, ptr(ws), ws.numel(), stream())
+    elif chunk > 0 or flush > 0:
+        ws = workspace.get(lib.ssv_gemm_batched_wgrad_blocked_workspace_bytes(nb, t, c, k, chunk), v.device)
+        call("ssv_gemm_batched_wgrad_blocked", nb, t, c, k, ptr(v), ptr(dm), ptr(du), chunk, flush, ptr(ws), ws.numel(), stream())
+    else:
+        ws = workspace.get(lib.ssv_gemm_batched_wgrad_workspace_bytes(nb, t, c, k), v.device)
+        call("ssv_gemm_batched_wgrad", nb, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
 
 
 def wino44_conv2d_fwd(x, w, in_affine=None, want_stats=False, keep_v=False):
@@ -1368,9 +1415,8 @@ def wino_conv2d_wgrad(v, dy, w_like, dw, accumulate=True, dgrad_follows=None):
     t = int(lib.ssv_wino_tiles(n, h, w_))
     dm = torch.empty((16, t, k), dtype=torch.float32, device=dy.device)
     call("ssv_wino_dy_transform", n, h, w_, k, ptr(dy), ptr(dm), stream())
-    ws = workspace.get(lib.ssv_gemm_batched_wgrad_workspace_bytes(16, t, c, k), dy.device)
     du = torch.empty((16, k, c), dtype=torch.float32, device=dy.device)
-    call("ssv_gemm_batched_wgrad", 16, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
+    _gemm_batched_wgrad(16, t, c, k, v, dm, du)
     call("ssv_wino_filter_grad", k, c, ptr(du), ptr(dw), int(accumulate), stream())
     return dw
 
@@ -1406,12 +1452,12 @@ def wino44_conv2d_wgrad(v, dy, w_like, dw, accumulate=True, dgrad_follows=None):
         call("ssv_wino44_dy_transform", n, h, w_, k, ptr(g), ptr(dm), stream())
     dy = g
     du = torch.empty((36, k, c), dtype=torch.float32, device=dy.device)
-    if WINOGRAD44_WGRAD_CHUNK > 0 or WINOGRAD44_WGRAD_FLUSH > 0:
-        ws = workspace.get(lib.ssv_gemm_batched_wgrad_blocked_workspace_bytes(36, t, c, k, WINOGRAD44_WGRAD_CHUNK), dy.device)
-        call("ssv_gemm_batched_wgrad_blocked", 36, t, c, k, ptr(v), ptr(dm), ptr(du), WINOGRAD44_WGRAD_CHUNK, WINOGRAD44_WGRAD_FLUSH, ptr(ws), ws.numel(), stream())
+    if ARITHMETIC == "bf16x3":
+        # the bf16 instruction folds 32 products per accumulator rounding (the fp32 one: 2), so a chain's rounding error is that of one 16x shorter: the register-level
+        # flush is not needed for the 2e-6 bar (tests/test_gpu_winograd44.py measures it), the chunked fp64 fold stays
+        _gemm_batched_wgrad(36, t, c, k, v, dm, du, WINOGRAD44_WGRAD_CHUNK, WINOGRAD44_WGRAD_FLUSH_BF16X3)
     else:
-        ws = workspace.get(lib.ssv_gemm_batched_wgrad_workspace_bytes(36, t, c, k), dy.device)
-        call("ssv_gemm_batched_wgrad", 36, t, c, k, ptr(v), ptr(dm), ptr(du), ptr(ws), ws.numel(), stream())
+        _gemm_batched_wgrad(36, t, c, k, v, dm, du, WINOGRAD44_WGRAD_CHUNK, WINOGRAD44_WGRAD_FLUSH)
     call("ssv_wino44_filter_grad", k, c, ptr(du), ptr(dw), int(accumulate), stream())
     return dw
 

@@ -89,6 +89,7 @@ def linear_evaluation(config, train_data, test_data, num_classes, device):
             ops.conv2d_wgrad(x.view(n, 1, 1, d), dlog.view(n, 1, 1, cpad), w, gw, accumulate=False)
             ops.colsum(dlog, gb, accumulate=False)
             _lib.call("ssv_sgd", flat.numel(), _lib.ptr(flat), _lib.ptr(grad), _lib.ptr(buf), lr, wd, mom, 0, int(first), _lib.stream())
+            ops.invalidate_weight_caches()         # w changed under its cached bf16 planes (every in-place update of a GEMM operand says so)
         return stats
 
     acc, step = 0.0, 0

@@ -69,6 +69,21 @@ class FusedSGD(torch.optim.Optimizer):
         self.momentum_buffer = ops.fill_(torch.empty_like(self.arena.data), 0.0)
         self._steps = 0
         self.grad_sync = None        # set by the data-parallel wrapper (distributed.attach_grad_sync): its finish() runs before the update
+        # (lr, weight decay, momentum, first-step flag) in device memory: what the update of a step CAPTURED as a HIP graph reads (ssv_sgd_nesterov_dev), so that the
+        # schedules move four device floats and not kernel arguments - one graph serves the whole run (graph.StepGraph calls push_hyper() before every replay)
+        self._hyper_dev = ops.fill_(torch.empty(4, dtype=torch.float32, device=self.arena.data.device), 0.0)
+        self._hyper_sent = None
+
+    def hyper(self):
+        g = self.param_groups[0]
+        return (float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), 0.0 if self._steps > 0 else 1.0)
+
+    def push_hyper(self):
+        """Bring the device copy of the hyper-parameters up to date (a blocking 16-byte copy, only when a schedule has moved them)."""
+        h = self.hyper()
+        if h != self._hyper_sent:
+            self._hyper_dev.copy_(torch.tensor(h, dtype=torch.float32))
+            self._hyper_sent = h
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
@@ -84,8 +99,11 @@ class FusedSGD(torch.optim.Optimizer):
             self.grad_sync.finish()
             g2 = None
         ops.invalidate_weight_caches()               # the transposed-filter cache describes the weights we are about to change
-        _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.momentum_buffer),
-                  float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), int(self._steps == 0), _lib.stream())
+        if hnn.capturing():                          # recorded into a HIP graph: hyper-parameters from device memory (see __init__)
+            _lib.call("ssv_sgd_nesterov_dev", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.momentum_buffer), _lib.ptr(self._hyper_dev), _lib.stream())
+        else:
+            _lib.call("ssv_sgd_nesterov", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.momentum_buffer),
+                      float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), int(self._steps == 0), _lib.stream())
         self._steps += 1
 
 
@@ -102,10 +120,22 @@ class FusedAdamW(torch.optim.Optimizer):
         self.clip = float(clip)
         self._steps = 0
         # the step count lives in device memory (ssv_adamw_counted): nothing in the update's launch changes from step to step, so the training step can be
-        # replayed as a HIP graph (graph.StepGraph); _steps mirrors it on the host for readers
+        # replayed as a HIP graph (graph.StepGraph); _steps counts the EXECUTED steps on the host (eager steps and replays; StepGraph keeps it right)
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.arena.data.device)
-        self._bc_dev = ops.fill_(torch.empty(4, dtype=torch.float32, device=self.arena.data.device), 0.0)
+        self._bc_dev = ops.fill_(torch.empty(4, dtype=torch.float32, device=self.arena.data.device), 0.0)      # [bc1, 1/sqrt(bc2)] written by the device, [lr, weight decay] by push_hyper()
+        self._hyper_sent = None
         self.grad_sync = None
+
+    def hyper(self):
+        g = self.param_groups[0]
+        return (float(g["lr"]), float(g["weight_decay"]))
+
+    def push_hyper(self):
+        """Bring the device copy of (lr, weight decay) up to date: what a CAPTURED update reads (ssv_adamw_counted_dev), only when a schedule has moved them."""
+        h = self.hyper()
+        if h != self._hyper_sent:
+            self._bc_dev[2:4].copy_(torch.tensor(h, dtype=torch.float32))
+            self._hyper_sent = h
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
@@ -122,9 +152,13 @@ class FusedAdamW(torch.optim.Optimizer):
             g2 = None
         self._steps += 1
         ops.invalidate_weight_caches()
-        _lib.call("ssv_adamw_counted", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self._step_dev),
-                  _lib.ptr(self._bc_dev), self.clip, _lib.stream())
+        if hnn.capturing():
+            _lib.call("ssv_adamw_counted_dev", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), _lib.ptr(self._step_dev), _lib.ptr(self._bc_dev), self.clip, _lib.stream())
+        else:
+            _lib.call("ssv_adamw_counted", a.numel, _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(g2), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                      float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self._step_dev),
+                      _lib.ptr(self._bc_dev), self.clip, _lib.stream())
 
 
 def get_optimizer(config, params):

@@ -1,6 +1,6 @@
 """GPU: the training step replayed as one HIP graph (ssv_amd.graph.StepGraph) against the eager step it was captured from - the reference's own regime
 (configs/simclr.yaml: resnet18 reduce_bottom_conv on 32 x 32 images; models/simclr.py:86-95, models/byol.py:125-135, models/barlow.py:86-95).  Same kernels in the
-same order on the same data: every step's loss and the parameters afterwards are BITWISE those of the eager run, through a learning-rate change (new capture), a
+same order on the same data: every step's loss and the parameters afterwards are BITWISE those of the eager run, through a learning-rate change (device memory: the same graph), a
 ragged batch (eager fallback) and BYOL's per-step EMA between replays."""
 import os
 import sys
@@ -42,7 +42,7 @@ def test_replayed_steps_are_bitwise_the_eager_steps(dev, algo):
         sg = StepGraph(t, mode="1" if mode == "graph" else "0", graph_floors=False)          # the eager kernel selection: bitwise comparable
         losses = []
         for i, batch in enumerate(batches):
-            if i == 5:                                           # the schedule moves the learning rate: a new graph
+            if i == 5:                                           # the schedule moves the learning rate: four device floats, the same graph
                 for g in t.optim.param_groups:
                     g["lr"] *= 0.5
             if i == 7:                                           # the ragged last batch of an epoch: runs eagerly in both
@@ -131,7 +131,7 @@ def test_adamw_with_the_step_count_in_device_memory_is_the_by_value_update(dev):
 
 
 def test_dino_step_replays_as_a_graph_through_an_epoch_schedule_change(dev):
-    """DINO (models/dino.py:143-169) on a small ViT: AdamW's step count lives in device memory, the per-epoch scalars (temperatures, weight decay) are part of the
+    """DINO (models/dino.py:143-169) on a small ViT: AdamW's step count lives in device memory, the per-epoch scalars (temperatures; the weight decay is device memory) are part of the
     graph's key - the replayed steps are bitwise the eager ones, before and after `_after_epoch` moves the schedules (a new capture)."""
     import bench
     from ssv_amd.graph import StepGraph
@@ -228,18 +228,70 @@ def test_graph_survives_eager_work_between_replays_over_many_steps(dev):
         assert torch.equal(a, b), what
 
 
-def test_a_per_step_schedule_sends_the_graph_back_to_the_eager_step(dev):
-    """A learning rate that moves EVERY step would re-capture every step (a capture costs more than the launches it saves): after 8 captures with too few replays
-    the wrapper gives up for good and the steps go on eagerly."""
+def test_a_per_step_learning_rate_schedule_is_served_by_one_graph(dev):
+    """Learning rate, weight decay and momentum are device memory under capture (ssv_sgd_nesterov_dev; rounds 4-5 baked them into the graph and re-captured when they
+    moved): a schedule that moves the learning rate EVERY step replays ONE graph, bitwise the eager run - and the optimizer's step count follows the executed steps."""
     from ssv_amd.graph import StepGraph
-    t = _trainer(dev, "simclr")
-    sg = StepGraph(t, mode="1")
     b = _batches(dev, 1)[0]
+    runs = {}
+    for mode in ("0", "1"):
+        t = _trainer(dev, "simclr")
+        sg = StepGraph(t, mode=mode, graph_floors=False)
+        losses = []
+        for i in range(16):
+            for g in t.optim.param_groups:
+                g["lr"] = 0.2 * (1.0 - 0.01 * i)
+                g["weight_decay"] = 1e-4 * (1.0 + 0.1 * i)
+            losses.append(sg(b)["loss"])
+        torch.cuda.synchronize()
+        runs[mode] = (losses, t.optim.arena.data.clone(), t.optim._steps, sg.describe())
+    (le, pe, ne, _), (lg, pg, ng, info) = runs["0"], runs["1"]
+    assert info["captures"] == 1 and info["graphs"] == 1 and info["replays"] >= 13 and info["disabled"] is None, info
+    assert all(np.isfinite(le)) and le == lg and torch.equal(pe, pg)
+    assert ne == ng == 16
+
+
+def test_a_graph_key_that_moves_every_step_sends_the_graph_back_to_the_eager_step(dev):
+    """A scalar that still reaches a kernel as an ARGUMENT and moves every step (here: a trainer whose graph_key() does) would re-capture every step: after 8 captures with
+    too few replays the wrapper gives up for good and the steps go on eagerly; at most MAX_LIVE graphs were ever live, the others retired."""
+    from ssv_amd import graph
+    t = _trainer(dev, "simclr")
+    sg = graph.StepGraph(t, mode="1")
+    b = _batches(dev, 1)[0]
+    tick = [0]
+    t.graph_key = lambda: (tick[0],)
     losses = []
     for i in range(16):
-        for g in t.optim.param_groups:
-            g["lr"] = 0.2 * (1.0 - 0.01 * i)
+        tick[0] = i
         losses.append(sg(b)["loss"])
+        assert len(sg.graphs) <= graph.MAX_LIVE
     info = sg.describe()
     assert info["captures"] == 8 and info["graphs"] == 0 and "changes too often" in info["disabled"], info
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_a_failing_capture_falls_back_to_an_untainted_eager_step(dev):
+    """A capture that raises half way (here: in the loss) has already RECORDED the forward - the weight caches hold transposed / transformed / split filters that were never
+    computed and live in the discarded graph's pool, and the optimizer counted a step.  The fallback must run the eager step on clean caches with the count rolled
+    back: bitwise the step of a trainer that never tried to capture."""
+    from ssv_amd import nn as hnn
+    from ssv_amd.graph import StepGraph
+    batches = _batches(dev, 4)
+    runs = {}
+    for mode in ("plain", "failing"):
+        t = _trainer(dev, "simclr")
+        sg = StepGraph(t, mode="1" if mode == "failing" else "0", graph_floors=False)
+        if mode == "failing":
+            real = t.loss_fn
+
+            def boom(*a, **k):
+                if hnn.capturing():
+                    raise RuntimeError("injected failure under capture")
+                return real(*a, **k)
+            t.loss_fn = boom
+        losses = [sg(b)["loss"] for b in batches]
+        torch.cuda.synchronize()
+        runs[mode] = (losses, t.optim.arena.data.clone(), t.optim._steps, sg.describe())
+    (lp, pp, np_, _), (lf, pf, nf, info) = runs["plain"], runs["failing"]
+    assert info["disabled"] is not None and "injected failure" in info["disabled"] and info["graphs"] == 0, info
+    assert lp == lf and torch.equal(pp, pf) and np_ == nf == 4

@@ -139,7 +139,14 @@ def test_grouped_conv_on_its_block_diagonal_bank(dev, case):
     dxg = ops.conv2d_dgrad(dyd, bank, xd.shape, st, 1, addend=add, groups=g)
     dxd = ops.conv2d_dgrad(dyd, bank, xd.shape, st, 1, addend=add)
     close(nchw(dxg.cpu()), x.grad + nchw(add.cpu()).double(), what="grouped dgrad")
-    assert torch.equal(dxg, dxd)
+    if st == 1:
+        assert torch.equal(dxg, dxd)
+    else:
+        # the strided data gradient of a BANK runs its 64-column tile on the fp32 MFMA instruction in either arithmetic (no bf16-piece variant of that tile), the
+        # dense product of the same tensor takes the 128-column bf16x3 kernel: bit for bit only where both run the same instruction
+        with ops.arithmetic("f32"):
+            assert torch.equal(ops.conv2d_dgrad(dyd, bank, xd.shape, st, 1, addend=add, groups=g), ops.conv2d_dgrad(dyd, bank, xd.shape, st, 1, addend=add))
+        close(dxg.cpu(), dxd.cpu(), rtol=1e-5, what="grouped vs dense strided dgrad")
     dbank = torch.full_like(bank, float("nan"))             # whatever the skipped tiles leave behind must never be read
     ops.conv2d_wgrad(xd, dyd, bank, dbank, st, 1, accumulate=False, groups=g)
     dwg = torch.zeros_like(wgd)

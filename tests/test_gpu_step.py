@@ -721,35 +721,42 @@ def test_projection_shortcut_backward_without_its_reduction_pass_matches_the_two
     assert 0.0 < worst < 2e-5, f"worst per-tensor gradient difference {worst:.2e} (0 = the fused path did not run)"
 
 
+@pytest.mark.parametrize("arith,bar", [("f32", 2e-6), ("bf16x3", 1e-5)])
 @pytest.mark.parametrize("size,b", [(64, 6), (96, 3), (70, 2)])
-def test_compact_stride2_shortcut_gradient_matches_the_full_resolution_form(dev, size, b):
+def test_compact_stride2_shortcut_gradient_matches_the_full_resolution_form(dev, size, b, arith, bar):
     """The data gradient of a stage entry's 1x1 / stride-2 projection shortcut (networks/resnet.py:131-135) stays compact - one dense GEMM on the
     subsampled grid (ops.StridedGrad) - and conv1's data gradient, the last contribution to the unit input's gradient, adds it in its gate
     epilogue at the pixels with even (h, w) (ssv_conv2d_fwd_gated_s2add / _dyin_s2add).  Against the full-resolution form (the parity-class
     kernel writing three quarters zeros, read back as a dense addend): forward untouched, every gradient equal to rounding; odd map sizes
-    (35 -> 18, 9 -> 5) included."""
+    (35 -> 18, 9 -> 5) included.
+    The two forms run the SAME product on two different kernels (forward kernel on the subsampled grid / parity-class data-gradient kernel).  On the fp32 MFMA
+    instruction both are the same k-ordered fmaf chain and the gradients agree to 2e-6 - the bar of rounds 3-5, kept under SSV_ARITHMETIC=f32, where it proves that
+    every pixel gets the right addend.  In the bf16x3 arithmetic the two kernels fold the piece products through differently shaped LDS images and tiles, i.e. two
+    fp32-accurate evaluations with different rounding, and the difference - carried back through 50 layers - is bounded by 1e-5 (measured 2.8-3.7e-6), half the bar
+    the fused / unfused BatchNorm chain above is held to."""
     from ssv_amd import nn as hnn, ops
     a1, a2 = seeded_randn(2100, b, 3, size, size), seeded_randn(2101, b, 3, size, size)
     outs, calls = [], []
     inner = ops.compact_s2_dgrad
     prev_hw, hnn._BN_DY_MIN_HW = hnn._BN_DY_MIN_HW, 0            # small inputs: the dy_in form of conv1's data gradient too
     try:
-        for compact in (True, False):
-            prev, hnn._COMPACT_S2_DGRAD = hnn._COMPACT_S2_DGRAD, compact
-            calls.append(0)
+        with ops.arithmetic(arith):
+            for compact in (True, False):
+                prev, hnn._COMPACT_S2_DGRAD = hnn._COMPACT_S2_DGRAD, compact
+                calls.append(0)
 
-            def counted(*a, **k):
-                calls[-1] += 1
-                return inner(*a, **k)
-            ops.compact_s2_dgrad = counted
-            try:
-                m = _Step(dev, "resnet50", False)
-                loss, z1, z2 = m.step(a1, a2)
-                torch.cuda.synchronize()
-                outs.append((loss, z1.cpu(), m, m.grads.cpu().clone()))
-            finally:
-                hnn._COMPACT_S2_DGRAD = prev
-                ops.compact_s2_dgrad = inner
+                def counted(*a, **k):
+                    calls[-1] += 1
+                    return inner(*a, **k)
+                ops.compact_s2_dgrad = counted
+                try:
+                    m = _Step(dev, "resnet50", False)
+                    loss, z1, z2 = m.step(a1, a2)
+                    torch.cuda.synchronize()
+                    outs.append((loss, z1.cpu(), m, m.grads.cpu().clone()))
+                finally:
+                    hnn._COMPACT_S2_DGRAD = prev
+                    ops.compact_s2_dgrad = inner
     finally:
         hnn._BN_DY_MIN_HW = prev_hw
     assert calls == [6, 0], calls                                 # layer2 / layer3 / layer4 entries, two views
@@ -762,4 +769,4 @@ def test_compact_stride2_shortcut_gradient_matches_the_full_resolution_form(dev,
             assert float(a.abs().max()) < 1e-5
             continue
         worst = max(worst, float((a - r).norm() / r.norm()))
-    assert worst < 2e-6, f"worst per-tensor gradient difference {worst:.2e}"
+    assert worst < bar, f"worst per-tensor gradient difference {worst:.2e}"

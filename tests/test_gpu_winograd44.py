@@ -281,64 +281,3 @@ def test_one_pass_over_dy_leaves_both_backward_operands(dev, n, h, w_, c, k):
     assert rel(dw, dw_ref.cpu().double()) < 2e-5 and rel(dx, dx_ref.cpu().double()) < 2e-5
     with pytest.raises(_lib.SsvError):                      # a LazyGrad that the weight gradient has not visited cannot feed the Winograd data gradient
         ops.wino44_conv2d_dgrad(ops.LazyGrad(gd, xd, cd), w)
-
-
-@pytest.mark.parametrize("nb,t,c,k", [(36, 1813, 128, 128), (16, 520, 256, 256), (36, 100, 512, 512), (4, 333, 64, 192), (2, 129, 1024, 132)])
-@pytest.mark.parametrize("terms", [6, 9])
-def test_batched_gemm_on_the_bf16_pipe_by_operand_splitting(dev, nb, t, c, k, terms):
-    """ssv_gemm_batched_split (opt-in, csrc/gemm_split.hip): each fp32 operand as three bf16 pieces, 6 or 9 piece products accumulated in fp32 on
-    v_mfma_f32_32x32x16_bf16.  Against fp64 its error is no larger than the fp32-MFMA kernel's (ssv_gemm_batched) on the same operands - ragged row counts, a channel
-    count that is no multiple of the 128-wide tile (192, 132), contractions of 64 ... 1,024 - and 6 terms are as good as 9."""
-    from ssv_amd import _lib
-    g = torch.Generator(device=dev).manual_seed(11)
-    a = torch.randn(nb, t, c, device=dev, generator=g).clamp_min_(-0.5)          # mostly non-negative, like transformed ReLU outputs are not - mixed signs kept
-    w = torch.randn(nb, k, c, device=dev, generator=g) * (1.0 / c) ** 0.5
-    ref = torch.bmm(a.double(), w.double().transpose(1, 2))
-    y32 = torch.full((nb, t, k), float("nan"), device=dev)
-    ysp = torch.full((nb, t, k), float("nan"), device=dev)
-    _lib.call("ssv_gemm_batched", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(y32), _lib.stream())
-    _lib.call("ssv_gemm_batched_split", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(ysp), None, None, terms, _lib.stream())
-    torch.cuda.synchronize()
-    assert torch.isfinite(ysp).all()
-    e32 = float((y32.double() - ref).norm() / ref.norm())
-    esp = float((ysp.double() - ref).norm() / ref.norm())
-    worst32 = float((y32.double() - ref).abs().max() / ref.abs().max())
-    worstsp = float((ysp.double() - ref).abs().max() / ref.abs().max())
-    assert esp <= 1.10 * e32 + 1e-9, (esp, e32)
-    assert worstsp <= 1.5 * worst32 + 1e-9, (worstsp, worst32)
-    with pytest.raises(_lib.SsvError, match="terms"):
-        _lib.call("ssv_gemm_batched_split", nb, t, c, k, _lib.ptr(a), _lib.ptr(w), _lib.ptr(ysp), None, None, 3, _lib.stream())
-    # the plain 1x1 / Linear epilogue: + bias[channel] + addend[row][channel] (one product), the addend in place
-    bias = torch.randn(k, device=dev, generator=g)
-    acc = torch.randn(t, k, device=dev, generator=g)
-    want = ref[0] + bias.double() + acc.double()
-    _lib.call("ssv_gemm_batched_split", 1, t, c, k, _lib.ptr(a[0]), _lib.ptr(w[0]), _lib.ptr(acc), _lib.ptr(bias), _lib.ptr(acc), terms, _lib.stream())
-    torch.cuda.synchronize()
-    assert float((acc.double() - want).norm() / want.norm()) <= 1.10 * e32 + 1e-7
-
-
-@pytest.mark.parametrize("n,h,c", [(64, 28, 128), (64, 14, 256), (128, 7, 512)])
-def test_winograd_products_with_the_split_switch_keep_the_f44_error(dev, n, h, c):
-    """ops.SPLIT_BF16_TERMS = 6 (the opt-in switch): the F(4x4) forward and data gradient against fp64 are no worse than with the fp32-MFMA products."""
-    from ssv_amd import ops
-    g = torch.Generator(device=dev).manual_seed(13)
-    x = torch.relu(torch.randn(n, h, h, c, device=dev, generator=g))
-    w = (torch.randn(c, c, 3, 3, device=dev, generator=g) * (2.0 / (9 * c)) ** 0.5).contiguous(memory_format=torch.channels_last)
-    dy = torch.randn(n, h, h, c, device=dev, generator=g)
-    xd, wd = x.permute(0, 3, 1, 2).double(), w.double()
-    ref_y = torch.nn.functional.conv2d(xd, wd, padding=1).permute(0, 2, 3, 1)
-    ref_dx = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), wd, padding=1).permute(0, 2, 3, 1)
-    errs = {}
-    saved = ops.SPLIT_BF16_TERMS
-    try:
-        for terms in (0, 6):
-            ops.SPLIT_BF16_TERMS = terms
-            ops.invalidate_weight_caches()
-            y = ops.wino44_conv2d_fwd(x, w, want_stats=False)[0]
-            dx = ops.wino44_conv2d_dgrad(dy, w)
-            dx = dx[0] if isinstance(dx, tuple) else dx
-            errs[terms] = (float((y.double() - ref_y).norm() / ref_y.norm()), float((dx.double() - ref_dx).norm() / ref_dx.norm()))
-    finally:
-        ops.SPLIT_BF16_TERMS = saved
-        ops.invalidate_weight_caches()
-    assert errs[6][0] <= 1.10 * errs[0][0] and errs[6][1] <= 1.10 * errs[0][1], errs

@@ -235,7 +235,7 @@ def test_profiling_aggregators_classify_every_kernel_like_the_scope_it_runs_unde
 
 def test_step_graph_falls_back_to_the_eager_step_where_a_graph_cannot_be(monkeypatch):
     """graph.StepGraph's host logic without a GPU: the reasons it refuses (mode 0, unsafe trainer, wrong optimizer, CPU batch, large images under auto) all end in
-    trainer.train_step(batch) being called - the step never disappears - and the graph's key carries every scalar a captured step would bake in."""
+    trainer.train_step(batch) being called - the step never disappears - and the graph's key carries every scalar a captured step bakes in (and no more)."""
     from ssv_amd import graph
     from ssv_amd.utils import train_utils
 
@@ -272,9 +272,11 @@ def test_step_graph_falls_back_to_the_eager_step_where_a_graph_cannot_be(monkeyp
     sg(batch)
     assert sg.describe()["disabled"] == "SSV_STEP_GRAPH=0"
     key = graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs})
-    assert key[1] == (("lr", 0.2), ("momentum", 0.9), ("weight_decay", 1e-4)) and key[3] == (0.1, 0.04) and key[0][0][1] == (2, 3, 8, 8)
+    assert key[1] == () and key[3] == (0.1, 0.04) and key[0][0][1] == (2, 3, 8, 8)          # SGD: lr / weight decay / momentum are device memory under capture, not baked in
     t.optim.param_groups[0]["lr"] = 0.1
-    assert graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs}) != key     # the schedule moved: another graph
+    assert graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs}) == key     # the schedule moved four device floats: the same graph
+    t.graph_key = lambda: (0.1, 0.05)
+    assert graph.StepGraph(t, mode="1")._key({k: batch[k] for k in t.graph_inputs}) != key     # a scalar that still reaches a kernel as an argument moved: another graph
 
 
 def test_step_graph_lifetime_rules():

@@ -6,7 +6,7 @@ bytes / busy cycles get divided by another class's time.  First match wins; test
 # family (the transformed-domain GEMMs ARE conv_fwd_k launches), gated output (<2>, <3>: a data gradient's epilogue) -> conv_dgrad, dY / filter-gradient
 # transforms -> weight gradient.  The stem's rows-in-LDS kernels (round 4) are the stem's forward / weight gradient.
 CLASSES = (
-    ("conv_fwd", "conv_fwd_k"), ("conv_fwd", "stem_fwd_rows_k"), ("conv_fwd", "gemm_batched_split_k"),
+    ("conv_fwd", "conv_fwd_k"), ("conv_fwd", "stem_fwd_rows_k"),
     ("conv_dgrad", "conv_dgrad_k"), ("conv_dgrad", "wino_output_k<2"), ("conv_dgrad", "wino_output_k<3"), ("conv_dgrad", "wino44_output_k<2"), ("conv_dgrad", "wino44_output_k<3"),
     ("conv_wgrad", "conv_wgrad_k"), ("conv_wgrad", "stem_wgrad_rows_k"), ("conv_wgrad", "wgrad_reduce"),
     ("conv_wgrad", "wino_dy_k"), ("conv_wgrad", "wino_dfilter_k"), ("conv_wgrad", "wino44_dy_k"), ("conv_wgrad", "wino44_dy_both_k"), ("conv_wgrad", "wino44_dfilter_k"),
@@ -21,12 +21,27 @@ CLASSES = (
     ("pool", "maxpool_"), ("pool", "gap_"),
     ("misc", "gelu_"), ("misc", "colsum_"), ("misc", "wn_fwd_k"), ("misc", "wn_bwd_k"), ("misc", "knn_agree_k"), ("misc", "zero_count_k"), ("misc", "scale_k"), ("misc", "add_k"),
     ("misc", "fill_k"), ("misc", "pad_channels_k"), ("misc", "group_expand_k"), ("misc", "group_extract_k"), ("misc", "filter_transpose_k"), ("misc", "nchw_to_nhwc_k"),
-    ("misc", "nhwc_to_nchw_k"), ("misc", "queue_push_k"), ("misc", "queue_advance_k"), ("misc", "vit_embed_"),
+    ("misc", "nhwc_to_nchw_k"), ("misc", "queue_push_k"), ("misc", "queue_advance_k"), ("misc", "vit_embed_"), ("misc", "split_planes_k"),
 )
 CONV_FAMILY = ("conv_fwd", "conv_dgrad", "conv_wgrad")
 # host functions whose kernels run under another class's scope than the table gives them - both inside the conv family, so the family sums agree:
 # fc2's data gradient of the ViT FFN is a FORWARD-kernel launch (GELU-derivative epilogue) timed as a data gradient (DINO only)
 SCOPE_EXCEPTIONS = {"ssv_linear_fwd_gelugrad"}
+
+
+# template-argument count of the GEMM kernels whose LAST argument is SP (csrc/conv_mfma.hip): true = the launch multiplies in SSV_ARITH_BF16X3 (six bf16 piece
+# products per fp32 product on v_mfma_f32_16x16x32_bf16), false = on v_mfma_f32_32x32x2_f32
+_SP_ARGS = {"conv_fwd_k": 15, "conv_wgrad_k": 12, "conv_dgrad_k": 8}
+
+
+def is_bf16x3(name):
+    """Does this kernel (demangled name from a rocprofv3 trace) run its products as bf16 pieces?"""
+    import re
+    m = re.search(r"(conv_fwd_k|conv_wgrad_k|conv_dgrad_k)<([^>]*)>", name)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(",")]
+    return len(args) == _SP_ARGS[m.group(1)] and args[-1] == "true"
 
 
 def classify(name):
