@@ -78,6 +78,36 @@ def arithmetic_block(device):
             "switch": "SSV_ARITHMETIC=f32 runs every product on v_mfma_f32_32x32x2_f32 (the arithmetic of rounds 1-5): the fp32_mfma_instruction_path leg of this line"}
 
 
+def eval_knn_leg(device, n=50000, d=128, k=20, reps=3):
+    """The reference's kNN evaluation (utils/eval_utils.py:13-21: compute_neighbor_accuracy, k + 1 exact inner-product hits, best dropped) at CIFAR-10's train-set
+    size on projected features of BASELINE's width: one ssv_knn_label_agreement call = the Gram product Z Z^T in row chunks on the GEMM kernel + the streaming top-(k+1)
+    selection over each chunk of S.  Wall time per call, and the two parts from HIP events per launch (the library's profiling scopes)."""
+    from ssv_amd import _lib, ops
+    g = torch.Generator(device=device).manual_seed(n)
+    z = torch.nn.functional.normalize(torch.randn(n, d, device=device, generator=g), dim=1)
+    labels = torch.randint(0, 10, (n,), device=device, generator=g, dtype=torch.int32)
+    count = ops.knn_label_agreement(z, labels, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        count = ops.knn_label_agreement(z, labels, k)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    ops.knn_label_agreement(z, labels, k)
+    torch.cuda.synchronize()
+    prof = _lib.prof_collect()
+    _lib.prof_enable(False)
+    gram_ms, sel_ms = prof["conv_fwd"][0], prof["misc"][0]
+    return {"workload": f"compute_neighbor_accuracy on {n} x {d} unit features, k = {k} (CIFAR-10 train set, proj_dim 128)", "ms_per_call": round(ms, 3),
+            "queries_per_sec": round(n / ms * 1e3, 1), "agreement": round(count / (n * k), 5),
+            "gram": {"ms": round(gram_ms, 3), "algorithmic_gflop": round(2.0 * n * n * d / 1e9, 1), "tflops": round(2.0 * n * n * d / gram_ms / 1e9, 1),
+                     "arithmetic": "fp32 MFMA (exact inner products: integer-valued features count bit-exactly)", "s_written_gb": round(4.0 * n * n / 1e9, 2)},
+            "selection": {"ms": round(sel_ms, 3), "s_read_gb": round(4.0 * n * n / 1e9, 2), "gb_per_s": round(4.0 * n * n / sel_ms / 1e6, 1), "hbm_roof_gb_per_s": 6290.0,
+                          "frac": round(4.0 * n * n / sel_ms / 1e6 / 6290.0, 3)},
+            "timing": "wall clock over %d calls; parts: HIP events per launch of one more call" % reps}
+
+
 def fp32_instruction_leg(step, b, world, warmup=2, steps=6):
     """The same step with every product on v_mfma_f32_32x32x2_f32 (ops.arithmetic('f32')), timed in this process after the headline's timed region: either reading of
     `dtype: f32` finds its number in this line."""
@@ -254,9 +284,9 @@ def cpu_baseline(views, steps, algo="simclr", lr_scale=None, fp64=True):
     lr_scale = GATE_LR_SCALES[algo] if lr_scale is None else lr_scale
     host = os.cpu_count() or 1
     # SURVEY 8d asks for all host cores; on the 256-thread GPU boxes (2 x EPYC 9575F) the ATen / oneDNN step is pathological at 256 threads
-    # (round 2 measured ~320 s for ONE batch-32 step there against 3.5 s at 32 threads; that log was not kept).  32 threads is what the
-    # baseline uses; host_cpus and the CPU model are reported next to it.
-    torch.set_num_threads(min(host, 32))
+    # (round 2 measured ~320 s for ONE batch-32 step there against 3.5 s at 32 threads; that log was not kept).  Round 6: the thread count is SWEPT - one
+    # warm-up + one timed step of a scratch oracle at 32, 64 and 128 threads (those the host has) - and the trajectory below runs at the fastest; the sweep,
+    # host_cpus and the CPU model are reported next to the number.
     v1, v2 = views
     batch, size = v1.shape[0], v1.shape[-1]
     base = BENCH_CFG[algo]["optimizer"]
@@ -267,8 +297,19 @@ def cpu_baseline(views, steps, algo="simclr", lr_scale=None, fp64=True):
         make = lambda: oracle.BarlowOracle("resnet50", False, 4096, lr=lr, weight_decay=base["weight_decay"], normalize=True)
     else:
         make = lambda: oracle.SimCLROracle("resnet50", False, 128, lr=lr, weight_decay=base["weight_decay"])
-    m = make()
     step_of = lambda mm, a, b_: (lambda s: mm.train_step(a, b_, step=s)) if algo == "byol" else (lambda s: mm.train_step(a, b_, **({"return_z": True} if s == 0 else {})))
+    sweep = {}
+    for nt in sorted({min(host, c) for c in (32, 64, 128)}):
+        torch.set_num_threads(nt)
+        scratch = make()
+        probe = step_of(scratch, v1, v2)
+        probe(0)
+        t0 = time.perf_counter()
+        probe(1)
+        sweep[nt] = time.perf_counter() - t0
+        del scratch, probe
+    torch.set_num_threads(min(sweep, key=sweep.get))
+    m = make()
     run = step_of(m, v1, v2)
     first = run(0)                                             # warm-up step = step 0 of the gate
     losses, states, dt = [first["loss"]], [None], 0.0
@@ -287,6 +328,7 @@ def cpu_baseline(views, steps, algo="simclr", lr_scale=None, fp64=True):
         losses64 = [first64["loss"]] + [run64(s)["loss"] for s in range(1, steps + 1)]
         del m64
     out = {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cpus": host, "cpu_model": _cpu_model(), "kind": "port",
+           "thread_sweep_images_per_sec": {str(k): round(batch / v, 3) for k, v in sorted(sweep.items())},
            "sample": f"{steps} timed steps (1 warm-up) of the same {algo} ResNet-50 {size}x{size} step at batch {batch} on the GPU path's own augmented views, "
                      f"torch fp32 CPU, lr = config / {round(1 / lr_scale)}"}
     return out, losses, losses64, first.get("z_1"), first64.get("z_1"), states
@@ -1034,6 +1076,10 @@ def main():
             out["parity_gate"], out["cpu_baseline"] = parity_gate_and_cpu_baseline(device, args.algo, tf, source, sample_ids, rows)
             if args.algo == "simclr":
                 out["config1"] = config1_line(device)
+                try:
+                    out["eval_knn"] = eval_knn_leg(device)
+                except Exception as exc:
+                    out["eval_knn"] = {"error": f"{type(exc).__name__}: {exc}"}
         if legs:                                                       # BASELINE configs 4 and 5, driver-visible: each leg on its own, errors recorded
             out["other_configs"] = {}
             for other in ("byol", "dino"):

@@ -517,6 +517,10 @@ int ssv_gelu_bwd(int64_t n, const float* x, const float* dy, float* dx, void* st
  * dh must be 64.  lse and delta: [B][heads][T] (log-sum-exp of the scaled scores; rowsum(dout * o)). */
 int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
                       int32_t ld, float scale, float* o, int32_t ldo, float* lse, void* stream);
+/* ssv_attention_fwd in the given arithmetic (SSV_ARITH_F32_MFMA | SSV_ARITH_BF16X3: Q K^T and P V as six bf16 piece products per fp32 product, csrc/split_bf16.h;
+ * softmax statistics and outputs fp32 either way) */
+int ssv_attention_fwd_arith(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
+                            int32_t ld, float scale, float* o, int32_t ldo, float* lse, int32_t arithmetic, void* stream);
 int ssv_attention_bwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
                       int32_t ld, float scale, const float* o, const float* dout, int32_t ldo, const float* lse,
                       float* delta, float* dq, float* dk, float* dv, int32_t ldg, void* stream);

@@ -165,6 +165,7 @@ SIGNATURES = {
     "ssv_gelu_fwd": (C.c_int, [_i64, _vp, _vp, _vp]),
     "ssv_gelu_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "ssv_attention_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),
+    "ssv_attention_fwd_arith": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _i32, _vp]),
     "ssv_attention_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ssv_weightnorm_fwd": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ssv_weightnorm_bwd": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

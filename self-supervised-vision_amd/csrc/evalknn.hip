@@ -147,7 +147,7 @@ extern "C" int ssv_knn_label_agreement(int64_t n, int32_t d, const float* z, con
   }
   for (int64_t r0 = 0; r0 < n; r0 += cr) {
     const int rows = (int)((n - r0 < cr) ? (n - r0) : cr);
-    ssv_conv_desc cd;
+    ssv_conv_desc cd = {};            // fp32-MFMA arithmetic: the reference's search is exact inner products, and integer-valued features must count bit-exactly
     cd.N = rows; cd.H = 1; cd.W = 1; cd.C = d; cd.K = (int32_t)n; cd.R = 1; cd.S = 1; cd.stride = 1; cd.pad = 0; cd.Ho = 1; cd.Wo = 1;
     if (int rc = ssv_conv2d_fwd(&cd, z + r0 * d, z, nullptr, nullptr, S, stream)) return rc;      // S[rows, n] = Z[r0:r0+rows] Z^T
     ProfScope ps(SSV_PROF_MISC, s);

@@ -15,6 +15,7 @@
 // The contraction over the head dimension is taken in the order d = 32*half + s, so each lane's operand fragment is 32
 // CONSECUTIVE floats of one row (8 x 16-byte loads).
 #include "common.h"
+#include "split_bf16.h"
 
 namespace {
 
@@ -185,6 +186,148 @@ attn_fwd_k(int T, int heads, const float* __restrict__ Q, const float* __restric
   // (the loop's last barrier has passed: the four staging buffers are free - 2 x 2 x 32 x 68 floats, of which each wave takes a private 32 x 64 tile)
   static_assert(NW * 2048 <= 4 * 32 * TS, "one output tile per wave in the staging buffers");
   if (active) store_tile_T_rows(&skv[0][0] + wave * 2048, O + tok0 * ldo + h * DH, ldo, q0, min(32, T - q0), lane, o_lo, o_hi, 1.f / l);
+  if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = (m + log2f(l)) * LN2;
+}
+
+// ------------------------------------------------------------------------------------------------ attention forward, SSV_ARITH_BF16X3 (csrc/split_bf16.h)
+// The same tiling and softmax (S^T = K Q^T with the query on the lane, P^T fed back as the B operand of O^T += V^T P^T), every product as six bf16 piece products on
+// v_mfma_f32_32x32x16_bf16: a 32-key tile costs 2 x 24 MFMAs of 32 cycles where the fp32 form issues 2 x 32 of 64.
+//   * Q (pre-scaled) is split once per wave into registers: the instruction's B operand wants 8 consecutive d per lane and 16-wide slab, d = 16 s + 8 (lane >> 5) + e.
+//   * K and V tiles are split while they are staged: three planes of [32 keys][64 d] bf16 each (128-byte rows, 16-byte chunks XOR-swizzled).  K fragments are row reads
+//     (ds_read_b128); V^T fragments are transposed reads (ds_read_b64_tr_b16: a 16-lane group fetches 4 keys x 16 d and every lane receives ITS d's 4 keys).
+//   * P stays in the S accumulator's registers: lane (query, half) holds keys (j & 3) + 8 (j >> 2) + 4 half, so registers 8 s' .. 8 s' + 7 are the keys
+//     16 s' + 4 half + {0..3} and 16 s' + 8 + 4 half + {0..3} - the contraction index of the 16-key slab s' is taken in THAT order on both operands (the V^T
+//     fragment's two transposed reads start at exactly those two key quads), so P is split in place: no shuffle, no LDS round trip, as in the fp32 form.
+constexpr int KVP = 32 * 128;                                // bytes of one [32 keys][64 d] bf16 plane
+__device__ __forceinline__ int kplane_off(int key, int chunk) { return key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4); }      // ds_read_b128 of lanes = keys: 8 distinct chunks per key parity
+__device__ __forceinline__ int vplane_off(int key, int chunk) { return key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4); } // transposed reads: keys q and q + 2 on opposite 64-byte halves
+
+// eight floats -> the three planes' bf16x8
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8 (&pl)[3]) {
+  u32x2 pa[3], pb[3];
+  splitbf::split4(a, pa);
+  splitbf::split4(b, pb);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) pl[q] = __builtin_bit_cast(bf16x8, u32x4{pa[q][0], pa[q][1], pb[q][0], pb[q][1]});
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
+attn_fwd_sp_k(int T, int heads, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, int ld, float scale,
+              float* __restrict__ O, int ldo, float* __restrict__ LSE) {
+  // [stage][K | V][plane][32 keys x 128 B]; at the end: one fp32 output tile per wave (NW x 8 KB <= 48 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char skv[2 * 2 * 3 * KVP];
+  static_assert(NW * 8192 <= 2 * 2 * 3 * KVP, "one output tile per wave in the staging buffers");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, half = lane >> 5;
+  const int q0 = (blockIdx.x * NW + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const bool active = q0 < T;
+  const int64_t tok0 = (int64_t)b * T;
+  const int qrow = min(q0 + c, T - 1);
+  bf16x8 qf[4][3];                                             // slab s: d = 16 s + 8 half + {0..7}
+  {
+    const float* qp = Q + (tok0 + qrow) * ld + h * DH + 8 * half;
+    const float sc = scale * LOG2E;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split8(*(const f32x4*)(qp + 16 * s) * sc, *(const f32x4*)(qp + 16 * s + 4) * sc, qf[s]);
+  }
+  f32x16 o_lo = zero16(), o_hi = zero16();
+  float m = -INFINITY, l = 0.f;
+  const float* kbase = K + tok0 * ld + h * DH;
+  const float* vbase = V + tok0 * ld + h * DH;
+  constexpr int N4 = 512 / (NW * 64);
+  f32x4 rk[N4], rv[N4];
+  auto load_kv = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = (e & 15) * 4;
+      const int64_t row = min(row0 + r, T - 1);
+      rk[i] = *(const f32x4*)(kbase + row * ld + c4);
+      rv[i] = *(const f32x4*)(vbase + row * ld + c4);
+    }
+  };
+  auto store_kv = [&](int stage) {
+    unsigned char* kp = skv + stage * 6 * KVP;
+    unsigned char* vp = kp + 3 * KVP;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int e = i * NW * 64 + threadIdx.x, r = e >> 4, c4 = e & 15;          // c4: float4 index within the 64-float row
+      u32x2 pk[3], pv[3];
+      splitbf::split4(rk[i], pk);
+      splitbf::split4(rv[i], pv);
+      const int ko = kplane_off(r, c4 >> 1) + (c4 & 1) * 8, vo = vplane_off(r, c4 >> 1) + (c4 & 1) * 8;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { *(u32x2*)(kp + q * KVP + ko) = pk[q]; *(u32x2*)(vp + q * KVP + vo) = pv[q]; }
+    }
+  };
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < T; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < T;
+    if (more) load_kv(k0 + 32);
+    if (active) {
+      const unsigned char* kp = skv + buf * 6 * KVP;
+      const unsigned char* vp = kp + 3 * KVP;
+      f32x16 s = zero16();
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        bf16x8 kf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) kf[q] = *(const bf16x8*)(kp + q * KVP + kplane_off(c, 2 * sl + half));
+#define SSV_MM(P, Q_) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[P], qf[sl][Q_], s, 0, 0, 0)
+        SSV_MM(2, 0); SSV_MM(0, 2); SSV_MM(1, 1); SSV_MM(1, 0); SSV_MM(0, 1); SSV_MM(0, 0);
+#undef SSV_MM
+      }
+      float mt = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (k0 + rowof(j, half) >= T) s[j] = -INFINITY;
+        mt = fmaxf(mt, s[j]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m, mt);
+      const float alpha = ex2(m - mn);
+      float ls = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { s[j] = ex2(s[j] - mn); ls += s[j]; }
+      ls += __shfl_xor(ls, 32, 64);
+      l = l * alpha + ls;
+      m = mn;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { o_lo[j] *= alpha; o_hi[j] *= alpha; }
+      // lane -> its V^T rows: d = 32 hh + 16 ((lane >> 4) & 1) + (lane & 15); the lane's address names key quad row (lane & 15) >> 2, d piece (lane & 3)
+      const int jl = lane & 15, qq = jl >> 2, pp = jl & 3, dsel = (lane >> 4) & 1;
+      typedef __attribute__((address_space(3))) s16x4* lds_p;
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        if (k0 + 16 * sp >= T) continue;                       // every key of this slab is padding (uniform): P is 0 there
+        bf16x8 pf[3];
+        split8(f32x4{s[8 * sp], s[8 * sp + 1], s[8 * sp + 2], s[8 * sp + 3]}, f32x4{s[8 * sp + 4], s[8 * sp + 5], s[8 * sp + 6], s[8 * sp + 7]}, pf);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          bf16x8 vf[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const int chunk = 4 * hh + 2 * dsel + (pp >> 1);
+            const int key_a = 16 * sp + 4 * half + qq, key_b = key_a + 8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(vp + q * KVP + vplane_off(key_a, chunk) + 8 * (pp & 1)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(vp + q * KVP + vplane_off(key_b, chunk) + 8 * (pp & 1)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            vf[q] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+          }
+          f32x16& o = hh ? o_hi : o_lo;
+#define SSV_MM(P, Q_) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[P], pf[Q_], o, 0, 0, 0)
+          SSV_MM(2, 0); SSV_MM(0, 2); SSV_MM(1, 1); SSV_MM(1, 0); SSV_MM(0, 1); SSV_MM(0, 0);
+#undef SSV_MM
+        }
+      }
+    }
+    if (more) store_kv(buf ^ 1);
+    __syncthreads();
+  }
+  const bool valid = q0 + c < T;
+  if (active) store_tile_T_rows(reinterpret_cast<float*>(skv) + wave * 2048, O + tok0 * ldo + h * DH, ldo, q0, min(32, T - q0), lane, o_lo, o_hi, 1.f / l);
   if (valid && half == 0) LSE[((int64_t)b * heads + h) * T + q0 + c] = (m + log2f(l)) * LN2;
 }
 
@@ -830,7 +973,13 @@ __global__ void __launch_bounds__(256) vit_embed_bwd_k(int B, int T, int F, int 
 // ================================================================================================ C ABI
 extern "C" int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
                                  int32_t ld, float scale, float* o, int32_t ldo, float* lse, void* stream) {
+  return ssv_attention_fwd_arith(B, T, heads, dh, q, k, v, ld, scale, o, ldo, lse, SSV_ARITH_F32_MFMA, stream);
+}
+
+extern "C" int ssv_attention_fwd_arith(int32_t B, int32_t T, int32_t heads, int32_t dh, const float* q, const float* k, const float* v,
+                                       int32_t ld, float scale, float* o, int32_t ldo, float* lse, int32_t arithmetic, void* stream) {
   SSV_REQUIRE(B > 0 && T > 0 && heads > 0 && q && k && v && o && lse, "ssv_attention_fwd: bad arguments");
+  SSV_REQUIRE(arithmetic == SSV_ARITH_F32_MFMA || arithmetic == SSV_ARITH_BF16X3, "ssv_attention_fwd: unknown arithmetic %d", arithmetic);
   SSV_REQUIRE(dh == DH, "ssv_attention_fwd: head size must be %d (got %d)", DH, dh);
   SSV_REQUIRE(ld >= heads * dh && ldo >= heads * dh && ld % 4 == 0 && ldo % 4 == 0, "ssv_attention_fwd: row strides must cover heads*dh and be multiples of 4");
   SSV_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "ssv_attention_fwd: pointers must be 16-byte aligned");
@@ -839,7 +988,10 @@ extern "C" int ssv_attention_fwd(int32_t B, int32_t T, int32_t heads, int32_t dh
   ProfScope ps(SSV_PROF_ATTN, s);
   // 37-token local crops run the 64-row tile too: a 16x16x4-tile kernel with one wavefront per (image, head) was measured at 0.161 ms against
   // 0.166 ms here (T 37, 2048 images; profiles/r03_attention_kernels.txt) - both sit at ~2.9 TB/s of q/k/v/o traffic, not on the padded MFMA work.
-  if (T <= 64) hipLaunchKernelGGL(attn_fwd_k<2>, dim3(cdiv(T, 64), heads, B), dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
+  if (arithmetic == SSV_ARITH_BF16X3) {
+    if (T <= 64) hipLaunchKernelGGL(attn_fwd_sp_k<2>, dim3(cdiv(T, 64), heads, B), dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
+    else hipLaunchKernelGGL(attn_fwd_sp_k<4>, dim3(cdiv(T, 128), heads, B), dim3(256), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
+  } else if (T <= 64) hipLaunchKernelGGL(attn_fwd_k<2>, dim3(cdiv(T, 64), heads, B), dim3(128), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
   else hipLaunchKernelGGL(attn_fwd_k<4>, dim3(cdiv(T, 128), heads, B), dim3(256), 0, s, T, heads, q, k, v, ld, scale, o, ldo, lse);
   SSV_CHECK_LAUNCH("attn_fwd_k");
   return SSV_OK;

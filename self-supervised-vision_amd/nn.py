@@ -27,10 +27,7 @@ from ._lib import SsvError
 _SLOT = 0
 _STREAMS = {}
 _VIEW_STREAMS = os.environ.get("SSV_SINGLE_STREAM", "0") != "1"
-_VIEW_SKEW_CYCLES = int(float(os.environ.get("SSV_VIEW_SKEW_US", "0")) * 2400)     # diagnostic switch (do the two views' same-kind kernels collide?)
-_VIEW_SKEW_BWD_CYCLES = int(float(os.environ.get("SSV_VIEW_SKEW_BWD_US", "0")) * 2400)
-_VIEW_STREAM_PRIO = int(os.environ.get("SSV_VIEW_STREAM_PRIO", "0"))       # diagnostic switches: HIP stream priorities (-1 = high, 0 = default) of the view streams
-_INPUT_STREAM_PRIO = int(os.environ.get("SSV_INPUT_STREAM_PRIO", "0"))     # ... and of the stream the next batch's augmentation runs on
+# (round 6: the view-skew and stream-priority switches of round 4's experiments e4 / e8 are gone - both measured no effect, profiles/r04_experiments_step_time.txt)
 
 
 def view_streams():
@@ -120,8 +117,6 @@ class _ViewCtx:
             st.wait_event(self.pv.start)
             self.ctx = torch.cuda.stream(st)
             self.ctx.__enter__()
-            if _VIEW_SKEW_CYCLES and self.slot == 1:
-                torch.cuda._sleep(_VIEW_SKEW_CYCLES)          # diagnostic: view 1 starts this many cycles behind view 0
             self.pv.used.add(self.slot)
             _SLOT = self.slot
         return self
@@ -155,7 +150,7 @@ def data_ready(device, stream=None):
 def _view_stream_pair(device):
     device = _dev_key(device)
     if device not in _STREAMS:
-        _STREAMS[device] = (torch.cuda.Stream(device, priority=_VIEW_STREAM_PRIO), torch.cuda.Stream(device, priority=_VIEW_STREAM_PRIO))
+        _STREAMS[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
     return _STREAMS[device]
 
 
@@ -176,7 +171,7 @@ class input_stream:
             self.main = torch.cuda.current_stream(self.device)
             side = _INPUT_STREAMS.get(self.device)
             if side is None:
-                side = _INPUT_STREAMS[self.device] = torch.cuda.Stream(self.device, priority=_INPUT_STREAM_PRIO)
+                side = _INPUT_STREAMS[self.device] = torch.cuda.Stream(self.device)
                 side.wait_stream(self.main)               # whatever built the dataset on the ambient stream
             ready = _DATA_READY.get(self.device)
             if ready is not None:
@@ -964,8 +959,6 @@ class _Bridge(torch.autograd.Function):
         ctx.tape = None
         if _STREAMS:
             dy.record_stream(torch.cuda.current_stream(dy.device))
-        if _VIEW_SKEW_BWD_CYCLES and tape.slot == 1 and len(tape.ops) > 64:
-            torch.cuda._sleep(_VIEW_SKEW_BWD_CYCLES)          # diagnostic: view 1's encoder backward starts this many cycles behind view 0's
         dx = tape.backward(ctx.y, dy.contiguous())
         if dx is not None:
             dx = ctx.module._finish_input_grad(dx)

@@ -806,6 +806,7 @@ def knn_label_agreement(z, labels, k):
 
 # ------------------------------------------------------------------------------------------- ViT / DINO pieces
 LN_EPS = 1e-5
+ATTENTION_BF16X3 = True      # the attention forward's two products in the bf16x3 arithmetic when ops.ARITHMETIC says so (the backward stays on the fp32 instruction)
 
 
 def layernorm_fwd(x, gamma, beta, addend=None, eps=LN_EPS):
@@ -857,7 +858,8 @@ def attention_fwd(q, k, v, batch, tokens, heads):
         raise _lib.SsvError("attention: q, k, v must share one row stride")
     o = torch.empty((batch * tokens, hid), dtype=torch.float32, device=q.device)
     lse = torch.empty((batch, heads, tokens), dtype=torch.float32, device=q.device)
-    call("ssv_attention_fwd", batch, tokens, heads, dh, ptr(q), ptr(k), ptr(v), _ld(q), dh ** -0.5, ptr(o), hid, ptr(lse), stream())
+    call("ssv_attention_fwd_arith", batch, tokens, heads, dh, ptr(q), ptr(k), ptr(v), _ld(q), dh ** -0.5, ptr(o), hid, ptr(lse),
+         _lib.ARITH_BF16X3 if (ARITHMETIC == "bf16x3" and ATTENTION_BF16X3) else _lib.ARITH_F32_MFMA, stream())
     return o, lse
 
 
