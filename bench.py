@@ -815,6 +815,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="W > 1: this ONE process runs the step of rank 0 of a W-rank job "
                     "(ssv_amd.distributed.emulate_world: every data-parallel code path, transport replaced by device copies)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config3_rank_emulation / other_configs (BYOL, DINO) legs of the default line")
+    ap.add_argument("--no-arith-legs", action="store_true", help="skip the arithmetic block and the fp32-instruction leg (profiling runs: only the shipped step's kernels in the trace)")
     args = ap.parse_args()
 
     from ssv_amd import _lib, distributed as hdist
@@ -1012,7 +1013,7 @@ def main():
 
     # ---- the same step on the fp32 MFMA instruction, and what the shipped arithmetic is (rank 0, one GPU: after the timed region) ----
     fp32_leg, arith = None, None
-    if rank == 0 and world == 1 and not args.emulate_world:
+    if rank == 0 and world == 1 and not args.emulate_world and not args.no_arith_legs:
         from ssv_amd import ops as _ops
         try:
             arith = arithmetic_block(device)

@@ -444,7 +444,7 @@ __device__ __forceinline__ void k_loop2(int nkt, const float* As, const float* B
 // The structure was chosen by measurement (tools/probe/gemm_split_tuned_probe.hip, profiles/r06_probe_split_tuned.txt): two LDS stages with one barrier per tile lose
 // at every occupancy the LDS allows (106-160 against 175-185 TFLOP/s at 4096^3), the 16 x 16 x 32 instruction beats 32 x 32 x 16 by 6-15 % on every shape (the chip
 // holds a higher clock under it), and the split's vector work hides under the other resident workgroups' MFMAs (a build without the residual arithmetic: +0-1 %).
-template <int TM16, int TN16, bool KROWA, bool KROWB, int RBA, int RBB, int FLUSH = 0, class LoadTile, class StoreTile, class Xform = NoXform>
+template <int TM16, int TN16, bool KROWA, bool KROWB, int RBA, int RBB, int FLUSH = 0, int JSPLIT = 1, bool DUAL = false, class LoadTile, class StoreTile, class Xform = NoXform>
 __device__ __forceinline__ void k_loop_split(int nkt, const unsigned char* As, int a_plane, const unsigned char* Bs, int b_plane, int wr0, int wc0, int lane,
                                              f32x4 (&acc)[TM16][TN16], LoadTile&& load_tile, StoreTile&& store_tile, Xform&& xform_tile = NoXform()) {
   if (nkt <= 0) return;
@@ -455,35 +455,49 @@ __device__ __forceinline__ void k_loop_split(int nkt, const unsigned char* As, i
 #pragma unroll
       for (int j = 0; j < TN16; ++j) hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  f32x4 lo[TM16][TN16];                          // the five small piece products of every tile (splitbf::mma6), folded into acc at the end
+  // DUAL: the five small piece products in a second accumulator set (splitbf::mma6x2) - weight gradients and forward products with a long contraction
+  // (SP == 2: R * S * C > SP_DUAL_FROM), where six roundings per 32 products in ONE accumulator end 5-7 % over the fp32-MFMA kernel's error
+  f32x4 lo[DUAL ? TM16 : 1][DUAL ? TN16 : 1];
+  if constexpr (DUAL) {
 #pragma unroll
-  for (int i = 0; i < TM16; ++i)
+    for (int i = 0; i < TM16; ++i)
 #pragma unroll
-    for (int j = 0; j < TN16; ++j) lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TN16; ++j) lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   load_tile();
   xform_tile();
   store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     load_tile();                               // past the last tile: out-of-range offsets read zeros (or in-buffer rows never stored)
-    bf16x8 fb[TN16][3];
+    // JSPLIT > 1: the column fragments of TN16 / JSPLIT tiles at a time, the row fragments re-read per group (tried for the register-bound variants, round 6: the
+    // compiler keeps MORE registers live that way - 56 instead of 36 spilled dwords in the closing-sum variant - so every launch uses 1)
+    constexpr int TJ = TN16 / JSPLIT;
+    static_assert(TN16 % JSPLIT == 0, "column tiles per group");
 #pragma unroll
-    for (int j = 0; j < TN16; ++j)
+    for (int jg = 0; jg < JSPLIT; ++jg) {
+      bf16x8 fb[TJ][3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        if constexpr (KROWB) fb[j][q] = splitbf::krow_frag<RBB>(Bs + q * b_plane, wc0 + 16 * j, lane);
-        else fb[j][q] = splitbf::rowk_frag(Bs + q * b_plane, wc0 + 16 * j, lane);
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if constexpr (KROWB) fb[j][q] = splitbf::krow_frag<RBB>(Bs + q * b_plane, wc0 + 16 * (jg * TJ + j), lane);
+          else fb[j][q] = splitbf::rowk_frag(Bs + q * b_plane, wc0 + 16 * (jg * TJ + j), lane);
+        }
+#pragma unroll
+      for (int i = 0; i < TM16; ++i) {
+        bf16x8 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if constexpr (KROWA) fa[q] = splitbf::krow_frag<RBA>(As + q * a_plane, wr0 + 16 * i, lane);
+          else fa[q] = splitbf::rowk_frag(As + q * a_plane, wr0 + 16 * i, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          if constexpr (DUAL) splitbf::mma6x2(acc[i][jg * TJ + j], lo[i][jg * TJ + j], fb[j], fa);
+          else splitbf::mma6(acc[i][jg * TJ + j], fb[j], fa);
+        }
       }
-#pragma unroll
-    for (int i = 0; i < TM16; ++i) {
-      bf16x8 fa[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        if constexpr (KROWA) fa[q] = splitbf::krow_frag<RBA>(As + q * a_plane, wr0 + 16 * i, lane);
-        else fa[q] = splitbf::rowk_frag(As + q * a_plane, wr0 + 16 * i, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < TN16; ++j) splitbf::mma6(acc[i][j], lo[i][j], fb[j], fa);
     }
     if constexpr (FLUSH > 0) {
       if ((kt + 1) % FLUSH == 0) {               // uniform
@@ -501,7 +515,7 @@ __device__ __forceinline__ void k_loop_split(int nkt, const unsigned char* As, i
 #pragma unroll
     for (int j = 0; j < TN16; ++j) {
       if constexpr (FLUSH > 0) acc[i][j] = hi[i][j] + acc[i][j];
-      acc[i][j] += lo[i][j];
+      if constexpr (DUAL) acc[i][j] += lo[i][j];
     }
 }
 
@@ -758,16 +772,16 @@ __device__ __forceinline__ void epilogue_vec(const Acc& acc, float* __restrict__
 // (a materialised tensor, or the raw projection-shortcut output with its own BatchNorm affine).  The tensor itself is still needed (next
 // residual add, weight gradient, backward mask), so the workgroups of column tile 0 also store it and its ReLU byte mask: the stand-alone
 // element-wise pass (2 reads + 1 write at the HBM roofline, overlapped with nothing) becomes one extra read and one write inside a convolution.
-template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false, bool S2 = false, bool SP = false>
+template <int BM, int BN, int WGM, int WGN, int BK, bool VEC, int EPI = 0, bool STATS = false, int C4 = 0, bool XF = false, int GATE = 0, int OPM = 0, bool ADDS2 = false, bool S2 = false, int SP = 0>
 // Resident workgroups per CU the variant is compiled for: 3 (they hide each other's barriers, loads and epilogues) wherever the registers allow.
 // The formed-on-load operands carry a second staged stream (ra2) and their per-channel coefficients: 188 - 236 VGPRs, i.e. 2 per CU - except
 // the BatchNorm-backward operand on the 128 x 128 tile, which fits 168 with five spilled dwords in the epilogue (r03 x1: 4 - 5 % faster on the
 // 28x28 layers); the two-target gate (GATE 3) needs 218.  (kernel_resources.py lists every variant; r03_experiments_step_time.txt the A/Bs.)
-// SP (SSV_ARITH_BF16X3, csrc/split_bf16.h; the float4 path only): the same launch on the bf16 matrix pipe - the A operand is split into three bf16 planes while it is
+// SP > 0 (SSV_ARITH_BF16X3, csrc/split_bf16.h; the float4 path only; 1 = one accumulator per tile, 2 = two - see k_loop_split): the same launch on the bf16 matrix pipe - the A operand is split into three bf16 planes while it is
 // staged (after its formed-on-load transform), the weights arrive pre-split (p.w_planes), the main loop is k_loop_split and the accumulators are 16 x 16 tiles; every
 // epilogue is the fp32 variant's.  LDS: 192 bytes per staged row = 48 KB on the 128 x 128 tile (the fp32 image: 36.9 KB); narrow outputs (K < 128) take a 128 x 64
-// tile (36 KB, half the accumulators) where the fp32 variants take 256 x 64.  Two accumulator sets (splitbf::mma6): 2 workgroups per CU on the wide tile.
-__global__ void __launch_bounds__(256, SP ? ((BN == 128 || OPM == 2) ? 2 : 3) : ((OPM == 2 || GATE == 3 || S2 || C4 == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC))) SSV_CONV_ATTR
+// tile (36 KB, half the accumulators) where the fp32 variants take 256 x 64.
+__global__ void __launch_bounds__(256, SP ? ((OPM != 0 || GATE == 3 || (SP == 2 && BN == 128)) ? 2 : 3) : ((OPM == 2 || GATE == 3 || S2 || C4 == 3) ? 2 : (OPM == 1 ? ((BM == 128 && BN == 128) ? 3 : 2) : SSV_CONV_WGPC))) SSV_CONV_ATTR
 conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
            const float* addend, float* y) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -1234,7 +1248,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
       for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[so + (rsub + RPP * i) * LDT + chunk]) = rb[i];
     };
-    if constexpr (SP) k_loop_split<2 * TM, 2 * TN, false, false, 128, 128>(ktiles, Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile, xform_tile);
+    if constexpr (SP) k_loop_split<2 * TM, 2 * TN, false, false, 128, 128, 0, 1, SP == 2>(ktiles, Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile, xform_tile);
     else if constexpr (S2) k_loop2<TM, TN, LDT, BK, AP + BP, STAGE>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile);
     else k_loop<TM, TN, true, true, LDT, LDT, BK, AP + BP + (OPM ? AP + 4 : 0)>(ktiles, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
   } else {
@@ -1309,7 +1323,7 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
         constexpr int GR = TM * 32;
         const int g = rbase / GR;
         const int valid = min(GR, p.M - rbase);
-        epilogue_vec<TM, TN, 0, true>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
+        epilogue_vec<TM, TN, 0, true>(sel_acc<(SP != 0)>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                           [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                           nullptr, nullptr, p.aux_out + (size_t)g * p.K, p.aux_out2 + (size_t)g * p.K, valid > 0 ? valid : 0);
       } else if constexpr (GATE != 0) {
@@ -1327,15 +1341,15 @@ conv_fwd_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ w, c
             if ((ho | wo) & 1u) return -1;
             return ((long long)((int)n * p.add_H2 + (int)(ho >> 1)) * p.add_W2 + (int)(wo >> 1)) * p.K;
           };
-          epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
+          epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<(SP != 0)>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
                                                    nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64), add_off,
                                                    (long long)p.N * p.add_H2 * p.add_W2 * p.K);
         } else {
-          epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
+          epilogue_vec<TM, TN, 0, false, GATE>(sel_acc<(SP != 0)>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K, row_off,
                                                    nullptr, nullptr, nullptr, nullptr, 0, &p.gate, (long long)(rbase / 64));
         }
       } else {
-        epilogue_vec<TM, TN, EPI>(sel_acc<SP>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
+        epilogue_vec<TM, TN, EPI>(sel_acc<(SP != 0)>(acc, acc16), smem + wave * (32 * (TN * 32 + 4)), lane, n0 + wc0, p.K, bias, addend, y, (long long)p.M * p.K,
                                   [&](int r) -> long long { const int m = rbase + r; return m < p.M ? (long long)m * p.K : -1; },
                                   (EPI == 1 || EPI == 4) ? p.aux_out : nullptr, (EPI == 2 || EPI == 5) ? p.aux_in : nullptr);
       }
@@ -1838,7 +1852,7 @@ conv_wgrad_k(ConvKP p, const float* __restrict__ x, const float* __restrict__ dy
       else Bs[(brow + BRP * i) * BN + bcol] = rbs[i];
     }
   };
-  if constexpr (SP) k_loop_split<2 * TM, 2 * TN, true, true, BM * 2, BN * 2, FLUSH>((me - ms + BK - 1) / BK, Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile, xform_tile);
+  if constexpr (SP) k_loop_split<2 * TM, 2 * TN, true, true, BM * 2, BN * 2, FLUSH, 1, true>((me - ms + BK - 1) / BK, Asb, A_PLANE, Bsb, B_PLANE, wr0, wc0, lane, acc16, load_tile, store_tile, xform_tile);
   else k_loop<TM, TN, false, false, BM, BN, BK, (VECB ? AP + BP + (DYF ? AP : 0) : 0), FLUSH>((me - ms + BK - 1) / BK, As, Bs, wr0, wc0, lane, acc, load_tile, store_tile, xform_tile);
 
   if constexpr (BIAS) {
@@ -1983,6 +1997,14 @@ namespace {
 inline bool sp_fwd_ok(const ssv_conv_desc* d, int groups = 0) {
   return d->arithmetic == SSV_ARITH_BF16X3 && d->w_planes != nullptr && (((uintptr_t)d->w_planes) & 15) == 0 && d->C % 32 == 0 && d->K % 4 == 0;
 }
+// ... and with how many accumulators per tile: one up to a contraction of SP_DUAL_FROM products per output, two beyond (a property of the LAYER - every fused and
+// unfused variant of a layer takes the same form, so they stay bit-identical).  Measured on the 53 ResNet-50 layers (tests/test_gpu_split.py): with one accumulator
+// the error against fp64 is 0.8-1.0x the fp32-MFMA kernel's up to a contraction of 1,152 and 1.05-1.07x from 2,048 on.
+constexpr int SP_DUAL_FROM = 1152;
+inline int sp_fwd_mode(const ssv_conv_desc* d, int groups = 0) {
+  if (!sp_fwd_ok(d, groups)) return 0;
+  return (int64_t)d->R * d->S * d->C > SP_DUAL_FROM ? 2 : 1;
+}
 // the strided data-gradient kernel: its 128 x 128 tile (C >= 128), whole 32-channel k-tiles of the output channels, the weights pre-split
 inline bool sp_dgrad_ok(const ssv_conv_desc* d) {
   return d->arithmetic == SSV_ARITH_BF16X3 && d->w_planes != nullptr && (((uintptr_t)d->w_planes) & 15) == 0 && d->K % 32 == 0 && d->C >= 128 && d->C % 8 == 0;
@@ -2000,7 +2022,7 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   p.aux_out = pmean; p.aux_out2 = pm2; p.xf_scale = in_scale; p.xf_shift = in_shift;
   if (groups > 1) { p.Cg = d->C / groups; p.Kg = d->K / groups; }
   const bool stats = pmean != nullptr, xf = in_scale != nullptr;
-  const bool sp = sp_fwd_ok(d, groups);
+  const int sp = sp_fwd_mode(d, groups);
   const bool wide = d->K >= 128 && groups <= 1;               // block-diagonal banks: the 64-column tile sees the fewest foreign groups
   // (1x1 layers with few k-tiles - 64 -> 256 at 56x56 runs at 2.7 TB/s and 69 TFLOP/s, the SUM of its MFMA and HBM times - were tried on a 128 x 64 tile
   //  at 4 / 5 workgroups per CU, on a 64 x 256 tile writing whole 1 KB rows and as a persistent kernel that loads its next tile under the epilogue: no change, r03 x3)
@@ -2025,12 +2047,13 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
 #endif
 #define FWDG_(BM_, BN_, WM_, WN_, G_, SP_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 0, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWDG(BM_, BN_, WM_, WN_, G_) FWDG_(BM_, BN_, WM_, WN_, G_, false)
-#define FWDG_TILE(G_) do { if (sp) { if (wide) FWDG_(128, 128, 2, 2, G_, true); else FWDG_(128, 64, 2, 2, G_, true); } \
+#define FWDG(BM_, BN_, WM_, WN_, G_) FWDG_(BM_, BN_, WM_, WN_, G_, 0)
+#define FWDG_TILE(G_) do { if (sp == 2) { if (wide) FWDG_(128, 128, 2, 2, G_, 2); else FWDG_(128, 64, 2, 2, G_, 2); } \
+                           else if (sp) { if (wide) FWDG_(128, 128, 2, 2, G_, 1); else FWDG_(128, 64, 2, 2, G_, 1); } \
                            else    { if (wide) FWDG(128, 128, 2, 2, G_); else FWDG(256, 64, 4, 1, G_); } } while (0)
     if (add_H2 > 0) {                                          // compact stride-2 addend: wide tile, byte-mask gates (checked by the caller)
 #define FWDGS_(G_, SP_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 0, true, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWDGS(G_) do { if (sp) FWDGS_(G_, true); else FWDGS_(G_, false); } while (0)
+#define FWDGS(G_) do { if (sp == 2) FWDGS_(G_, 2); else if (sp) FWDGS_(G_, 1); else FWDGS_(G_, 0); } while (0)
       if (gate->x2) FWDGS(3); else FWDGS(2);
 #undef FWDGS
 #undef FWDGS_
@@ -2042,11 +2065,12 @@ int launch_fwd(const ssv_conv_desc* d, const float* x, const float* w, const flo
   }
 #define FWD_(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_, SP_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, BK_, true, false, ST_, C4_, XF_, 0, 0, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, addend, y)
-#define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) FWD_(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_, false)
+#define FWD(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_) FWD_(BM_, BN_, WM_, WN_, BK_, ST_, C4_, XF_, 0)
 // the float4 path with K-step 32: either arithmetic
 #define FWD_TILE_A(ST_, XF_) do { \
-    if (sp) { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, true); else FWD_(128, 64, 2, 2, 32, ST_, 0, XF_, true); } \
-    else    { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, false); else FWD_(256, 64, 4, 1, 32, ST_, 0, XF_, false); } } while (0)
+    if (sp == 2) { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, 2); else FWD_(128, 64, 2, 2, 32, ST_, 0, XF_, 2); } \
+    else if (sp) { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, 1); else FWD_(128, 64, 2, 2, 32, ST_, 0, XF_, 1); } \
+    else    { if (wide) FWD_(128, 128, 2, 2, 32, ST_, 0, XF_, 0); else FWD_(256, 64, 4, 1, 32, ST_, 0, XF_, 0); } } while (0)
 #define FWD_TILE(BK_, ST_, C4_, XF_) do { if (wide) FWD(128, 128, 2, 2, BK_, ST_, C4_, XF_); else FWD(256, 64, 4, 1, BK_, ST_, C4_, XF_); } while (0)
 #ifdef SSV_EXP_HALO
   if (halo) {
@@ -2193,17 +2217,18 @@ int fwd_dyin_impl(const ssv_conv_desc* d, const float* g, const ssv_bn_dyin* dyi
   p.add_H2 = add_H2; p.add_W2 = add_W2;
   if (gate) p.gate = *gate;
   const bool wide = d->K >= 128;
-  const bool sp = sp_fwd_ok(d);
+  const int sp = sp_fwd_mode(d);
   const unsigned grid = (unsigned)(wide ? cdiv(p.M, 128) * cdiv(d->K, 128) : (sp ? cdiv(p.M, 128) : cdiv(p.M, 256)) * cdiv(d->K, 64));
   const int gm = gate ? (gate->x2 ? 3 : (gate->mask ? 2 : 1)) : 0;
 #define FWDD_(BM_, BN_, WM_, WN_, G_, SP_) \
   hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, false, false, false, G_, 1, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
-#define FWDD(BM_, BN_, WM_, WN_, G_) FWDD_(BM_, BN_, WM_, WN_, G_, false)
-#define FWDD_TILE(G_) do { if (sp) { if (wide) FWDD_(128, 128, 2, 2, G_, true); else FWDD_(128, 64, 2, 2, G_, true); } \
+#define FWDD(BM_, BN_, WM_, WN_, G_) FWDD_(BM_, BN_, WM_, WN_, G_, 0)
+#define FWDD_TILE(G_) do { if (sp == 2) { if (wide) FWDD_(128, 128, 2, 2, G_, 2); else FWDD_(128, 64, 2, 2, G_, 2); } \
+                           else if (sp) { if (wide) FWDD_(128, 128, 2, 2, G_, 1); else FWDD_(128, 64, 2, 2, G_, 1); } \
                            else    { if (wide) FWDD(128, 128, 2, 2, G_); else FWDD(256, 64, 4, 1, G_); } } while (0)
   if (add_H2 > 0) {                                          // compact stride-2 addend: wide tile and byte-mask gate checked by the caller
 #define FWDDS_(G_, SP_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, G_, 1, true, false, SP_>), dim3(grid), dim3(256), 0, s, p, g, w, (const float*)nullptr, addend, y)
-#define FWDDS(G_) do { if (sp) FWDDS_(G_, true); else FWDDS_(G_, false); } while (0)
+#define FWDDS(G_) do { if (sp == 2) FWDDS_(G_, 2); else if (sp) FWDDS_(G_, 1); else FWDDS_(G_, 0); } while (0)
     if (gm == 3) FWDDS(3); else FWDDS(2);
 #undef FWDDS
 #undef FWDDS_
@@ -2250,11 +2275,12 @@ extern "C" int ssv_conv2d_fwd_sumin_stats(const ssv_conv_desc* d, const float* x
   // (a 128 x 64 tile with K-step 64 - 256-byte row pieces - is 6 % faster for the 256 -> 64 conv1 of the 56x56 stage, r03 x1, but its statistics
   // epilogue sums each 64-row group in another order: the forward would no longer be bit-identical to bn_apply + conv2d_fwd_stats.  Not taken.)
   const bool wide = d->K >= 128;
-  const bool sp = sp_fwd_ok(d);
+  const int sp = sp_fwd_mode(d);
   const unsigned grid = wide ? (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128)) : (unsigned)((sp ? cdiv(p.M, 128) : cdiv(p.M, 256)) * cdiv(d->K, 64));
 #define FWDS(BM_, BN_, WM_, WN_, SP_) hipLaunchKernelGGL((conv_fwd_k<BM_, BN_, WM_, WN_, 32, true, false, true, false, false, 0, 2, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, (const float*)nullptr, (const float*)nullptr, y)
-  if (sp) { if (wide) FWDS(128, 128, 2, 2, true); else FWDS(128, 64, 2, 2, true); }
-  else    { if (wide) FWDS(128, 128, 2, 2, false); else FWDS(256, 64, 4, 1, false); }
+  if (sp == 2) { if (wide) FWDS(128, 128, 2, 2, 2); else FWDS(128, 64, 2, 2, 2); }
+  else if (sp) { if (wide) FWDS(128, 128, 2, 2, 1); else FWDS(128, 64, 2, 2, 1); }
+  else    { if (wide) FWDS(128, 128, 2, 2, 0); else FWDS(256, 64, 4, 1, 0); }
 #undef FWDS
   SSV_CHECK_LAUNCH("ssv_conv2d_fwd_sumin_stats");
   return SSV_OK;
@@ -2308,8 +2334,10 @@ extern "C" int ssv_linear_gelu_fwd(const ssv_conv_desc* d, const float* x, const
   } else
 #endif
 #define FWDE(E_, SP_, OUT_) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, E_, false, 0, false, 0, 0, false, false, SP_>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, OUT_)
-  if (sp_fwd_ok(d)) { if (h) FWDE(1, true, h); else FWDE(3, true, act); }
-  else              { if (h) FWDE(1, false, h); else FWDE(3, false, act); }
+  const int sp = sp_fwd_mode(d);
+  if (sp == 2)  { if (h) FWDE(1, 2, h); else FWDE(3, 2, act); }
+  else if (sp)  { if (h) FWDE(1, 1, h); else FWDE(3, 1, act); }
+  else          { if (h) FWDE(1, 0, h); else FWDE(3, 0, act); }
 #undef FWDE
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd");
   return SSV_OK;
@@ -2353,7 +2381,8 @@ extern "C" int ssv_linear_fwd_gelugrad(const ssv_conv_desc* d, const float* dy, 
     hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   else
 #endif
-  if (sp_fwd_ok(d)) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  if (sp_fwd_mode(d) == 2) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, false, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  else if (sp_fwd_mode(d) == 1) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2, false, 0, false, 0, 0, false, false, 1>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   else hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   SSV_CHECK_LAUNCH("ssv_linear_fwd_gelugrad");
   return SSV_OK;
@@ -2371,7 +2400,8 @@ extern "C" int ssv_linear_gelu_fwd_dact(const ssv_conv_desc* d, const float* x, 
   ConvKP p = make_kp(d);
   p.aux_out = act;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-  if (sp_fwd_ok(d)) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4, false, 0, false, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
+  if (sp_fwd_mode(d) == 2) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4, false, 0, false, 0, 0, false, false, 2>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
+  else if (sp_fwd_mode(d) == 1) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4, false, 0, false, 0, 0, false, false, 1>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
   else hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 4>), dim3(grid), dim3(256), 0, s, p, x, w, bias, (const float*)nullptr, dact);
   SSV_CHECK_LAUNCH("ssv_linear_gelu_fwd_dact");
   return SSV_OK;
@@ -2389,7 +2419,8 @@ extern "C" int ssv_linear_fwd_mulgrad(const ssv_conv_desc* d, const float* dy, c
   ConvKP p = make_kp(d);
   p.aux_in = dact;
   const unsigned grid = (unsigned)(cdiv(p.M, 128) * cdiv(d->K, 128));
-  if (sp_fwd_ok(d)) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5, false, 0, false, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  if (sp_fwd_mode(d) == 2) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5, false, 0, false, 0, 0, false, false, 2>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
+  else if (sp_fwd_mode(d) == 1) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5, false, 0, false, 0, 0, false, false, 1>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   else hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, 5>), dim3(grid), dim3(256), 0, s, p, dy, wt, (const float*)nullptr, addend, dh);
   SSV_CHECK_LAUNCH("ssv_linear_fwd_mulgrad");
   return SSV_OK;
@@ -2990,8 +3021,10 @@ extern "C" int ssv_gemm_batched_split(int32_t batch, int64_t rows, int32_t C, in
   const bool wide = K >= 128;
   const dim3 grid((unsigned)(cdiv(p.M, 128) * cdiv(K, wide ? 128 : 64)), (unsigned)batch);
   const float* w = nullptr;
-  if (wide) hipLaunchKernelGGL((conv_fwd_k<128, 128, 2, 2, 32, true, false, false, false, false, 0, 0, false, false, true>), grid, dim3(256), 0, s, p, a, w, bias, addend, y);
-  else      hipLaunchKernelGGL((conv_fwd_k<128, 64, 2, 2, 32, true, false, false, false, false, 0, 0, false, false, true>), grid, dim3(256), 0, s, p, a, w, bias, addend, y);
+#define BSP(BN_, SP_) hipLaunchKernelGGL((conv_fwd_k<128, BN_, 2, 2, 32, true, false, false, false, false, 0, 0, false, false, SP_>), grid, dim3(256), 0, s, p, a, w, bias, addend, y)
+  if (C > SP_DUAL_FROM) { if (wide) BSP(128, 2); else BSP(64, 2); }
+  else                  { if (wide) BSP(128, 1); else BSP(64, 1); }
+#undef BSP
   SSV_CHECK_LAUNCH("ssv_gemm_batched_split");
   return SSV_OK;
 }

@@ -5,8 +5,7 @@
 //   a * b = sum of ai * bj.  Every ai * bj is exact (8 x 8 bits) and summed in fp32 by v_mfma_f32_16x16x32_bf16, which folds 32 products per accumulator
 //   rounding (v_mfma_f32_32x32x2_f32 folds 2).  SIX of the nine terms are kept - a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 - what is dropped (a1b2, a2b1, a2b2) is
 //   <= 2^-23 |a b| in the worst case and ~2^-27 rms - below ONE fp32 rounding of the product.  Measured against fp64 the 6-term and the 9-term product have the
-//   same error; with the small terms in an accumulator of their own (mma6 below) it is 2.5-3x BELOW the fp32-MFMA kernel's on every product shape of the
-//   networks (tests/test_gpu_split.py; tools/probe/gemm_split_tuned_probe.hip).
+//   same error: at or below the fp32-MFMA kernel's on every product shape of the networks (mma6 / mma6x2 below; tests/test_gpu_split.py).
 //
 // Edge magnitudes (decided, tested in tests/test_gpu_split.py::test_edge_magnitudes):
 //   * +-0 split to (+-0, 0, 0): products with zero are exact zeros.
@@ -110,15 +109,24 @@ __device__ __forceinline__ bf16x8 krow_frag(const unsigned char* plane, int ch0,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// ---- the six piece products of one (output-row fragment, output-column fragment) pair -------------------------------------------------------------------
-// TWO accumulators per 16 x 16 tile: `acc` takes a0b0 - ONE accumulator rounding per 32 products at the magnitude of the running sum - and `lo` the five small
-// terms (<= 2^-8 of a0b0 each: their roundings are 2^-8 of an ulp of the result); the epilogue adds the two.  Measured (tools/probe/gemm_split_tuned_probe.hip,
-// profiles/r06_probe_split_accmode.txt): with all six terms in one accumulator the error against fp64 is set by that accumulator's six roundings per 32 products
-// and sits just under the fp32-MFMA kernel's (9.9e-7 vs 1.15e-6 at a contraction of 4,096; 12 % OVER it on one weight-gradient shape) - nine terms or another term
-// order change nothing; with the second accumulator it is 2.5-3x lower on every shape (3.9e-7 at 4,096; 4.0e-8 vs 8.3e-8 at 64).
-// Both are 16 x 16 tiles with the COLUMN operand as the instruction's A: lane l then holds output row (l & 15) and the four consecutive output columns
-// 4 (l >> 4) .. + 3 - 16-byte pieces of whole output rows for the epilogue.
-__device__ __forceinline__ void mma6(f32x4& acc, f32x4& lo, const bf16x8 (&col)[3], const bf16x8 (&row)[3]) {
+// ---- the six piece products of one (output-row fragment, output-column fragment) pair and k-tile ---------------------------------------------------------
+// Two forms, chosen per product KIND (never per fused variant: the fused and unfused forms of one layer stay bit-identical):
+//   mma6   - all six terms into the running 16 x 16 accumulator, smallest first.  The accumulator takes six roundings per 32 products and those set the error: it sits
+//            10-13 % UNDER the fp32-MFMA kernel's on forward-shaped products (9.9e-7 vs 1.15e-6 at a contraction of 4,096), but 12 % OVER it on a weight-gradient
+//            shape.  64 accumulator registers per lane on the 128 x 128 tile: three workgroups per CU.  Forward and data-gradient launches.
+//   mma6x2 - a0b0 into the running accumulator (ONE rounding per 32 products at the running sum's magnitude) and the five small terms (<= 2^-8 of a0b0 each) into a
+//            second one, added in the epilogue: 2.5-3x lower error (3.9e-7 at 4,096), 64 more registers - two workgroups per CU, 12-19 % slower per launch.
+//            Weight gradients (their contraction runs over ~10^5 pixels in chunks).
+// Measured: tools/probe/gemm_split_tuned_probe.hip, profiles/r06_probe_split_accmode.txt, r06_probe_split_prefetch.txt.  A third form - the six products summed in a
+// fresh tile that the vector unit adds to the accumulator - has mma6x2's error but the compiler keeps all 16 fresh tiles live (117-161 spilled dwords): not shipped.
+// Every tile has the COLUMN operand as the instruction's A: lane l then holds output row (l & 15) and the four consecutive output columns 4 (l >> 4) .. + 3 -
+// 16-byte pieces of whole output rows for the epilogue.
+__device__ __forceinline__ void mma6(f32x4& acc, const bf16x8 (&col)[3], const bf16x8 (&row)[3]) {
+#define SSV_MM(P, Q) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col[P], row[Q], acc, 0, 0, 0)
+  SSV_MM(2, 0); SSV_MM(0, 2); SSV_MM(1, 1); SSV_MM(1, 0); SSV_MM(0, 1); SSV_MM(0, 0);
+#undef SSV_MM
+}
+__device__ __forceinline__ void mma6x2(f32x4& acc, f32x4& lo, const bf16x8 (&col)[3], const bf16x8 (&row)[3]) {
 #define SSV_ML(P, Q) lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col[P], row[Q], lo, 0, 0, 0)
   SSV_ML(2, 0); SSV_ML(0, 2); SSV_ML(1, 1); SSV_ML(1, 0); SSV_ML(0, 1);
 #undef SSV_ML

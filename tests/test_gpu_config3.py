@@ -164,7 +164,12 @@ def _check_against_fp64(flat, g32, g64, dz_hip, dz32, dz64):
     for got, c32, c64 in zip(dz_hip, dz32, dz64):
         assert _rel(got.cpu(), c64) <= 3 * _rel(c32, c64) + 1e-6, (_rel(got.cpu(), c64), _rel(c32, c64))
     e_hip, e_cpu = _arena_vs_params(flat, g64, g32)
-    assert max(e_hip[-4:]) <= 3 * max(e_cpu[-4:]) + 1e-5, f"projector tail: hip {max(e_hip[-4:]):.2e}, cpu fp32 {max(e_cpu[-4:]):.2e}"
+    # the tensors with NO ReLU decision in their gradient: fc2.weight, bn2.weight, bn2.bias (behind the head's ReLU) and bn1.weight (a flipped element has x_hat ~ 0, so it
+    # drops out of sum g * x_hat).  bn1.BIAS is not one of them - its gradient is sum g * mask, and one flipped element of 16 rows moves it by ~1e-3 (rounds 3-5 took the
+    # last FOUR tensors, bn1.bias among them: green only while no hidden unit of this batch sat within rounding of zero; round 6's arithmetic flips one).
+    # Order of the non-zero-gradient tail: ..., fc1.weight, bn1.weight, bn1.bias, fc2.weight, bn2.weight, bn2.bias
+    tail = (-5, -3, -2, -1)
+    assert max(e_hip[i] for i in tail) <= 3 * max(e_cpu[i] for i in tail) + 1e-5, f"projector tail: hip {[e_hip[i] for i in tail]}, cpu fp32 {[e_cpu[i] for i in tail]}"
     assert max(e_hip) < 5e-2, f"worst per-tensor gradient error {max(e_hip):.2e} (flip size at this batch: ~1e-2)"
 
 

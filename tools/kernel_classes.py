@@ -41,7 +41,7 @@ def is_bf16x3(name):
     if not m:
         return False
     args = [a.strip() for a in m.group(2).split(",")]
-    return len(args) == _SP_ARGS[m.group(1)] and args[-1] == "true"
+    return len(args) == _SP_ARGS[m.group(1)] and args[-1] in ("true", "1", "2")        # conv_fwd_k: 1 = one accumulator per tile, 2 = two (long contractions)
 
 
 def classify(name):

@@ -55,7 +55,7 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2 (&pl)[3]) {
   }
 }
 
-template <int BM, int BN, int BK, int NSTAGE, bool M16, int WGPC, bool NOSPLIT, int ACCM = 0>
+template <int BM, int BN, int BK, int NSTAGE, bool M16, int WGPC, bool NOSPLIT, int ACCM = 0, int PF = 1>
 __global__ void __launch_bounds__(256, WGPC)
 ksplit(int rows, int C, int K, int tiles_n, const float* __restrict__ A, const unsigned short* __restrict__ Wp, float* __restrict__ Y,
        long long bsA, long long bsW, long long bsY) {
@@ -93,7 +93,7 @@ ksplit(int rows, int C, int K, int tiles_n, const float* __restrict__ A, const u
     boff[i] = (n0 + row < K) ? ((n0 + row) * C + k8 * 8) * 2 : OOB_OFF;
     blds[i] = row * ROWB + ((k8 ^ swz<BK, M16>(row)) << 4);
   }
-  u32x4 ra[AP], rb[3][BP];
+  u32x4 ra[AP], rb[3][BP], ra2[PF == 2 ? AP : 1], rb2[PF == 2 ? 3 : 1][BP];      // PF 2: a second register stage, loads issued TWO k-tiles ahead
   const int plane_bytes = K * C * 2;
   auto load_tile = [&](int kt) {
 #pragma unroll
@@ -172,7 +172,36 @@ ksplit(int rows, int C, int K, int tiles_n, const float* __restrict__ A, const u
   };
 
   const int nkt = C / BK;
-  if constexpr (NSTAGE == 1) {
+  if constexpr (NSTAGE == 1 && PF == 2) {
+    auto load2 = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) ra2[i] = bload4(ra_, aoff[i], kt * BK * 4);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < BP; ++i) rb2[q][i] = bload4(rw_, boff[i] == OOB_OFF ? OOB_OFF : boff[i] + q * plane_bytes, kt * BK * 2);
+    };
+    auto swap_in = [&]() {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) ra[i] = ra2[i];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < BP; ++i) rb[q][i] = rb2[q][i];
+    };
+    load_tile(0);
+    store_tile(0);
+    load_tile(1);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      load2(kt + 2);                            // two tiles ahead: a tile's bytes are in flight for two k-tiles of MFMAs
+      mma_tile(0);
+      __syncthreads();
+      store_tile(0);                            // tile kt + 1 (loaded one iteration ago)
+      swap_in();
+      __syncthreads();
+    }
+  } else if constexpr (NSTAGE == 1) {
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -352,6 +381,10 @@ int main(int argc, char** argv) {
       RUN("128x128x32 16x16x32 wgpc2, 2 accumulators", 128, 128, 32, 1, true, 2, false, 1);
       RUN("128x128x32 16x16x32 wgpc2, 9 terms", 128, 128, 32, 1, true, 2, false, 3);
       RUN("256x128x32 16x16x32 wgpc1, 2 accumulators", 256, 128, 32, 1, true, 1, false, 1);
+      RUN("128x128x32 2 acc, loads 2 tiles ahead, wgpc2", 128, 128, 32, 1, true, 2, false, 1, 2);
+      RUN("128x128x32 1 acc, wgpc3", 128, 128, 32, 1, true, 3, false, 0);
+      RUN("128x128x32 1 acc, loads 2 tiles ahead, wgpc3", 128, 128, 32, 1, true, 3, false, 0, 2);
+      RUN("128x128x32 1 acc, loads 2 tiles ahead, wgpc2", 128, 128, 32, 1, true, 2, false, 0, 2);
     } else {
     RUN("128x128x32 1-stage 32x32x16 wgpc2", 128, 128, 32, 1, false, 2, false);
     RUN("128x128x32 1-stage 32x32x16 wgpc3", 128, 128, 32, 1, false, 3, false);

@@ -10,8 +10,8 @@ set -u
 TAG=$1; shift
 OUT=gpurun_out
 export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --prof-steps 0 $*"
-PMCARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --prof-steps 0 $*"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-arith-legs --prof-steps 0 $*"
+PMCARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-arith-legs --prof-steps 0 $*"
 stats() {   # $1 = name, env SSV_SINGLE_STREAM inherited
   rm -rf $OUT/_prof_$1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof_$1 -- python3 $ARGS > $OUT/_prof_$1.log 2>&1
