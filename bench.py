@@ -31,9 +31,9 @@ import torch  # noqa: E402
 # rocprofv3 --pmc passes aggregated by tools/pmc_traffic.py / tools/pmc_mfma.py (tools/profile_step.sh) and the per-layer operand-stream table of
 # tools/bench_conv.py.  Each file records the build it was measured on (src_sha16 = ssv_source_sha16() of the profiled library); counters of another
 # build are NOT replayed: the line then carries traffic: null and counters_stale: true.
-PMC_FILES = {"simclr": "r05_simclr_b%d_pmc_hbm_traffic.json", "dino": "r05_dino_b%d_pmc_hbm_traffic.json"}
-CONV_LAYER_FILE = "r05_conv_layers_b%d.csv"
-PMC_MFMA_FILES = {"simclr": "r05_simclr_b%d_pmc_mfma.json", "dino": "r05_dino_b%d_pmc_mfma.json"}
+PMC_FILES = {"simclr": "r06_simclr_b%d_pmc_hbm_traffic.json", "dino": "r06_dino_b%d_pmc_hbm_traffic.json"}
+CONV_LAYER_FILE = "r06_conv_layers_b%d.csv"
+PMC_MFMA_FILES = {"simclr": "r06_simclr_b%d_pmc_mfma.json", "dino": "r06_dino_b%d_pmc_mfma.json"}
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity headline)
 BF16X3_TERMS = 6                     # bf16 piece products per fp32 product in the shipped arithmetic (csrc/split_bf16.h)
@@ -963,12 +963,25 @@ def main():
                 mfma = dict(mfma["summary"], source=used["mfma"])
         # operand streams of the conv family in the variants the step launches (the fused BatchNorm operands - shortcut, BatchNorm input, gate
         # operands, the written activation - are streams of these kernels now): per view from tools/bench_conv.py's per-layer model, x 2 views
-        family_gb, family_src = None, None
+        family_gb, family_src, traffic_ratios = None, None, None
         if args.algo == "simclr":
             layer_rows = committed(CONV_LAYER_FILE % b, "layers")
             if layer_rows is not None:
-                tot = [r for r in layer_rows if r["layer"].startswith("TOTAL")]
-                family_gb, family_src = round(2 * sum(float(r["fwd_GB"]) for r in tot), 1), used["layers"]
+                tot = {r["layer"].split()[1]: 2 * float(r["fwd_GB"]) for r in layer_rows if r["layer"].startswith("TOTAL")}       # per product, two views
+                family_gb, family_src = round(sum(tot.values()), 1), used["layers"]
+                if pmc is not None:
+                    # counted (PMC) next to algorithmic (every operand stream of the launched variant once) per kernel class.  The forward-kernel class also runs the
+                    # stride-1 data gradients (forward kernel on the transposed filter) and the Winograd input / output transforms; the data-gradient class the strided
+                    # kernel and the gated Winograd output transforms: the two are priced together.  The transformed-domain tensors of the Winograd layers (V, M, the
+                    # transformed gradients) are counted bytes that the algorithmic figure does not have - the bytes the 2.25-4x fewer multiplies are bought with.
+                    cnt = lambda *ks: sum(pmc[k]["fetch"] + pmc[k]["write"] for k in ks if k in pmc)
+                    pairs = {"conv_fwd+conv_dgrad": (cnt("conv_fwd", "conv_dgrad"), tot.get("fwd", 0.0) + tot.get("dgrad", 0.0)), "conv_wgrad": (cnt("conv_wgrad"), tot.get("wgrad", 0.0))}
+                    traffic_ratios = {k: {"counted_gb": round(c, 1), "algorithmic_gb": round(a, 1), "ratio": round(c / a, 3) if a else None} for k, (c, a) in pairs.items()}
+                    for k in ("bn_fwd", "bn_bwd", "aug", "pool", "optim", "loss", "misc"):
+                        if k in pmc:
+                            traffic_ratios[k] = {"counted_gb": round(pmc[k]["fetch"] + pmc[k]["write"], 1), "algorithmic_gb": None,
+                                                 "note": "streaming passes: every byte counted is a byte the pass exists to move (their algorithmic figure is 0 once fused away)"}
+                    traffic_ratios["whole_step"] = {"counted_gb": whole_traffic, "survey_8d_streaming_model_gb": round(1.067 * b, 1), "ratio": round(whole_traffic / (1.067 * b), 3)}
         attn_ms = prof.get("attn", (0.0, 0))[0] / args.prof_steps
         from ssv_amd import ops as _ops
         bf = _ops.ARITHMETIC == "bf16x3"
@@ -998,6 +1011,7 @@ def main():
                                         "DESIGN 4.4) are in `traffic` but NOT in this figure" % family_src) if family_gb is not None
                                        else "conv operands only (x, w, y once per product): the fused BatchNorm streams these kernels also carry are NOT in this figure",
                 "conv_operands_only_gb_per_step": None if algo_bytes_step is None else round(algo_bytes_step / 1e9, 1),
+                "traffic_ratios": traffic_ratios,
                 # whole step: PMC traffic of ALL kernels against SURVEY 8(d)'s streaming model (1.067 GB / sample: 12 fp32 accesses per conv-output element)
                 "whole_step_traffic_gb": whole_traffic,
                 "whole_step_algorithmic_gb": round(1.067 * b, 1) if args.algo == "simclr" else None,

@@ -1964,6 +1964,9 @@ WgradPlan plan_wgrad(const ssv_conv_desc* d, int groups = 0) {
   const bool bd = groups > 1 && d->C % 64 == 0;     // block-diagonal bank: 64 x 64 tiles, of which only those a group touches do any work
   w.bm = (d->K >= 128 && !bd) ? 128 : 64;
   w.bn = (RSC <= 64 || bd) ? 64 : 128;      // 1x1 convs on 64 channels: a 128-wide tile would be half empty
+#ifdef SSV_EXP_WGRAD_BN64                   // diagnostic builds only (round 6): the bf16x3 weight gradient on 128 x 64 tiles (half the accumulator registers: 3-4 workgroups per CU)
+  if (d->arithmetic == SSV_ARITH_BF16X3 && w.bm == 128) w.bn = 64;
+#endif
   w.it = cdiv(d->K, w.bm);
   w.jt = cdiv(RSC, w.bn);
   int tiles = w.it * w.jt;
