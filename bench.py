@@ -80,32 +80,52 @@ def arithmetic_block(device):
 
 def eval_knn_leg(device, n=50000, d=128, k=20, reps=3):
     """The reference's kNN evaluation (utils/eval_utils.py:13-21: compute_neighbor_accuracy, k + 1 exact inner-product hits, best dropped) at CIFAR-10's train-set
-    size on projected features of BASELINE's width: one ssv_knn_label_agreement call = the Gram product Z Z^T in row chunks on the GEMM kernel + the streaming top-(k+1)
-    selection over each chunk of S.  Wall time per call, and the two parts from HIP events per launch (the library's profiling scopes)."""
+    size on projected features of BASELINE's width.  Shipped: ONE fused launch (csrc/evalknn.hip knn_fused_k: the Gram product Z Z^T on the bf16x3 arithmetic with a
+    streaming top-21 per query on its accumulators - S is never written) + a merge of the column parts.  Beside it, in the same run, the round-3..5 form
+    (SSV_ARITHMETIC=f32: Gram in row chunks on the fp32-MFMA GEMM kernel, S written and read back by a one-wavefront-per-query selection).  Wall time per call; kernel
+    parts from HIP events per launch (the library's profiling scopes)."""
     from ssv_amd import _lib, ops
     g = torch.Generator(device=device).manual_seed(n)
     z = torch.nn.functional.normalize(torch.randn(n, d, device=device, generator=g), dim=1)
     labels = torch.randint(0, 10, (n,), device=device, generator=g, dtype=torch.int32)
-    count = ops.knn_label_agreement(z, labels, k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+
+    def timed():
         count = ops.knn_label_agreement(z, labels, k)
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    _lib.prof_enable(True)
-    _lib.prof_reset()
-    ops.knn_label_agreement(z, labels, k)
-    torch.cuda.synchronize()
-    prof = _lib.prof_collect()
-    _lib.prof_enable(False)
-    gram_ms, sel_ms = prof["conv_fwd"][0], prof["misc"][0]
-    return {"workload": f"compute_neighbor_accuracy on {n} x {d} unit features, k = {k} (CIFAR-10 train set, proj_dim 128)", "ms_per_call": round(ms, 3),
-            "queries_per_sec": round(n / ms * 1e3, 1), "agreement": round(count / (n * k), 5),
-            "gram": {"ms": round(gram_ms, 3), "algorithmic_gflop": round(2.0 * n * n * d / 1e9, 1), "tflops": round(2.0 * n * n * d / gram_ms / 1e9, 1),
-                     "arithmetic": "fp32 MFMA (exact inner products: integer-valued features count bit-exactly)", "s_written_gb": round(4.0 * n * n / 1e9, 2)},
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            count = ops.knn_label_agreement(z, labels, k)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        ops.knn_label_agreement(z, labels, k)
+        torch.cuda.synchronize()
+        prof = _lib.prof_collect()
+        _lib.prof_enable(False)
+        return count, ms, prof
+
+    gflop = 2.0 * n * n * d / 1e9
+    count, ms, prof = timed()
+    fused = ops.ARITHMETIC == "bf16x3"
+    kern_ms = prof["misc"][0] + prof["conv_fwd"][0]
+    out = {"workload": f"compute_neighbor_accuracy on {n} x {d} unit features, k = {k} (CIFAR-10 train set, proj_dim 128)", "ms_per_call": round(ms, 3),
+           "queries_per_sec": round(n / ms * 1e3, 1), "agreement": round(count / (n * k), 5), "arithmetic": ops.ARITHMETIC,
+           "form": "fused Gram + top-21 (S never written)" if fused else "Gram on the GEMM kernel, S written, one-wavefront-per-query selection",
+           "kernel_ms": round(kern_ms, 3), "algorithmic_gflop": round(gflop, 1), "tflops": round(gflop / kern_ms, 1),
+           "roof_tflops": BF16X3_PEAK_TFLOPS if fused else FP32_MFMA_PEAK_TFLOPS, "frac": round(gflop / kern_ms / (BF16X3_PEAK_TFLOPS if fused else FP32_MFMA_PEAK_TFLOPS), 3),
+           "timing": "wall clock over %d calls; kernel_ms: HIP events per launch of one more call" % reps}
+    if fused:
+        with ops.arithmetic("f32"):
+            count0, ms0, prof0 = timed()
+        gram_ms, sel_ms = prof0["conv_fwd"][0], prof0["misc"][0]
+        out["unfused_fp32_path"] = {
+            "ms_per_call": round(ms0, 3), "agreement": round(count0 / (n * k), 5),
+            "gram": {"ms": round(gram_ms, 3), "tflops": round(gflop / gram_ms, 1), "s_written_gb": round(4.0 * n * n / 1e9, 2)},
             "selection": {"ms": round(sel_ms, 3), "s_read_gb": round(4.0 * n * n / 1e9, 2), "gb_per_s": round(4.0 * n * n / sel_ms / 1e6, 1), "hbm_roof_gb_per_s": 6290.0,
-                          "frac": round(4.0 * n * n / sel_ms / 1e6 / 6290.0, 3)},
-            "timing": "wall clock over %d calls; parts: HIP events per launch of one more call" % reps}
+                          "frac": round(4.0 * n * n / sel_ms / 1e6 / 6290.0, 3)}}
+        out["speedup_vs_unfused"] = round(ms0 / ms, 2)
+        out["count_difference_vs_unfused"] = int(count - count0)
+    return out
 
 
 def fp32_instruction_leg(step, b, world, warmup=2, steps=6):

@@ -465,6 +465,11 @@ int ssv_center_view(int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo, c
 size_t ssv_knn_workspace_bytes(int64_t n);
 int ssv_knn_label_agreement(int64_t n, int32_t d, const float* z, const int32_t* labels, int32_t k,
                             unsigned long long* count, void* ws, size_t ws_bytes, void* stream);
+/* The same search with the Gram product Z Z^T in the given arithmetic (SSV_ARITH_F32_MFMA | SSV_ARITH_BF16X3; widths without a bf16-piece kernel - d % 32 != 0 - run on
+ * fp32 MFMA either way).  Workspace: ssv_knn_workspace_bytes_arith(n, d, arithmetic) (the bf16x3 form also holds the three planes of z). */
+size_t ssv_knn_workspace_bytes_arith(int64_t n, int32_t d, int32_t arithmetic);
+int ssv_knn_label_agreement_arith(int64_t n, int32_t d, const float* z, const int32_t* labels, int32_t k,
+                                  unsigned long long* count, int32_t arithmetic, void* ws, size_t ws_bytes, void* stream);
 
 /* ==== "next" row 1 of the scope table: DINO on the reference's ViT (networks/vit.py, models/dino.py) ====================
  * Linear layers of the encoder and of the projection head are ssv_conv2d_fwd/dgrad/wgrad with H = W = R = S = 1 over

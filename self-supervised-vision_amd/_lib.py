@@ -152,6 +152,8 @@ SIGNATURES = {
     "ssv_center_view": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _f3, _f3, _vp, _vp]),
     "ssv_knn_workspace_bytes": (_sz, [_i64]),
     "ssv_knn_label_agreement": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "ssv_knn_workspace_bytes_arith": (_sz, [_i64, _i32, _i32]),
+    "ssv_knn_label_agreement_arith": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _sz, _vp]),
     "ssv_vit_embed_fwd": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ssv_vit_embed_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ssv_layernorm_fwd": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),

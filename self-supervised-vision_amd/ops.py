@@ -799,8 +799,9 @@ def knn_label_agreement(z, labels, k):
         d = z.shape[1]
     z = z.contiguous()
     count = torch.empty((1,), dtype=torch.int64, device=z.device)
-    ws = torch.empty(_lib.load().ssv_knn_workspace_bytes(n), dtype=torch.uint8, device=z.device)    # up to ~1 GB: not kept in the training scratch
-    call("ssv_knn_label_agreement", n, d, ptr(z), ptr(labels), int(k), ptr(count), ptr(ws), ws.numel(), stream())
+    arith = _lib.ARITH_BF16X3 if ARITHMETIC == "bf16x3" else _lib.ARITH_F32_MFMA
+    ws = torch.empty(_lib.load().ssv_knn_workspace_bytes_arith(n, d, arith), dtype=torch.uint8, device=z.device)    # up to ~1 GB: not kept in the training scratch
+    call("ssv_knn_label_agreement_arith", n, d, ptr(z), ptr(labels), int(k), ptr(count), arith, ptr(ws), ws.numel(), stream())
     return int(count.item())
 
 

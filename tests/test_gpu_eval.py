@@ -34,6 +34,49 @@ def test_knn_counts_bit_exact_on_exactly_representable_scores(dev):
         assert ops.knn_label_agreement(z.to(dev), labels.to(dev), k) == want, (n, d, k)
 
 
+@pytest.mark.parametrize("n,d,k", [(21, 32, 20), (65, 64, 20), (300, 128, 20), (1000, 32, 7), (4100, 64, 20), (4100, 128, 1), (12000, 32, 20), (9000, 128, 20)])
+def test_fused_knn_counts_bit_exact_on_exactly_representable_scores(dev, n, d, k):
+    """The search fused into the bf16x3 Gram product (d in {32, 64, 128}, k <= 20; csrc/evalknn.hip knn_fused_k, one part up to the merge of several column parts at the
+    larger n): small-integer features make every score exact and full of ties, so the count is fully determined by value-descending / index-ascending order."""
+    from ssv_amd import ops
+    g = torch.Generator().manual_seed(n + d + k)
+    z = torch.randint(-2, 3, (n, d), generator=g).float()
+    labels = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32)
+    want = evalknn.neighbor_agreement_count(z.numpy(), labels.numpy(), k)
+    with ops.arithmetic("bf16x3"):
+        assert ops.knn_label_agreement(z.to(dev), labels.to(dev), k) == want
+    with ops.arithmetic("f32"):
+        assert ops.knn_label_agreement(z.to(dev), labels.to(dev), k) == want
+
+
+def test_fused_knn_all_scores_equal_and_duplicates(dev):
+    """Every score the same (identical features): the neighbours of every query are the lowest indices, and the best hit dropped is index 0 - not the query."""
+    from ssv_amd import ops
+    n, d, k = 700, 64, 20
+    z = torch.ones(n, d)
+    labels = (torch.arange(n) % 3).to(torch.int32)
+    want = evalknn.neighbor_agreement_count(z.numpy(), labels.numpy(), k)
+    assert ops.knn_label_agreement(z.to(dev), labels.to(dev), k) == want
+
+
+def test_fused_knn_agrees_with_the_unfused_search_on_unit_features(dev):
+    """Random unit features (the reference's input, proj_dim 128): the fused bf16x3 search, the fp32-MFMA Gram + selection and the fp64 oracle give the same count up to
+    rounding-level near-ties at the 21st place (a handful in n k = 10^5 pairs)."""
+    from ssv_amd import ops
+    n, d, k = 5000, 128, 20
+    g = torch.Generator().manual_seed(77)
+    z = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    labels = torch.randint(0, 10, (n,), generator=g, dtype=torch.int32)
+    want = evalknn.neighbor_agreement_count(z.numpy(), labels.numpy(), k)
+    with ops.arithmetic("bf16x3"):
+        fused = ops.knn_label_agreement(z.to(dev), labels.to(dev), k)
+        again = ops.knn_label_agreement(z.to(dev), labels.to(dev), k)
+    with ops.arithmetic("f32"):
+        unfused = ops.knn_label_agreement(z.to(dev), labels.to(dev), k)
+    assert fused == again                               # appends in a fixed order: reproducible
+    assert abs(fused - want) <= 4 and abs(unfused - want) <= 4, (fused, unfused, want)
+
+
 def test_knn_large_set_multi_chunk_property(dev):
     """n above one S chunk (4096 rows): planted duplicates - every vector appears exactly twice with the same label and is far
     from everything else, so with k=1 (after dropping the best hit) the agreement count is exactly n."""

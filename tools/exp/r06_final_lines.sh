@@ -16,5 +16,5 @@ d = json.load(open("gpurun_out/${L}_bench_simclr.json"))
 print("config3", {k: d["config3_rank_emulation"].get(k) for k in ("ms_per_step", "compute_side_scaling_ceiling")})
 print("other", {k: (v.get("value"), v.get("pass"), v.get("leg_seconds")) for k, v in d["other_configs"].items()})
 print("config1", d["config1"]["gpu"]["value"], d["config1"]["gpu"]["ms_per_step"], d["config1"]["cpu"]["value"], d["config1"]["loss_step0"])
-print("knn", d["eval_knn"]["ms_per_call"], d["eval_knn"]["gram"], d["eval_knn"]["selection"])
+print("knn", {k: d["eval_knn"].get(k) for k in ("ms_per_call", "kernel_ms", "tflops", "frac", "speedup_vs_unfused", "count_difference_vs_unfused")}, d["eval_knn"].get("unfused_fp32_path"))
 PY
