@@ -333,6 +333,8 @@ static int choose_parts(int64_t n) {
   return (int)(p < 1 ? 1 : p > 8 ? 8 : p);
 }
 }  // namespace fused
+using fused::knn_finish_k;
+using fused::knn_fused_k;
 
 // ---- linear probe: NLLLoss(log_softmax(logits)) + accuracy (utils/eval_utils.py:52-54), one wavefront per row ----------------
 // stats[0] += sum of per-row losses, stats[1] += number of rows whose arg-max is the label; dlogits = (softmax - onehot) * gscale
@@ -427,10 +429,10 @@ extern "C" int ssv_knn_label_agreement_arith(int64_t n, int32_t d, const float* 
     ProfScope ps(SSV_PROF_MISC, s);
     hipLaunchKernelGGL(zero_count_k, dim3(1), dim3(1), 0, s, count);
     const dim3 grid((unsigned)cdiv64(n, 128), (unsigned)parts);
-    if (d == 128) hipLaunchKernelGGL(fused::knn_fused_k<128>, grid, dim3(256), 0, s, z, (int)n, cpp, pv, pi);
-    else if (d == 64) hipLaunchKernelGGL(fused::knn_fused_k<64>, grid, dim3(256), 0, s, z, (int)n, cpp, pv, pi);
-    else hipLaunchKernelGGL(fused::knn_fused_k<32>, grid, dim3(256), 0, s, z, (int)n, cpp, pv, pi);
-    hipLaunchKernelGGL(fused::knn_finish_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, (int)n, parts, (const float*)pv, (const int*)pi, labels, k, count);
+    if (d == 128) hipLaunchKernelGGL(knn_fused_k<128>, grid, dim3(256), 0, s, z, (int)n, cpp, pv, pi);
+    else if (d == 64) hipLaunchKernelGGL(knn_fused_k<64>, grid, dim3(256), 0, s, z, (int)n, cpp, pv, pi);
+    else hipLaunchKernelGGL(knn_fused_k<32>, grid, dim3(256), 0, s, z, (int)n, cpp, pv, pi);
+    hipLaunchKernelGGL(knn_finish_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, (int)n, parts, (const float*)pv, (const int*)pi, labels, k, count);
     SSV_CHECK_LAUNCH("knn_fused_k");
     return SSV_OK;
   }

@@ -19,7 +19,7 @@ CLASSES = (
     ("loss", "ce_reduce_k"), ("loss", "negdot_pair_k"), ("loss", "finish_sum_k"), ("loss", "relic_"), ("loss", "moco_"),
     ("optim", "sgd_"), ("optim", "adamw_k"), ("optim", "adamw_tick_k"), ("optim", "ema_k"), ("aug", "aug_"), ("aug", "multicrop"), ("aug", "center_view_k"),
     ("pool", "maxpool_"), ("pool", "gap_"),
-    ("misc", "gelu_"), ("misc", "colsum_"), ("misc", "wn_fwd_k"), ("misc", "wn_bwd_k"), ("misc", "knn_agree_k"), ("misc", "zero_count_k"), ("misc", "scale_k"), ("misc", "add_k"),
+    ("misc", "gelu_"), ("misc", "colsum_"), ("misc", "wn_fwd_k"), ("misc", "wn_bwd_k"), ("misc", "knn_agree_k"), ("misc", "knn_fused_k"), ("misc", "knn_finish_k"), ("misc", "zero_count_k"), ("misc", "scale_k"), ("misc", "add_k"),
     ("misc", "fill_k"), ("misc", "pad_channels_k"), ("misc", "group_expand_k"), ("misc", "group_extract_k"), ("misc", "filter_transpose_k"), ("misc", "nchw_to_nhwc_k"),
     ("misc", "nhwc_to_nchw_k"), ("misc", "queue_push_k"), ("misc", "queue_advance_k"), ("misc", "vit_embed_"), ("misc", "split_planes_k"),
 )
