@@ -469,17 +469,19 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
         wino_v = y.__dict__.pop("_wino_v", None)       # Winograd forward: its transformed input is the weight gradient's operand
 
         def bwd(dy, existing):
+            # x is the output of a BatchNorm + ReLU and nothing else will add to its gradient: gate + reduce in the data gradient's epilogue
+            gate = getattr(x, "_bn_gate", None) if (need_dx and tape.last[0] and _FUSE_BN_BWD) else None
+            # will the data gradient take the plain Winograd path (ops.conv2d_dgrad: no addend, no second gate target)?  Only then does the Winograd dY transform
+            # of the weight gradient also write the data gradient's transformed operand (2.25x dY) - otherwise it would be written for nothing and live as long as dy
+            plain_dgrad = need_dx and existing[0] is None and (gate is None or getattr(gate, "x2", None) is None)
             ops.conv2d_wgrad(src, dy, weight, grad_of(weight, slot), stride, pad, accumulate=True, in_affine=affine, wino_v=wino_v,
-                             dbias=None if bias is None else grad_of(bias, slot),
-                             dgrad_follows=need_dx and existing[0] is None)      # a plain data gradient follows: the Winograd dY transform writes its operand too
+                             dbias=None if bias is None else grad_of(bias, slot), dgrad_follows=plain_dgrad)
             if not need_dx:
                 return (None,)
             ex = existing[0]
             if (compact_dx and _COMPACT_S2_DGRAD and _FUSE_BN_BWD and ex is None and not tape.last[0] and stride == 2 and pad == 0
                     and weight.shape[2] == 1 and weight.shape[3] == 1 and not isinstance(dy, ops.LazyGrad)):
                 return (ops.compact_s2_dgrad(dy, weight, src.shape),)
-            # x is the output of a BatchNorm + ReLU and nothing else will add to its gradient: gate + reduce in this epilogue
-            gate = getattr(x, "_bn_gate", None) if (tape.last[0] and _FUSE_BN_BWD) else None
             dx = ops.conv2d_dgrad(dy, weight, src.shape, stride, pad, addend=ex, out=ex, gate=gate)
             return (dx,)
         tape.record((x,), y, bwd)

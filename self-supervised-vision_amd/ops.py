@@ -1136,7 +1136,9 @@ def use_winograd(wshape, stride, pad, x_shape, want_stats):
         return False
     n, h, w_ = x_shape[0], x_shape[1], x_shape[2]
     if min(c, k) < WINOGRAD_MIN_CHANNELS:          # narrow layers: only where every product runs F(4x4) (forward / data / weight gradient share the 0.75 ratio rule)
-        if not (min(c, k) >= WINOGRAD44_MIN_CHANNELS and WINOGRAD44_WGRAD and _use_wino44(n, h, w_, c, k, WINOGRAD44_MAX_RATIO_DGRAD)):
+        # (the forward's own ratio too: a narrow layer admitted on the data gradient's ratio alone would run its forward on F(2x2) when SSV_WINOGRAD44_FWD_RATIO is lowered)
+        if not (min(c, k) >= WINOGRAD44_MIN_CHANNELS and WINOGRAD44_WGRAD
+                and _use_wino44(n, h, w_, c, k, min(WINOGRAD44_MAX_RATIO_FWD_NO_V2, WINOGRAD44_MAX_RATIO_DGRAD))):
             return False
     t = n * ((h + 1) // 2) * ((w_ + 1) // 2)
     if t < WINOGRAD_MIN_TILES or t * max(c, k) >= _MAX_ELEMS:
