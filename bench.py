@@ -588,6 +588,9 @@ def _config1_views(device, batch):
     return views[0], views[1]
 
 
+GRAPH_WARM_REPLAYS = 20
+
+
 def config1_hip(device, batch=64, gpu_steps=50, graph=True):
     """The HIP side of config 1: step-0 loss, `gpu_steps` timed eager steps, then (graph=True) the same trainer's step() replayed as one HIP graph."""
     v1, v2 = _config1_views(device, batch)
@@ -605,14 +608,14 @@ def config1_hip(device, batch=64, gpu_steps=50, graph=True):
     if graph:
         # the same trainer's step through TwoViewTrainer.step: replayed as ONE HIP graph at this size (ssv_amd.graph.StepGraph, SSV_STEP_GRAPH=auto)
         t = hip_step.trainer
-        for _ in range(3):
-            t.step({"aug_1": v1, "aug_2": v2})
+        for _ in range(3 + GRAPH_WARM_REPLAYS):                       # two eager steps, the capture, then untimed replays: the first replays after a capture run
+            t.step({"aug_1": v1, "aug_2": v2})                        # 5-10 % slower than the steady state a training run sits in (tools/exp/r06_cifar_graph_floors.py)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(gpu_steps):
+        for _ in range(2 * gpu_steps):
             t.step({"aug_1": v1, "aug_2": v2})
         torch.cuda.synchronize()
-        res["graph_dt"] = (time.perf_counter() - t0) / gpu_steps
+        res["graph_dt"] = (time.perf_counter() - t0) / (2 * gpu_steps)
         res["step_graph"] = t._step_graph.describe()
     return res
 
@@ -651,8 +654,8 @@ def config1_line(device, batch=64, cpu_steps=10, gpu_steps=50):
     if hip["graph_dt"] is not None:
         gpu_dt = hip["graph_dt"]
         gpu = {"value": round(batch / gpu_dt, 1), "unit": "images/sec", "ms_per_step": round(gpu_dt * 1e3, 3),
-               "sample": f"{gpu_steps} timed steps of the HIP trainer's step() on the same views, loss read every step: the step replayed as one HIP graph "
-                         "(ssv_amd.graph.StepGraph; ~490 launches whose host enqueue time equals the GPU's work at this size); measured in a child process",
+               "sample": f"{2 * gpu_steps} timed steps (after {GRAPH_WARM_REPLAYS} untimed replays) of the HIP trainer's step() on the same views, loss read every step: the step replayed as one HIP graph "
+                         "(ssv_amd.graph.StepGraph; ~640 launches whose host enqueue time equals the GPU's work at this size); measured in a child process",
                "step_graph": hip["step_graph"], "eager": eager}
     else:
         gpu = dict(eager, unit="images/sec", step_graph={"error": child_error})
