@@ -81,14 +81,27 @@ rows, tot = [], {}
 hdr = ["layer", "count", "HxW", "C", "K", "RxS", "stride", "GFLOP", "fwd_variant", "fwd_ms", "fwd_TF", "fwd_wgs", "fwd_waves768",
        "dgrad_variant", "dgrad_ms", "dgrad_TF", "dgrad_wgs", "wgrad_variant", "wgrad_ms", "wgrad_TF",
        "fwd_GB", "fwd_TBs", "fwd_frac", "dgrad_GB", "dgrad_TBs", "dgrad_frac", "wgrad_GB", "wgrad_TBs", "wgrad_frac"]
-MFMA_PEAK, HBM_PEAK = 157.3e12, 6.29e12      # fp32 MFMA dense; HBM achievable (MI355X_MICROARCH.md): a layer's own bound = max(FLOP / MFMA_PEAK, bytes / HBM_PEAK)
+# a layer's own bound = max(FLOP / matrix-pipe peak of the arithmetic the launch runs on, bytes / HBM achievable) (MI355X_MICROARCH.md): fp32 MFMA dense 157.3 TFLOP/s;
+# SSV_ARITH_BF16X3 (round 6): dense bf16 2,500 TFLOP/s / 6 piece products per fp32 product = 416.7 TFLOP/s of fp32 products
+FP32_PEAK, BF16X3_PEAK, HBM_PEAK = 157.3e12, 2500e12 / 6, 6.29e12
 
 
-def roof(flop, nbytes, ms):
+def pipe_peak(x_shape, w_shape, stride, pad, product):
+    """The roof of the pipe this product of this layer runs on: asks the library (ssv_conv_arithmetic) what the descriptor the step builds will run."""
+    if ops.ARITHMETIC != "bf16x3" or w_shape[1] == 3:
+        return FP32_PEAK
+    import ctypes
+    d = ops.conv_desc(tuple(x_shape), tuple(w_shape), stride, pad)
+    d.arithmetic = _lib.ARITH_BF16X3
+    d.w_planes = 16                                            # any non-null address: the query does not dereference it
+    return BF16X3_PEAK if _lib.load().ssv_conv_arithmetic(ctypes.byref(d), product) == _lib.ARITH_BF16X3 else FP32_PEAK
+
+
+def roof(flop, nbytes, ms, peak):
     """(GB moved when every operand stream of the variant is moved exactly once, TB/s achieved, fraction of the layer's own roofline bound)."""
     if ms != ms:
         return "", "", ""
-    bound = max(flop / MFMA_PEAK, nbytes / HBM_PEAK)
+    bound = max(flop / peak, nbytes / HBM_PEAK)
     return round(nbytes / 1e9, 2), round(nbytes / (ms * 1e-3) / 1e12, 2), round(bound / (ms * 1e-3), 3)
 
 print(f"ResNet-50 @224, batch {B} per view, {REP} repeats")
@@ -190,19 +203,20 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
         by_d += xin if addend is not None else 0                                 # residual gradient read
         by_d += xin + (n_in * Cx / 4 if not lazy_in else 0)                      # gate: the BatchNorm input (+ byte mask)
     tf = lambda t: flop / (t * 1e-3) / 1e12
+    peaks = [pipe_peak(x.shape, w.shape, s, p, q) for q in range(3)]
     wgs = grid_fwd(m, K)
     row = [name, cnt, f"{H}x{H}", C, K, f"{R}x{R}", s, round(flop / 1e9, 1), fv, round(t_f, 3), round(tf(t_f), 1), wgs, round(wgs / 768, 2),
            dv, round(t_d, 3), round(tf(t_d), 1) if t_d == t_d else "", dwgs, wv, round(t_w, 3), round(tf(t_w), 1),
-           *roof(flop, by_f, t_f), *roof(flop, by_d, t_d), *roof(flop, by_w, t_w)]
+           *roof(flop, by_f, t_f, peaks[0]), *roof(flop, by_d, t_d, peaks[1]), *roof(flop, by_w, t_w, peaks[2])]
     rows.append(row)
     print(" ".join(f"{str(v):>13s}" for v in row), flush=True)
-    for k, t, nb in (("fwd", t_f, by_f), ("dgrad", t_d, by_d), ("wgrad", t_w, by_w)):
+    for k, t, nb, pk in (("fwd", t_f, by_f, peaks[0]), ("dgrad", t_d, by_d, peaks[1]), ("wgrad", t_w, by_w, peaks[2])):
         if t == t:
             a = tot.setdefault(k, [0.0, 0.0, 0.0, 0.0])
             a[0] += t * cnt
             a[1] += flop * cnt
             a[2] += nb * cnt
-            a[3] += max(flop / MFMA_PEAK, nb / HBM_PEAK) * 1e3 * cnt
+            a[3] += max(flop / pk, nb / HBM_PEAK) * 1e3 * cnt
     del x, y, dy, w, dw
 for k, (t, f, nb, bound) in tot.items():
     print(f"total {k:6s}: {t:8.2f} ms per view  {f / (t * 1e-3) / 1e12:6.1f} TFLOP/s  {nb / 1e9:7.2f} GB of operand streams  {nb / (t * 1e-3) / 1e12:5.2f} TB/s  "
