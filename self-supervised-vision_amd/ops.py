@@ -1120,7 +1120,16 @@ WINOGRAD_MIN_CHANNELS = int(os.environ.get("SSV_WINOGRAD_MIN_CHANNELS", "128"))
 # Round 5: that verdict was F(2x2)'s.  With all three products on F(4x4) (2.25x instead of 4x transformed tensors, no second transformed input, one pass over dY) the
 # 64-channel 3x3 layers of layer1 (56x56) win too: same-box A/B 215.9 -> 210.7 ms per step (profiles/r05_probe_wino64_step_ab.txt).  Narrower layers than
 # WINOGRAD_MIN_CHANNELS therefore take Winograd from this width on - but only where F(4x4) is what runs (`_use_wino44`), never F(2x2).
-WINOGRAD44_MIN_CHANNELS = int(os.environ.get("SSV_WINOGRAD44_MIN_CHANNELS", "64"))
+# Round 6: on the bf16x3 arithmetic the direct product is 1.4x cheaper and the verdict flips back - the three 64-channel layers on the direct kernels: +0.5 % images/s
+# and 707 -> 654 GB of HBM traffic per step (same box, alternating, profiles/r06_probe_wino_floor_traffic.txt; the 128-channel layers direct as well: 625 GB but
+# -1.7 %).  Default therefore by arithmetic: 128 on bf16x3, 64 on fp32 MFMA; SSV_WINOGRAD44_MIN_CHANNELS=<n> overrides both.
+WINOGRAD44_MIN_CHANNELS = int(os.environ["SSV_WINOGRAD44_MIN_CHANNELS"]) if os.environ.get("SSV_WINOGRAD44_MIN_CHANNELS") else None
+
+
+def _wino44_min_channels():
+    return WINOGRAD44_MIN_CHANNELS if WINOGRAD44_MIN_CHANNELS is not None else (128 if ARITHMETIC == "bf16x3" else 64)
+
+
 WINOGRAD_MIN_TILES = int(os.environ.get("SSV_WINOGRAD_MIN_TILES", "256"))     # below that the three launches cost more than they save
 
 
@@ -1137,7 +1146,7 @@ def use_winograd(wshape, stride, pad, x_shape, want_stats):
     n, h, w_ = x_shape[0], x_shape[1], x_shape[2]
     if min(c, k) < WINOGRAD_MIN_CHANNELS:          # narrow layers: only where every product runs F(4x4) (forward / data / weight gradient share the 0.75 ratio rule)
         # (the forward's own ratio too: a narrow layer admitted on the data gradient's ratio alone would run its forward on F(2x2) when SSV_WINOGRAD44_FWD_RATIO is lowered)
-        if not (min(c, k) >= WINOGRAD44_MIN_CHANNELS and WINOGRAD44_WGRAD
+        if not (min(c, k) >= _wino44_min_channels() and WINOGRAD44_WGRAD
                 and _use_wino44(n, h, w_, c, k, min(WINOGRAD44_MAX_RATIO_FWD_NO_V2, WINOGRAD44_MAX_RATIO_DGRAD))):
             return False
     t = n * ((h + 1) // 2) * ((w_ + 1) // 2)

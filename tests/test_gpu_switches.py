@@ -18,7 +18,7 @@ SWITCHES = [
     ("SSV_SINGLE_STREAM", "1"),
     ("SSV_NO_WINOGRAD", "1"), ("SSV_WINOGRAD_MIN_CHANNELS", "64"), ("SSV_WINOGRAD_MIN_TILES", "16"),
     ("SSV_WINOGRAD44", "0"), ("SSV_WINOGRAD44_WGRAD", "0"), ("SSV_WINOGRAD44_WGRAD_CHUNK", "0"), ("SSV_WINOGRAD44_WGRAD_FLUSH", "0"), ("SSV_WINOGRAD44_FWD_RATIO", "0.6"),
-    ("SSV_WINOGRAD44_DY_BOTH", "0"), ("SSV_WINOGRAD44_MIN_TILES", "16"), ("SSV_WINOGRAD44_MIN_CHANNELS", "128"), ("SSV_WINOGRAD_KEEP_V", "0"),
+    ("SSV_WINOGRAD44_DY_BOTH", "0"), ("SSV_WINOGRAD44_MIN_TILES", "16"), ("SSV_WINOGRAD44_MIN_CHANNELS", "64"), ("SSV_WINOGRAD_KEEP_V", "0"),
     ("SSV_NO_NARROW_WINO_INPUT_FUSION", "1"),
     ("SSV_NTXENT_SPLITS", "1"),
     ("SSV_STEP_GRAPH", "0"),

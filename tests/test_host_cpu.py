@@ -148,14 +148,27 @@ def test_dispatch_predicates_of_the_round3_paths():
     assert wino(128, 128, 3, 1, 1, (512, 28, 28, 128)) and wino(256, 256, 3, 1, 1, (512, 14, 14, 256)) and wino(512, 512, 3, 1, 1, (512, 7, 7, 512))
     # layer1 (64 channels): F(2x2) measured slower (profiles/r03_probe_winograd.txt) - it runs Winograd only where ALL products take F(4x4) (round 5: enough
     # tiles, the weight gradient on F(4x4)), never F(2x2)
-    assert wino(64, 64, 3, 1, 1, (512, 56, 56, 64)) and not wino(64, 64, 3, 1, 1, (4, 56, 56, 64)) and not wino(32, 32, 3, 1, 1, (512, 56, 56, 32))
-    for name, off in (("WINOGRAD44", False), ("WINOGRAD44_WGRAD", False), ("WINOGRAD44_MIN_CHANNELS", 128)):
-        keep = getattr(ops, name)
-        setattr(ops, name, off)
-        try:
-            assert not wino(64, 64, 3, 1, 1, (512, 56, 56, 64)), name
-        finally:
-            setattr(ops, name, keep)
+    # ... and (round 6) only on the fp32-MFMA arithmetic: on bf16x3 the direct product of those layers is faster and moves fewer bytes
+    # (profiles/r06_probe_wino_floor_traffic.txt), unless SSV_WINOGRAD44_MIN_CHANNELS says otherwise
+    keep_arith, keep_floor = ops.ARITHMETIC, ops.WINOGRAD44_MIN_CHANNELS
+    try:
+        ops.WINOGRAD44_MIN_CHANNELS = None
+        ops.ARITHMETIC = "bf16x3"
+        assert not wino(64, 64, 3, 1, 1, (512, 56, 56, 64)) and wino(128, 128, 3, 1, 1, (512, 28, 28, 128))
+        ops.WINOGRAD44_MIN_CHANNELS = 64
+        assert wino(64, 64, 3, 1, 1, (512, 56, 56, 64))
+        ops.WINOGRAD44_MIN_CHANNELS = None
+        ops.ARITHMETIC = "f32"
+        assert wino(64, 64, 3, 1, 1, (512, 56, 56, 64)) and not wino(64, 64, 3, 1, 1, (4, 56, 56, 64)) and not wino(32, 32, 3, 1, 1, (512, 56, 56, 32))
+        for name, off in (("WINOGRAD44", False), ("WINOGRAD44_WGRAD", False), ("WINOGRAD44_MIN_CHANNELS", 128)):
+            keep = getattr(ops, name)
+            setattr(ops, name, off)
+            try:
+                assert not wino(64, 64, 3, 1, 1, (512, 56, 56, 64)), name
+            finally:
+                setattr(ops, name, keep)
+    finally:
+        ops.ARITHMETIC, ops.WINOGRAD44_MIN_CHANNELS = keep_arith, keep_floor
     assert not wino(128, 128, 3, 2, 1, (512, 56, 56, 128))         # stride 2
     assert not wino(128, 128, 1, 1, 0, (512, 28, 28, 128))         # 1x1
     assert not wino(128, 128, 3, 1, 1, (2, 8, 8, 128))             # 32 tiles: not worth three extra launches
