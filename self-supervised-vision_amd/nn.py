@@ -998,6 +998,11 @@ class HipModule(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------- parameter holders
+# Round 6: on the bf16x3 arithmetic a narrow k x k layer (fewer than 128 output channels: layer1's 3x3) takes the 128 x 64 tile, not the fp32 variants' 256 x 64, and
+# is bound by bytes - its input BatchNorm + ReLU formed on load pays there too: +0.6 % images/s, -5.6 GB per step (profiles/r06_probe_narrow_fuse.txt)
+_FUSE_NARROW_3X3 = os.environ.get("SSV_NO_NARROW_3X3_INPUT_FUSION", "0") != "1"
+
+
 class HipConv2d(HipModule):
     """Bias-free convolution; ``weight`` is [O,I,k,k] in channels_last (OHWI) memory."""
 
@@ -1017,8 +1022,9 @@ class HipConv2d(HipModule):
         # a k x k filter re-stages (and re-transforms) every input element k*k times: with the 256 x 64 tile of narrow layers (cout < 128,
         # twice the staged A rows per thread) that VALU work costs more than the apply pass it saves (measured: layer1's 3x3 forward at
         # 99 TFLOP/s fused against 116 on a materialised input, profiles/r02_*_conv_layers_*.csv); wider layers keep the fusion - and so do narrow ones that
-        # run Winograd (round 5): the input transform forms BatchNorm + ReLU once per loaded element, whatever the filter size
-        if self.weight.shape[2] > 1 and (not _FUSE_BN_APPLY_3X3 or self.weight.shape[0] < 128):
+        # run Winograd (round 5): the input transform forms BatchNorm + ReLU once per loaded element, whatever the filter size - and, round 6, narrow ones on
+        # the bf16x3 arithmetic (_FUSE_NARROW_3X3 above)
+        if self.weight.shape[2] > 1 and (not _FUSE_BN_APPLY_3X3 or (self.weight.shape[0] < 128 and not (_FUSE_NARROW_3X3 and ops.ARITHMETIC == "bf16x3"))):
             if not (_FUSE_BN_APPLY_3X3 and _FUSE_NARROW_WINO and x_shape is not None and self.groups == 1
                     and ops.use_winograd(tuple(self.weight.shape), self.stride, self.pad, tuple(x_shape), True)):
                 return False

@@ -19,7 +19,7 @@ SWITCHES = [
     ("SSV_NO_WINOGRAD", "1"), ("SSV_WINOGRAD_MIN_CHANNELS", "64"), ("SSV_WINOGRAD_MIN_TILES", "16"),
     ("SSV_WINOGRAD44", "0"), ("SSV_WINOGRAD44_WGRAD", "0"), ("SSV_WINOGRAD44_WGRAD_CHUNK", "0"), ("SSV_WINOGRAD44_WGRAD_FLUSH", "0"), ("SSV_WINOGRAD44_FWD_RATIO", "0.6"),
     ("SSV_WINOGRAD44_DY_BOTH", "0"), ("SSV_WINOGRAD44_MIN_TILES", "16"), ("SSV_WINOGRAD44_MIN_CHANNELS", "64"), ("SSV_WINOGRAD_KEEP_V", "0"),
-    ("SSV_NO_NARROW_WINO_INPUT_FUSION", "1"),
+    ("SSV_NO_NARROW_WINO_INPUT_FUSION", "1"), ("SSV_NO_NARROW_3X3_INPUT_FUSION", "1"),
     ("SSV_NTXENT_SPLITS", "1"),
     ("SSV_STEP_GRAPH", "0"),
     ("SSV_NO_BN_STATS_FUSION", "1"), ("SSV_NO_BN_APPLY_FUSION", "1"), ("SSV_NO_BN_APPLY_FUSION_3X3", "1"), ("SSV_NO_BN_BWD_FUSION", "1"),
@@ -41,7 +41,7 @@ RESNEXT = "tests/test_gpu_step.py::test_resnext50_grouped_convs_match_reference"
 # which golden bodies a switch can change (every child runs the r18 body; a second body only where the switch's kernels are not in resnet18 / 32 x 32)
 EXTRA = {**{n: [R50] for n in ("SSV_ARITHMETIC", "SSV_NO_BN_APPLY_FUSION", "SSV_NO_BN_DY_FUSION", "SSV_BN_DY_MIN_HW", "SSV_BN_DY_MIN_K", "SSV_NO_CLOSING_FUSION", "SSV_CLOSING_HW",
                                  "SSV_NO_SHORTCUT_GATE", "SSV_NO_POOLED_STEM_REDUCE", "SSV_NO_STEM_POOL_FUSION", "SSV_NO_ROW_STEM", "SSV_NO_STEM_PADDING",
-                                 "SSV_NO_COMPACT_S2_DGRAD", "SSV_NO_BN_BWD_FUSION")},
+                                 "SSV_NO_COMPACT_S2_DGRAD", "SSV_NO_BN_BWD_FUSION", "SSV_NO_NARROW_3X3_INPUT_FUSION", "SSV_WINOGRAD44_MIN_CHANNELS")},
          "SSV_NO_GELUGRAD_FWD_KERNEL": [DINO], "SSV_NO_GELU_DACT": [DINO], "SSV_NO_BIAS_GRAD_FUSION": [DINO], "SSV_NO_GROUP_AWARE_TILES": [RESNEXT]}
 
 
