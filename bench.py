@@ -78,7 +78,7 @@ def arithmetic_block(device):
             "switch": "SSV_ARITHMETIC=f32 runs every product on v_mfma_f32_32x32x2_f32 (the arithmetic of rounds 1-5): the fp32_mfma_instruction_path leg of this line"}
 
 
-def eval_knn_leg(device, n=50000, d=128, k=20, reps=3):
+def eval_knn_leg(device, n=50000, d=128, k=20, reps=10):
     """The reference's kNN evaluation (utils/eval_utils.py:13-21: compute_neighbor_accuracy, k + 1 exact inner-product hits, best dropped) at CIFAR-10's train-set
     size on projected features of BASELINE's width.  Shipped: ONE fused launch (csrc/evalknn.hip knn_fused_k: the Gram product Z Z^T on the bf16x3 arithmetic with a
     streaming top-21 per query on its accumulators - S is never written) + a merge of the column parts.  Beside it, in the same run, the round-3..5 form
@@ -90,7 +90,8 @@ def eval_knn_leg(device, n=50000, d=128, k=20, reps=3):
     labels = torch.randint(0, 10, (n,), device=device, generator=g, dtype=torch.int32)
 
     def timed():
-        count = ops.knn_label_agreement(z, labels, k)
+        for _ in range(3):                                    # the first calls of a form run below the clock the following ones hold
+            count = ops.knn_label_agreement(z, labels, k)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -113,7 +114,7 @@ def eval_knn_leg(device, n=50000, d=128, k=20, reps=3):
            "form": "fused Gram + top-21 (S never written)" if fused else "Gram on the GEMM kernel, S written, one-wavefront-per-query selection",
            "kernel_ms": round(kern_ms, 3), "algorithmic_gflop": round(gflop, 1), "tflops": round(gflop / kern_ms, 1),
            "roof_tflops": BF16X3_PEAK_TFLOPS if fused else FP32_MFMA_PEAK_TFLOPS, "frac": round(gflop / kern_ms / (BF16X3_PEAK_TFLOPS if fused else FP32_MFMA_PEAK_TFLOPS), 3),
-           "timing": "wall clock over %d calls; kernel_ms: HIP events per launch of one more call" % reps}
+           "timing": "wall clock over %d calls after 3 untimed ones; kernel_ms: HIP events per launch of one more call" % reps}
     if fused:
         with ops.arithmetic("f32"):
             count0, ms0, prof0 = timed()
