@@ -357,13 +357,29 @@ _FUSE_BN_DY = os.environ.get("SSV_NO_BN_DY_FUSION", "0") != "1"            # dia
 # ... for feature maps of at least this many pixels.  Forming dx on load costs the consumers a second operand stream and ~3 VALU per element
 # between their barriers; it pays where the removed pass is long (56x56 / 28x28 maps: 257.3 -> 254.6 ms per step at bs 512) and not on the
 # small deep maps (all layers: 256.9 ms) - measured with SSV_BN_DY_MIN_HW = 0 / 784 / 3136 / off, three runs each.
-_BN_DY_MIN_HW = int(os.environ.get("SSV_BN_DY_MIN_HW", "784"))
+# Round 6: on the bf16x3 arithmetic the consumers are bound by bytes, not by the matrix pipe, and the 14x14 maps pay too (re-measured with the traffic counters,
+# profiles/r06_probe_thresholds_traffic.txt: both thresholds at 196 +0.4 % images/s, 648 -> 640 GB per step, BatchNorm passes 20 -> 14 ms).  Default by
+# arithmetic: 196 on bf16x3, 784 on fp32 MFMA; SSV_BN_DY_MIN_HW=<pixels> overrides both (tests assign the module variable).
+_BN_DY_MIN_HW = int(os.environ["SSV_BN_DY_MIN_HW"]) if os.environ.get("SSV_BN_DY_MIN_HW") else None
+
+
+def _bn_dy_min_hw():
+    return _BN_DY_MIN_HW if _BN_DY_MIN_HW is not None else (196 if ops.ARITHMETIC == "bf16x3" else 784)
+
+
 _BN_DY_MIN_K = int(os.environ.get("SSV_BN_DY_MIN_K", "0"))                 # diagnostic: only convolutions with at least this many output channels
 _FUSE_CLOSING = os.environ.get("SSV_NO_CLOSING_FUSION", "0") != "1"        # diagnostic switch: the closing activation of a unit gets its own pass
 # ... on feature maps of [lo, hi] pixels.  Measured at bs 512 (three runs each, profiles/r02_experiments_step_time.txt exp12): off 252.8 ms, every
 # stage 250.3, the 56x56 / 28x28 stages only 249.8, the 14x14 / 7x7 stages only 252.4 - as for the BatchNorm-backward operand, the pass is
 # worth removing where it is long.
-_CLOSING_HW = tuple(int(v) for v in os.environ.get("SSV_CLOSING_HW", "784,1000000000").split(","))
+# (round 6, bf16x3: from 196 pixels - see _BN_DY_MIN_HW above)
+_CLOSING_HW = tuple(int(v) for v in os.environ["SSV_CLOSING_HW"].split(",")) if os.environ.get("SSV_CLOSING_HW") else None
+
+
+def _closing_hw():
+    return _CLOSING_HW if _CLOSING_HW is not None else ((196 if ops.ARITHMETIC == "bf16x3" else 784), 10 ** 9)
+
+
 _FUSE_SHORTCUT_GATE = os.environ.get("SSV_NO_SHORTCUT_GATE", "0") != "1"   # diagnostic switch: the projection shortcut's BatchNorm backward reduces in its own pass
 _FUSE_BN_APPLY_3X3 = os.environ.get("SSV_NO_BN_APPLY_FUSION_3X3", "0") != "1"   # diagnostic switch: fuse the input BatchNorm of 1x1 convolutions only
 _FUSE_NARROW_WINO = os.environ.get("SSV_NO_NARROW_WINO_INPUT_FUSION", "0") != "1"   # diagnostic switch: narrow (< 128 channels) Winograd layers get a materialised input
@@ -436,7 +452,7 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
     y = None
     if isinstance(x, LazySum):
         if (x.t is None and want and _FUSE_CLOSING and ops.can_form_closing_sum(weight.shape, stride, pad)
-                and _CLOSING_HW[0] <= x.shape[1] * x.shape[2] <= _CLOSING_HW[1]):
+                and _closing_hw()[0] <= x.shape[1] * x.shape[2] <= _closing_hw()[1]):
             y, part, a, mask = ops.conv2d_fwd_sumin(x.raw, x.res, x.scale, x.shift, x.res_affine, weight, want_mask=x.want_mask)
             x.set(a, mask)
             y._bn_partials = part
@@ -456,7 +472,7 @@ def conv(tape, x, weight, stride, pad, bias=None, bn_stats=False, compact_dx=Fal
             y._bn_partials = tuple(fused[1:])
         else:
             y = ops.conv2d_fwd(src, weight, stride, pad, bias=bias)
-    if (tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _BN_DY_MIN_HW
+    if (tape is not None and bias is None and _FUSE_BN_DY and ops.can_lazy_dy(weight.shape, stride, pad) and y.shape[1] * y.shape[2] >= _bn_dy_min_hw()
             and weight.shape[0] >= _BN_DY_MIN_K):
         y._lazy_dy_ok = True       # a BatchNorm behind this output may hand its backward over as an ops.LazyGrad (formed by wgrad / dgrad)
     if (tape is not None and lazy is not None and bias is None and _FUSE_BN_DY and _FUSE_BN_BWD

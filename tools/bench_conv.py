@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from ssv_amd import _lib, ops  # noqa: E402
+from ssv_amd import nn as hnn  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 REP = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -132,9 +133,9 @@ for (H, C, K, R, s, p, kind), (name, cnt) in resnet50_shapes().items():
     # k*k times costs more than the apply pass saves there): layer1's 3x3 runs the plain statistics variant, its gate reads the byte mask
     # ... unless that narrow layer runs Winograd (round 5: 64 channels on F(4x4)): its input transform forms BatchNorm + ReLU on load (nn.HipConv2d.can_fuse_input)
     lazy_in = kind == "lazy" and ops.can_fuse_conv_input(Cx, K) and (not (R > 1 and K < 128) or ops.use_winograd(tuple(w.shape), s, p, x.shape, True))
-    big = Ho * Ho >= 784
+    big = Ho * Ho >= hnn._bn_dy_min_hw()                       # the shipped threshold of the arithmetic in use (784 px on fp32 MFMA, 196 on bf16x3)
     dyl = ops.LazyGrad(dy, torch.randn_like(y), torch.randn(4, K, device=dev).contiguous()) if (big and C != 3 and ops.can_lazy_dy(w.shape, s, p)) else None
-    sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= 784 and ops.can_form_closing_sum(w.shape, s, p)
+    sum_in = "conv1" in name and name != "p64.0.conv1" and H * H >= hnn._closing_hw()[0] and ops.can_form_closing_sum(w.shape, s, p)
     if C == 3:
         # which stem kernels the library takes for this shape: asked of the library itself (rows-in-LDS from 224-pixel image rows, else the row-taps gather)
         import ctypes
