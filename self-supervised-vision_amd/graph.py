@@ -157,7 +157,8 @@ class StepGraph:
         opt = tuple(sorted((k, float(v) if isinstance(v, (int, float)) else tuple(float(x) for x in v)) for k, v in g.items()
                            if k in ("betas", "eps")))            # lr / weight decay / momentum are device memory (optim.push_hyper): not part of the key
         extra = tuple(self.trainer.graph_key()) if hasattr(self.trainer, "graph_key") else ()
-        return (tuple((k, tuple(t.shape), t.stride()) for k, t in sorted(ins.items())), opt, float(getattr(self.trainer.optim, "clip", 0.0)), extra)
+        # ... and the arithmetic: it selects kernels AND (round 6) dispatch thresholds, so a step captured under one never replays under the other (ops.arithmetic())
+        return (tuple((k, tuple(t.shape), t.stride()) for k, t in sorted(ins.items())), opt, float(getattr(self.trainer.optim, "clip", 0.0)), extra, ops.ARITHMETIC)
 
     # ---- the step ------------------------------------------------------------------------------------------------------------
     def __call__(self, batch):
