@@ -139,6 +139,27 @@ def test_batch_chunks_alignment_and_its_error():
         ops._batch_chunks(2, (lim + 5, 10))
 
 
+def test_dispatch_defaults_follow_the_arithmetic():
+    """Round 6: three dispatch decisions trade multiplies (or VALU work) for bytes and were re-measured on the bf16x3 arithmetic with the traffic counters
+    (profiles/r06_probe_wino_floor_traffic.txt, r06_probe_narrow_fuse.txt, r06_probe_thresholds_traffic.txt).  Their defaults follow ops.ARITHMETIC at CALL time -
+    bench.py's fp32-instruction leg switches it inside one process - and an explicit setting (environment variable / module variable) overrides both."""
+    from ssv_amd import nn as hnn
+    from ssv_amd import ops
+    keep = (ops.ARITHMETIC, ops.WINOGRAD44_MIN_CHANNELS, hnn._BN_DY_MIN_HW, hnn._CLOSING_HW)
+    try:
+        ops.WINOGRAD44_MIN_CHANNELS, hnn._BN_DY_MIN_HW, hnn._CLOSING_HW = None, None, None
+        ops.ARITHMETIC = "bf16x3"
+        assert (ops._wino44_min_channels(), hnn._bn_dy_min_hw(), hnn._closing_hw()) == (128, 196, (196, 10 ** 9))
+        ops.ARITHMETIC = "f32"
+        assert (ops._wino44_min_channels(), hnn._bn_dy_min_hw(), hnn._closing_hw()) == (64, 784, (784, 10 ** 9))
+        ops.WINOGRAD44_MIN_CHANNELS, hnn._BN_DY_MIN_HW, hnn._CLOSING_HW = 256, 0, (0, 100)
+        for a in ("bf16x3", "f32"):
+            ops.ARITHMETIC = a
+            assert (ops._wino44_min_channels(), hnn._bn_dy_min_hw(), hnn._closing_hw()) == (256, 0, (0, 100))
+    finally:
+        ops.ARITHMETIC, ops.WINOGRAD44_MIN_CHANNELS, hnn._BN_DY_MIN_HW, hnn._CLOSING_HW = keep
+
+
 def test_dispatch_predicates_of_the_round3_paths():
     """Host logic that decides which kernel family a layer runs on (no compute): Winograd F(2x2, 3x3) only for 3x3 / stride 1 / padding 1 layers with
     >= 128 channels on both sides and enough tiles (networks/resnet.py:7-10,56-58: conv2 of ten ResNet-50 units), the row-taps stem only for a
