@@ -1,12 +1,12 @@
 #!/bin/bash
 # r06: generic same-box A/B of environment switches on the headline step: images/s (alternating rounds) and HBM traffic per step (FETCH_SIZE / WRITE_SIZE passes).
-#   bash tools/exp/r06_env_ab.sh <rounds> "name1:ENV=V ENV2=V" "name2:..." ...      (a first configuration "shipped:SSV_X=0" is always added)
+#   [BENCH_EXTRA="--algo dino"] bash tools/exp/r06_env_ab.sh <rounds> "name1:ENV=V ENV2=V" "name2:..." ...      (a first configuration "shipped:SSV_X=0" is always added)
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out
 ROUNDS=$1; shift
-B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-arith-legs --prof-steps 1"
-PMCARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-arith-legs --prof-steps 0"
+B="python bench.py ${BENCH_EXTRA:-} --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-arith-legs --prof-steps 1"
+PMCARGS="bench.py ${BENCH_EXTRA:-} --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-arith-legs --prof-steps 0"
 CFGS=("shipped:SSV_X=0" "$@")
 for rnd in $(seq 1 $ROUNDS); do
   for c in "${CFGS[@]}"; do
@@ -15,8 +15,9 @@ for rnd in $(seq 1 $ROUNDS); do
     python - <<PY
 import json
 d = json.load(open("$OUT/_ab.json")); k = d["roofline"]["classes"]
-print("%-14s %8.2f images/s %8.3f ms/step  fwd %.1f dgrad %.1f wgrad %.1f bn %.1f ms" % ("$name", d["value"], d["ms_per_step"], k["conv_fwd"]["ms_per_step"], k["conv_dgrad"]["ms_per_step"],
-      k["conv_wgrad"]["ms_per_step"], k["bn_fwd"]["ms_per_step"] + k["bn_bwd"]["ms_per_step"]))
+ms = lambda c: k.get(c, {}).get("ms_per_step", 0.0)
+print("%-14s %8.2f images/s %8.3f ms/step  fwd %.1f dgrad %.1f wgrad %.1f bn %.1f attn %.1f norm %.1f ms" % ("$name", d["value"], d["ms_per_step"], ms("conv_fwd"), ms("conv_dgrad"),
+      ms("conv_wgrad"), ms("bn_fwd") + ms("bn_bwd"), ms("attn"), ms("norm")))
 PY
   done
 done
